@@ -1,0 +1,249 @@
+"""CPU: the oracle (oracle/) against the golden vectors generated from the reference
+(tests/golden/make_golden.py) and against closed-form known answers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import st_ito_oracle as O
+
+SR = 48000
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_g1_biquad_coefficients(golden_dir):
+    g = _g(golden_dir, "eq_biquad.npz")
+    kinds = ["low_shelf", "peaking", "high_shelf"]
+    import ctypes
+    for (k, gain, f, q), ba in zip(g["args"], g["ba"]):
+        b, a = O.biquad(gain, f, q, SR, kinds[int(k)])
+        np.testing.assert_array_equal(np.concatenate([b, a]), ba)
+        out = np.zeros(6)
+        O._lib().oracle_rbj_biquad(gain, f, q, float(SR), [0, 1, 2][int(k)],
+                                   out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        np.testing.assert_allclose(out, ba, rtol=1e-14, atol=1e-15)
+
+
+def test_g2_parametric_eq_bitexact(golden_dir):
+    g = _g(golden_dir, "eq_parametric.npz")
+    imp = np.zeros_like(g["noise"]); imp[0, 0] = 1.0
+    for p, yn, yi in zip(g["params"], g["y_noise"], g["y_impulse"]):
+        np.testing.assert_array_equal(O.parametric_eq_scipy(g["noise"], SR, p), yn)
+        np.testing.assert_array_equal(O.parametric_eq_scipy(imp, SR, p), yi)
+        # the C restatement may differ from scipy by float64 rounding of libm pow/sin/cos only
+        np.testing.assert_allclose(O.parametric_eq_c(g["noise"], SR, p), yn, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(O.parametric_eq_c(imp, SR, p), yi, rtol=2e-6, atol=1e-7)
+
+
+def _eq_plugins(n, bypass):
+    return O.make_plugins(["ParametricEQ"] * n, with_bypass=bypass)
+
+
+def test_g3_g4_process_audio_and_param_dict(golden_dir):
+    g = _g(golden_dir, "process_audio.npz")
+    for ci, (nplug, bypass, chs) in enumerate(g["cases"]):
+        plugins = _eq_plugins(int(nplug), bool(bypass))
+        y = O.process_audio(g[f"x{ci}"].copy(), g[f"w{ci}"], SR, plugins)
+        assert y.shape == g[f"y{ci}"].shape
+        np.testing.assert_allclose(y, g[f"y{ci}"], rtol=2e-6, atol=2e-7)
+        assert np.isclose(np.abs(y).max(), 1.0)
+        d = O.parameters_to_dict(g[f"w{ci}"], plugins)
+        flat = np.array([v for pn in d for v in d[pn].values()])
+        np.testing.assert_allclose(flat, g[f"d{ci}"], rtol=1e-15)
+    plugins = _eq_plugins(1, False)
+    plugins["ParametricEQ"]["fixed_parameters"] = {"band1_gain_db": 12.0, "band1_cutoff_freq": 2500.0}
+    y = O.process_audio(g["xf"].copy(), g["wf"], SR, plugins)
+    np.testing.assert_allclose(y, g["yf"], rtol=2e-6, atol=2e-7)
+
+
+def test_bypass_is_a_dead_dimension():
+    """style_transfer.py:89-92: `continue` only continues the inner loop."""
+    rng = np.random.default_rng(0)
+    x = (0.1 * rng.standard_normal((1, 4000))).astype(np.float32)
+    plugins = _eq_plugins(1, True)
+    w = rng.random(19)
+    w[0] = 0.1
+    y0 = O.process_audio(x.copy(), w, SR, plugins)
+    w[0] = 0.9
+    y1 = O.process_audio(x.copy(), w, SR, plugins)
+    np.testing.assert_array_equal(y0, y1)
+
+
+def test_g5_get_param_embeds_postprocessing(golden_dir, capsys):
+    import sys
+    sys.path.insert(0, golden_dir)
+    g = _g(golden_dir, "param_embeds_toy.npz")
+
+    class Toy(torch.nn.Module):
+        def __init__(self, nan_mode):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.nan_mode = nan_mode
+
+        def forward(self, x):
+            mid = torch.stack([x[:, 0, :8] * 3 + 1, x[:, -1, 8:16] - 2], 1).flatten(1)
+            side = torch.stack([x[:, 0, 16:24], x[:, -1, 24:32] * 5], 1).flatten(1)
+            if self.nan_mode == 1:
+                mid = mid.clone(); mid[0, 0] = float("nan")
+            if self.nan_mode == 2:
+                side = side.clone(); side[0, 1] = float("nan")
+            return mid, side
+
+    for mode in (0, 1, 2):
+        e = O.get_param_embeds(torch.from_numpy(g["x"].copy()), Toy(mode), SR)
+        np.testing.assert_array_equal(e["mid"].numpy(), g[f"mid{mode}"])
+        np.testing.assert_array_equal(e["side"].numpy(), g[f"side{mode}"])
+
+
+@pytest.mark.parametrize("norm", ["minmax", "batchnorm", "none"])
+def test_g6_cnn14_trunk(golden_dir, norm):
+    g = _g(golden_dir, f"cnn14_trunk_{norm}.npz")
+    m = O.make_synthetic_model(int(g["seed"]), input_norm=norm)
+    with torch.no_grad():
+        x = torch.from_numpy(g["x"])
+        lm = m.logmel(x)
+        np.testing.assert_allclose(lm.numpy(), g["logmel"], rtol=1e-5, atol=1e-5)
+        mid, side = m(x)
+        np.testing.assert_allclose(mid.numpy(), g["mid"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(side.numpy(), g["side"], rtol=1e-4, atol=1e-5)
+        midm, sidem = m(torch.from_numpy(g["x_mono"]))
+        np.testing.assert_allclose(midm.numpy(), g["mid_mono"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(midm.numpy(), sidem.numpy())  # panns.py:271-274
+        e = O.get_param_embeds(x.clone(), m, SR)
+        np.testing.assert_allclose(e["mid"].numpy(), g["embed_mid"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(e["side"].numpy(), g["embed_side"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["stereo", "mono"])
+def test_g7_evaluate_losses(golden_dir, tag):
+    g = _g(golden_dir, f"evaluate_{tag}.npz")
+    m = O.make_synthetic_model(int(g["seed"]), input_norm="minmax")
+    plugins = _eq_plugins(1, False)
+    x = torch.from_numpy(g["x"].copy())
+    tgt = torch.from_numpy(g["target"].copy())
+    x /= x.abs().max().clamp(min=1e-8)          # style_transfer.py:452-453
+    tgt /= tgt.abs().max().clamp(min=1e-8)
+    te = O.get_param_embeds(tgt, m, SR)
+    fvals, embeds, audios = O.evaluate(list(g["W"]), x, SR, plugins, te, m)
+    np.testing.assert_allclose(fvals, g["fvals"], rtol=1e-4, atol=1e-6)
+    assert audios.shape[-1] == 262144           # zero-padded (style_transfer.py:517-518)
+    i = int(np.argmin(fvals))
+    np.testing.assert_array_equal(g["W"][i], g["wopt"])
+    out = O.process_audio(x.squeeze(0).numpy(), g["wopt"], SR, plugins)
+    np.testing.assert_allclose(out, g["output_audio"], rtol=2e-6, atol=2e-7)
+
+
+# ---------------- closed-form known answers for the unpinned pieces ----------------
+def test_eq_zero_gain_is_identity():
+    x = (0.2 * np.random.default_rng(1).standard_normal((1, 5000))).astype(np.float32)
+    y = O.OracleParametricEQ().process(x, SR)
+    np.testing.assert_allclose(y, x, atol=1e-7)
+
+
+def test_eq_magnitude_response_closed_form():
+    b, a = O.biquad(12.0, 1000.0, 2.0, SR, "peaking")
+    imp = np.zeros(1 << 16); imp[0] = 1
+    import scipy.signal
+    h = scipy.signal.lfilter(b, a, imp)
+    H = np.fft.rfft(h)
+    for f in (100.0, 500.0, 1000.0, 2000.0, 8000.0):
+        z = np.exp(-1j * 2 * np.pi * f / SR)
+        ref = (b[0] + b[1] * z + b[2] * z * z) / (a[0] + a[1] * z + a[2] * z * z)
+        k = f / SR * (1 << 16)
+        got = np.interp(k, np.arange(len(H)), np.abs(H))
+        assert abs(got - abs(ref)) < 2e-3 * abs(ref)
+    z = np.exp(-1j * 2 * np.pi * 1000.0 / SR)
+    peak = abs((b[0] + b[1] * z + b[2] * z * z) / (a[0] + a[1] * z + a[2] * z * z))
+    assert abs(20 * np.log10(peak) - 12.0) < 1e-9
+
+
+def test_compressor_identity_and_static_curve():
+    comp = O.OracleCompressor()
+    x = (0.5 * np.sin(np.arange(4000) * 0.05))[None].astype(np.float32)
+    comp.parameters["threshold_db"].set_value(0.0)   # |x| < 1 = thr -> gain 1
+    np.testing.assert_array_equal(comp.process(x, SR), x)
+    comp.parameters["threshold_db"].set_value(-20.0)
+    comp.parameters["ratio"].set_value(4.0)
+    comp.parameters["attack_ms"].set_value(0.1)
+    dc = np.full((1, 48000), 0.5, np.float32)
+    y = comp.process(dc, SR)
+    expect = 0.5 * (0.5 / 0.1) ** (1 / 4.0 - 1)
+    assert abs(y[0, -1] - expect) < 1e-5
+
+
+def test_delay_echo_spacing():
+    d = O.OracleDelay()
+    d.parameters["delay_seconds"].set_value(0.05)
+    d.parameters["feedback"].set_value(0.5)
+    d.parameters["mix"].set_value(0.5)
+    x = np.zeros((1, 10000), np.float32); x[0, 0] = 1.0
+    y = d.process(x, SR)[0]
+    D = int(np.float32(0.05) * np.float32(SR))
+    nz = np.nonzero(y)[0]
+    np.testing.assert_array_equal(nz[:4], [0, D, 2 * D, 3 * D])
+    np.testing.assert_allclose(y[nz[:4]], [0.5, 0.5, 0.25, 0.125], rtol=1e-6)
+
+
+def test_freeverb_first_echo_and_sizes():
+    import ctypes
+    cs = (ctypes.c_int * 16)(); asz = (ctypes.c_int * 8)()
+    O._lib().oracle_freeverb_sizes(float(SR), cs, asz)
+    assert cs[0] == 1116 * 48000 // 44100 == 1214 and cs[8] == (1116 + 23) * 48000 // 44100
+    assert asz[3] == 225 * 48000 // 44100 == 244
+    r = O.OracleReverb()
+    r.parameters["wet_dry"].set_value(1.0)
+    r.parameters["width"].set_value(1.0)
+    x = np.zeros((2, 4000), np.float32); x[:, 0] = 1.0
+    y = r.process(x, SR)
+    # wet only: first non-zero output appears when the 1st allpass sees the impulse (t = 0:
+    # allpass returns -input = 0 since combs output 0) -> first comb echo at 1214 samples
+    assert np.all(y[0, :1214] == 0.0) and y[0, 1214] != 0.0
+
+
+def test_distortion_and_gain_known_values():
+    d = O.OracleDistortion()
+    d.parameters["drive_db"].set_value(20.0)
+    d.parameters["output_gain_db"].set_value(-6.0)
+    x = np.array([[0.01, -0.2, 0.5]], np.float32)
+    np.testing.assert_allclose(d.process(x, SR), np.tanh(x * 10.0) * 10 ** (-6 / 20), rtol=1e-6)
+    gn = O.OracleGain()
+    gn.parameters["gain_db"].set_value(6.0)
+    np.testing.assert_allclose(gn.process(x, SR), x * 10 ** (6 / 20), rtol=1e-6)
+
+
+def test_stft_frontend_known_answers():
+    n_fft, hop = 2048, 1024
+    L = 20480
+    t = np.arange(L)
+    k0 = 100  # bin-centred sinusoid
+    x = torch.from_numpy(np.cos(2 * np.pi * k0 * t / n_fft).astype(np.float32))[None]
+    S = O.Spectrogram(n_fft, hop)(x)[0, 0].numpy()
+    assert S.shape == (L // hop + 1, n_fft // 2 + 1)
+    mid = S[5]
+    assert mid.argmax() == k0
+    # periodic Hann, amplitude 1 cosine: |X[k0]| = N/4 -> power N^2/16
+    assert abs(mid[k0] - (n_fft ** 2) / 16) / ((n_fft ** 2) / 16) < 1e-4
+    # FFT restatement of the same frame agrees with the conv1d form
+    frame = np.pad(x[0].numpy(), (1024, 1024), mode="reflect")[5 * hop: 5 * hop + n_fft]
+    P = np.abs(np.fft.rfft(frame.astype(np.float64) * O.hann_periodic(n_fft))) ** 2
+    np.testing.assert_allclose(mid, P, rtol=1e-3, atol=1e-2)
+    melW = O.mel_filterbank(SR, n_fft, 128, 20, 20000)
+    assert melW.shape == (128, 1025) and melW.dtype == np.float32
+    assert (melW >= 0).all() and (melW.sum(1) > 0).all()
+    assert ((melW > 0).sum(0) <= 2).all()          # each FFT bin feeds at most two mel bands
+
+
+def test_cosine_of_identical_audio_is_minus_one():
+    m = O.make_synthetic_model(0)
+    x = O.synth_audio(3, 2, 32768)[None]
+    e = O.get_param_embeds(x.clone(), m, SR)
+    plugins = O.make_plugins(["ParametricEQ"])
+    w = np.array([p.raw_value for p in plugins["ParametricEQ"]["instance"].parameters.values()])
+    xl = torch.nn.functional.pad(x, (0, 262144 - 32768))
+    te = O.get_param_embeds(xl.clone(), m, SR)
+    f, _, _ = O.evaluate([w], x, SR, plugins, te, m)
+    assert abs(f[0] + 1.0) < 1e-5
