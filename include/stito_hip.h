@@ -1,0 +1,188 @@
+/*
+ * stito_hip.h -- C ABI of libstito_hip.so: the MI355X (gfx950) implementation of st-ito's
+ * ES "evaluate-population" hot path.
+ *
+ * The reference (csteinmetz1/st-ito) is pure Python and has no FFI; the entry points below
+ * are what a binding for this path replaces, one per stage of
+ *     run_es.evaluate()                      st_ito/style_transfer.py:474-573
+ * (file:line relative to the reference repository):
+ *
+ *   stito_render_population   <- the per-candidate loop over process_audio()
+ *                                st_ito/style_transfer.py:45-115, 512-521 and the Basic*
+ *                                plugin .process() methods st_ito/effects.py:784-959
+ *   stito_normalize_audio     <- x /= clip(max|x|, 1e-8)   style_transfer.py:113
+ *   stito_logmel              <- peak-normalise + mid/side + Spectrogram + LogmelFilterBank +
+ *                                input_norm   st_ito/utils.py:473-474, models/panns.py:213-245
+ *   stito_cnn14_*             <- Cnn14 conv stack / pooling head / fc_mid, fc_side
+ *                                st_ito/models/panns.py:250-281
+ *   stito_embed_loss          <- NaN scrub + F.normalize + -cosine_similarity + mean
+ *                                st_ito/utils.py:491-501, style_transfer.py:544-571
+ *
+ * Conventions: every pointer named *_dev is a device pointer owned by the caller (PyTorch in
+ * the Python host); `stream` is a hipStream_t passed as void*; all work is enqueued on that
+ * stream and nothing synchronises.  Functions return 0 on success and a negative STITO_E_*
+ * code otherwise; stito_last_error() returns a thread-local message for the last failure.
+ * No torch types appear here.  There is no CPU fallback: without a HIP device the calls fail.
+ */
+#ifndef STITO_HIP_H
+#define STITO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STITO_OK 0
+#define STITO_E_INVALID -1      /* bad argument (ValueError on the Python side) */
+#define STITO_E_UNSUPPORTED -2  /* valid in the reference, not built here */
+#define STITO_E_WORKSPACE -3    /* workspace too small */
+#define STITO_E_HIP -4          /* a HIP runtime call failed */
+
+/* Effect kinds; parameter order inside an effect is the reference's `parameters` dict order. */
+enum {
+    STITO_FX_PARAMETRIC_EQ = 0, /* effects.py:800-873, 18 params, 1-channel plugin */
+    STITO_FX_COMPRESSOR = 1,    /* effects.py:876-897,  4 params, 1-channel */
+    STITO_FX_DISTORTION = 2,    /* effects.py:900-916,  2 params, 1-channel */
+    STITO_FX_DELAY = 3,         /* effects.py:919-934,  3 params, 2-channel in run_optim.py:395 */
+    STITO_FX_REVERB = 4,        /* effects.py:937-959,  4 params, 2-channel */
+    STITO_FX_GAIN = 5,          /* effects.py:532-542,  1 param  (BASELINE "gain" stage) */
+    STITO_FX_NUM_KINDS = 6
+};
+
+#define STITO_MAX_FX_PARAMS 18
+
+/* One plugin of the chain == one entry of the reference's `plugins` dict
+ * (run_optim.py:376-437, style_transfer.py:17-42). */
+typedef struct {
+    int32_t kind;         /* STITO_FX_* */
+    int32_t num_channels; /* plugin["num_channels"]: 1 = run per channel, 2 = stereo (up-mixes mono) */
+    int32_t w_offset;     /* index in w of this plugin's first slot */
+    int32_t has_bypass;   /* 1: slot 0 is the dead "our_bypass" dimension (style_transfer.py:28, 89-92) */
+    uint32_t fixed_mask;  /* bit p set: parameter p comes from fixed_raw[p], but still consumes a w slot
+                             (style_transfer.py:79-84) */
+    uint32_t reserved;
+    double fixed_raw[STITO_MAX_FX_PARAMS]; /* raw [0,1] value = (v - min) / (max - min) */
+} stito_fx_desc;
+
+const char *stito_last_error(void);
+int stito_version(void);
+
+/* Number of real parameters of an effect kind (without the bypass slot), or <0. */
+int stito_fx_num_params(int kind);
+/* Channel count of the rendered audio for `in_channels` input channels (style_transfer.py:94-104). */
+int stito_chain_out_channels(const stito_fx_desc *chain, int n_fx, int in_channels);
+/* Total number of w slots the chain consumes. */
+int stito_chain_num_dims(const stito_fx_desc *chain, int n_fx);
+
+size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n_fx, int in_channels,
+                                    int64_t n_samples, int pop);
+
+/* Render every candidate of the population through the chain.
+ *   x_dev        (in_channels, n_samples) float32, shared by all candidates
+ *   w_dev        (pop, n_dims) float64, raw parameters in [0,1] (CMA-ES phenotypes)
+ *   audio_dev    (pop, out_channels, n_samples) float32: chain output BEFORE peak normalisation
+ *   peaks_dev    (pop) float32: max |audio| over channels and samples of each candidate
+ * The final `x /= clip(peak, 1e-8)` of process_audio() is applied by stito_normalize_audio /
+ * stito_logmel so that the audio tensor only has to be rewritten when the caller wants it. */
+int stito_render_population(const stito_fx_desc *chain, int n_fx, const float *x_dev, int in_channels,
+                            int64_t n_samples, const double *w_dev, int pop, int n_dims,
+                            double sample_rate, float *audio_dev, float *peaks_dev, void *workspace_dev,
+                            size_t workspace_bytes, void *stream);
+
+/* max|x| per candidate over (channels, n_samples). */
+int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples, float *peaks_dev,
+               void *stream);
+/* audio[p] /= clip(peaks[p], 1e-8)  (style_transfer.py:113). */
+int stito_normalize_audio(float *audio_dev, int pop, int channels, int64_t n_samples,
+                          const float *peaks_dev, void *stream);
+
+/* ---- front end --------------------------------------------------------------------------- */
+enum { STITO_NORM_NONE = 0, STITO_NORM_MINMAX = 1, STITO_NORM_BATCHNORM = 2 };
+
+typedef struct {
+    int32_t n_fft;        /* window_size (power of two, <= 4096) */
+    int32_t hop;          /* hop_size */
+    int32_t n_mels;       /* mel_bins (<= 256) */
+    int32_t norm_mode;    /* STITO_NORM_* (Cnn14.input_norm, panns.py:233-245) */
+    const float *window_dev;      /* (n_fft) analysis window (periodic Hann in the reference) */
+    const float *twiddle_dev;     /* (n_fft/2, 2) cos/sin of exp(-2 pi i k / n_fft) */
+    const int32_t *mel_start_dev; /* (n_mels) first FFT bin of each band */
+    const int32_t *mel_len_dev;   /* (n_mels) number of consecutive bins */
+    const int32_t *mel_off_dev;   /* (n_mels) offset of the band's weights in mel_w_dev */
+    const float *mel_w_dev;       /* packed non-zero runs of melW[:, m] */
+    const float *bn0_scale_dev;   /* (n_mels) gamma/sqrt(var+eps)        (BATCHNORM only) */
+    const float *bn0_shift_dev;   /* (n_mels) beta - mean*scale          (BATCHNORM only) */
+} stito_frontend;
+
+/* T = n_samples / hop + 1 frames (center=True, reflect padding). */
+int64_t stito_num_frames(int64_t n_samples, int hop);
+
+/* audio_dev (pop, channels, n_samples) + peaks_dev (pop) = max|audio[p]|; norm_passes = how many
+ * `x /= clip(max|x|, 1e-8)` the reference applies before the model: 2 for rendered candidates
+ * (style_transfer.py:113 then utils.py:473-474), 1 for get_param_embeds() alone, 0 = none
+ * -> logmel_dev (pop*channels, T, n_mels) float32, streams interleaved [p0_mid, p0_side, p1_mid, ...]
+ * (panns.py:219-227).  channels == 1: one stream per candidate. */
+int stito_logmel(const stito_frontend *fe, const float *audio_dev, const float *peaks_dev,
+                 int norm_passes, int pop, int channels, int64_t n_samples, float *logmel_dev, void *stream);
+
+/* ---- Cnn14 trunk -------------------------------------------------------------------------- */
+#define STITO_CNN14_NUM_CONVS 12
+
+typedef struct {
+    int32_t embed_dim;
+    int32_t n_mels;
+    int32_t channels[7];   /* 1,64,128,256,512,1024,2048 */
+    int32_t reserved;
+    /* conv weights in the packed layout produced by stito_cnn14_pack_conv; BN folded to
+     * per-channel scale/shift applied after the convolution (eval mode, panns.py:67-68) */
+    const float *conv_w_dev[STITO_CNN14_NUM_CONVS];
+    const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
+    const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
+    const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
+    const float *fc_mid_b_dev;   /* (embed_dim) */
+    const float *fc_side_wt_dev; /* (2048, embed_dim) */
+    const float *fc_side_b_dev;  /* (embed_dim) */
+} stito_cnn14_weights;
+
+/* Number of floats of a packed conv weight for (cout, cin). */
+size_t stito_cnn14_packed_conv_floats(int cout, int cin);
+/* (cout, cin, 3, 3) PyTorch layout -> packed layout used by the MFMA kernel. */
+int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, float *packed_dev, void *stream);
+/* BN(eval) -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  gamma_dev == NULL:
+ * identity (use_batchnorm=False). */
+int stito_bn_fold(const float *gamma_dev, const float *beta_dev, const float *mean_dev,
+                  const float *var_dev, double eps, int n, float *scale_dev, float *shift_dev,
+                  void *stream);
+/* (rows, cols) -> (cols, rows) float32 transpose (fc weights). */
+int stito_transpose(const float *in_dev, int rows, int cols, float *out_dev, void *stream);
+
+size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int n_streams, int64_t n_frames);
+
+/* logmel_dev (n_streams, T, n_mels) -> mid_dev / side_dev (n_cand, embed_dim), the raw fc outputs
+ * (before L2 normalisation).  channels == 2: streams are [mid, side] pairs; channels == 1:
+ * side := mid (panns.py:271-274). */
+int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, int n_cand, int channels,
+                        int64_t n_frames, float *mid_dev, float *side_dev, void *workspace_dev,
+                        size_t workspace_bytes, void *stream);
+
+/* Individual layers, exposed for parity tests and profiling.
+ * in (n, H, W, cin) NHWC -> out (n, H', W', cout) NHWC, y = relu(conv3x3(x) * scale + shift),
+ * pool != 0: 2x2 average pooling (floor). */
+int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
+                          const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
+                          int pool, void *stream);
+
+/* ---- embeddings -> fitness ----------------------------------------------------------------- */
+/* In place: NaN scrub (utils.py:491-497), L2-normalise mid/side (n_cand, E).  If target_mid_dev
+ * is not NULL also writes loss_dev (n_cand) = mean(-cos(mid, target_mid), -cos(side, target_side))
+ * (style_transfer.py:544-571); targets are (1, E). */
+int stito_embed_loss(float *mid_dev, float *side_dev, int n_cand, int embed_dim,
+                     const float *target_mid_dev, const float *target_side_dev, float *loss_dev,
+                     int32_t *flags_dev /* (2) scratch */, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STITO_HIP_H */

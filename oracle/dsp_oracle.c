@@ -176,7 +176,7 @@ void oracle_delay(const float *x, float *y, int64_t n, double sample_rate,
 {
     float ds = (float)delay_seconds, fb = (float)feedback, mx = (float)mix;
     if (ds == 0.0f) { if (y != x) memcpy(y, x, sizeof(float) * (size_t)n); return; }
-    int64_t D = (int64_t)(int)(ds * (float)sample_rate);
+    int64_t D = (int64_t)(int)((double)ds * sample_rate); /* (int)(delaySeconds * spec.sampleRate), sampleRate is double */
     float dry = 1.0f - mx, wet = mx;
     if (D <= 0) {
         /* pop-before-push with zero delay reads the slot about to be overwritten, which

@@ -1,0 +1,783 @@
+// dsp.hip -- population-parallel audio-effect chain for gfx950.
+//
+// Replaces the per-candidate Python loop over process_audio() (reference
+// st_ito/style_transfer.py:45-115, 512-521) and the Basic* plugins' .process()
+// (st_ito/effects.py:784-959).  Audio lives in HBM as (pop, channels, n) float32; every effect
+// works in place on that buffer.  The time axis is serial in the reference (IIR / delay-line
+// recurrences); each kernel below uses the time-parallel formulation that fits its recurrence:
+//
+//   parametric EQ  : 12th-order LTI cascade, float64 like scipy.lfilter (effects.py:465-512).
+//                    One workgroup per stream, 256 time-chunks per stream; zero-state pass,
+//                    12x12 state-transition power + chunk scan in LDS, corrected pass.
+//   compressor     : envelope is a non-linear one-pole (switching attack/release) -> one lane
+//                    per stream, serial in time, LDS-transposed tiles for coalescing; the
+//                    gain computer (pow) runs fully parallel afterwards.
+//   Freeverb       : one workgroup per candidate, all delay lines resident in LDS (~112 KB);
+//                    time advances in tiles shorter than the shortest delay line, so comb /
+//                    all-pass updates inside a tile are independent; the comb damping one-pole
+//                    is a wave-level affine scan.
+//   delay          : feedback delay of D samples = D independent geometric recurrences.
+//   distortion/gain: element-wise.
+#include "common.h"
+
+namespace stito {
+
+static constexpr int COEF_STRIDE = 32;  // doubles per (effect, candidate)
+
+struct InView {  // where a stage reads its input from
+    const float *base;
+    int64_t cand_stride;  // 0: the shared input x
+    int64_t ch_stride;
+    int in_ch;  // channel c reads channel c % in_ch (mono -> stereo up-mix, style_transfer.py:94-95)
+};
+
+__device__ __forceinline__ const float *in_ptr(const InView &v, int cand, int ch) {
+    return v.base + (int64_t)cand * v.cand_stride + (int64_t)(ch % v.in_ch) * v.ch_stride;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter tables: (min, max) of every Parameter, reference order
+//   EQ effects.py:822-841, compressor 885-888, distortion 903-904, delay 924-926,
+//   reverb 946-949, gain 538.
+// ------------------------------------------------------------------------------------------------
+__constant__ double c_pmin[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
+    {-24, 20, 0.1, -24, 20, 0.1, -24, 20, 0.1, -24, 20, 0.1, -24, 20, 0.1, -24, 200, 0.1},
+    {-80, 1, 0.1, 10},
+    {-48, -24},
+    {0.01, 0.05, 0.0},
+    {0, 0, 0, 0},
+    {-48}};
+__constant__ double c_pmax[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
+    {24, 4000, 4, 24, 10000, 4, 24, 10000, 4, 24, 10000, 4, 24, 10000, 4, 24, 18000, 4},
+    {0, 20, 100, 1000},
+    {48, 24},
+    {1.0, 1.0, 1.0},
+    {1, 1, 1, 1},
+    {48}};
+static const int h_nparams[STITO_FX_NUM_KINDS] = {18, 4, 2, 3, 4, 1};
+
+struct ChainArgs {
+    int n_fx;
+    stito_fx_desc fx[16];
+};
+
+// juce::Decibels::decibelsToGain<float>
+__device__ __forceinline__ float db_to_gain(float db, float minus_inf) {
+    return db > minus_inf ? powf(10.0f, db * 0.05f) : 0.0f;
+}
+
+// RBJ biquad, effects.py:395-450.  kind: 0 low-shelf, 1 peaking, 2 high-shelf.
+__device__ void rbj(double gain_db, double f, double q, double sr, int kind, double *o /*b0 b1 b2 a1 a2*/) {
+    const double A = pow(10.0, gain_db / 40.0);
+    const double w0 = 2.0 * M_PI * (f / sr);
+    const double alpha = sin(w0) / (2.0 * q);
+    const double cw = cos(w0);
+    const double sA = sqrt(A);
+    double b0, b1, b2, a0, a1, a2;
+    if (kind == 2) {
+        b0 = A * ((A + 1) + (A - 1) * cw + 2 * sA * alpha);
+        b1 = -2 * A * ((A - 1) + (A + 1) * cw);
+        b2 = A * ((A + 1) + (A - 1) * cw - 2 * sA * alpha);
+        a0 = (A + 1) - (A - 1) * cw + 2 * sA * alpha;
+        a1 = 2 * ((A - 1) - (A + 1) * cw);
+        a2 = (A + 1) - (A - 1) * cw - 2 * sA * alpha;
+    } else if (kind == 0) {
+        b0 = A * ((A + 1) - (A - 1) * cw + 2 * sA * alpha);
+        b1 = 2 * A * ((A - 1) - (A + 1) * cw);
+        b2 = A * ((A + 1) - (A - 1) * cw - 2 * sA * alpha);
+        a0 = (A + 1) + (A - 1) * cw + 2 * sA * alpha;
+        a1 = -2 * ((A - 1) + (A + 1) * cw);
+        a2 = (A + 1) + (A - 1) * cw - 2 * sA * alpha;
+    } else {
+        b0 = 1 + alpha * A;
+        b1 = -2 * cw;
+        b2 = 1 - alpha * A;
+        a0 = 1 + alpha / A;
+        a1 = -2 * cw;
+        a2 = 1 - alpha / A;
+    }
+    o[0] = b0 / a0; o[1] = b1 / a0; o[2] = b2 / a0; o[3] = a1 / a0; o[4] = a2 / a0;
+}
+
+// One thread per (candidate, effect): raw [0,1] -> value (Parameter.get_value, effects.py:795-797)
+// -> the constants the effect kernel needs.
+__global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, int D, double sr,
+                          double *__restrict__ coef) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * chain.n_fx) return;
+    const int f = idx / P, cand = idx % P;
+    const stito_fx_desc &fx = chain.fx[f];
+    const int kind = fx.kind;
+    double v[STITO_MAX_FX_PARAMS];
+    const int np = kind == 0 ? 18 : kind == 1 ? 4 : kind == 2 ? 2 : kind == 3 ? 3 : kind == 4 ? 4 : 1;
+    for (int p = 0; p < np; ++p) {
+        const double raw = ((fx.fixed_mask >> p) & 1u) ? fx.fixed_raw[p]
+                                                       : w[(int64_t)cand * D + fx.w_offset + fx.has_bypass + p];
+        v[p] = __dadd_rn(__dmul_rn(raw, c_pmax[kind][p] - c_pmin[kind][p]), c_pmin[kind][p]);
+    }
+    double *o = coef + ((int64_t)f * P + cand) * COEF_STRIDE;
+    if (kind == STITO_FX_PARAMETRIC_EQ) {
+        for (int s = 0; s < 6; ++s) rbj(v[3 * s], v[3 * s + 1], v[3 * s + 2], sr, s == 0 ? 0 : (s == 5 ? 2 : 1), o + 5 * s);
+    } else if (kind == STITO_FX_COMPRESSOR) {  // juce::dsp::Compressor<float>::update + BallisticsFilter
+        const float thr = db_to_gain((float)v[0], -200.0f);
+        const float expf_ = (float)(-2.0 * M_PI * 1000.0 / sr);
+        const float at = (float)v[2], rl = (float)v[3];
+        o[0] = thr;
+        o[1] = 1.0f / thr;
+        o[2] = 1.0f / (float)v[1] - 1.0f;
+        o[3] = at < 1.0e-3f ? 0.0f : expf(expf_ / at);
+        o[4] = rl < 1.0e-3f ? 0.0f : expf(expf_ / rl);
+    } else if (kind == STITO_FX_DISTORTION) {
+        o[0] = db_to_gain((float)v[0], -100.0f);
+        o[1] = db_to_gain((float)v[1], -100.0f);
+    } else if (kind == STITO_FX_DELAY) {
+        const float ds = (float)v[0];
+        o[0] = ds == 0.0f ? 0.0 : (double)(int)((double)ds * sr);
+        o[1] = (float)v[1];
+        o[2] = (float)v[2];
+    } else if (kind == STITO_FX_REVERB) {  // juce::Reverb::setParameters; wet=wet_dry, dry=1-wet_dry (effects.py:956-957)
+        const float room = (float)v[0], dampp = (float)v[1], wetl = (float)v[2], dryl = (float)(1 - v[2]),
+                    width = (float)v[3];
+        const float wet = wetl * 3.0f;
+        o[0] = dampp * 0.4f;
+        o[1] = room * 0.28f + 0.7f;
+        o[2] = 0.5f * wet * (1.0f + width);
+        o[3] = 0.5f * wet * (1.0f - width);
+        o[4] = dryl * 2.0f;
+    } else {
+        o[0] = powf(10.0f, (float)v[0] / 20.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parametric EQ
+// ------------------------------------------------------------------------------------------------
+static constexpr int EQ_NC = 256;  // time chunks per stream == threads per workgroup
+static constexpr int EQ_TS = 32;   // samples per LDS tile row
+
+struct EqSec { double b0, b1, b2, a1, a2; };
+
+// scipy.signal.lfilter's direct-form-II-transposed step for the 6-section cascade
+__device__ __forceinline__ double eq_step(double x, const EqSec (&c)[6], double (&z)[12]) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const double y = fma(c[s].b0, x, z[2 * s]);
+        z[2 * s] = fma(-c[s].a1, y, fma(c[s].b1, x, z[2 * s + 1]));
+        z[2 * s + 1] = fma(-c[s].a2, y, c[s].b2 * x);
+        x = y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out, int64_t out_cand_stride,
+                                               int C, int64_t L, const double *__restrict__ coef) {
+    __shared__ float tile[EQ_NC][EQ_TS + 1];
+    __shared__ double zst[12][EQ_NC];
+    __shared__ double mat[3][144];
+
+    const int s = blockIdx.x;
+    const int cand = s / C, ch = s % C;
+    const float *__restrict__ x = in_ptr(in, cand, ch);
+    float *__restrict__ y = out + (int64_t)cand * out_cand_stride + (int64_t)ch * L;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    EqSec sec[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        sec[k].b0 = cf[5 * k]; sec[k].b1 = cf[5 * k + 1]; sec[k].b2 = cf[5 * k + 2];
+        sec[k].a1 = cf[5 * k + 3]; sec[k].a2 = cf[5 * k + 4];
+    }
+    const int tid = threadIdx.x;
+    const int64_t B = (L + EQ_NC - 1) / EQ_NC;  // chunk length
+    const int64_t start = (int64_t)tid * B;
+    int64_t len = L - start;
+    len = len < 0 ? 0 : (len > B ? B : len);
+    const int lr = tid >> 5, lj = tid & 31;
+
+    double z[12];
+    // ---- pass A: zero-state response of every chunk, keep only the final state -------------
+#pragma unroll
+    for (int k = 0; k < 12; ++k) z[k] = 0.0;
+    for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < EQ_NC / 8; ++it) {
+            const int r = it * 8 + lr;
+            const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
+            tile[r][lj] = (pos < B && idx < L) ? x[idx] : 0.0f;
+        }
+        __syncthreads();
+        int64_t n = len - t0;
+        n = n < 0 ? 0 : (n > EQ_TS ? EQ_TS : n);
+        for (int j = 0; j < (int)n; ++j) (void)eq_step((double)tile[tid][j], sec, z);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) zst[k][tid] = z[k];
+
+    // ---- one-step transition matrix A (x = 0) and Phi = A^B by repeated squaring ------------
+    if (tid < 12) {
+        double e[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) e[k] = (k == tid) ? 1.0 : 0.0;
+        (void)eq_step(0.0, sec, e);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) mat[1][k * 12 + tid] = e[k];  // base
+    }
+    if (tid < 144) mat[0][tid] = (tid / 12 == tid % 12) ? 1.0 : 0.0;  // result = I
+    __syncthreads();
+    {
+        const int r = tid / 12, k = tid % 12;
+        for (int64_t e = B; e > 0; e >>= 1) {
+            if (e & 1) {  // result = base * result
+                double acc = 0.0;
+                if (tid < 144)
+                    for (int m = 0; m < 12; ++m) acc = fma(mat[1][r * 12 + m], mat[0][m * 12 + k], acc);
+                __syncthreads();
+                if (tid < 144) mat[0][tid] = acc;
+                __syncthreads();
+            }
+            double acc = 0.0;
+            if (tid < 144)
+                for (int m = 0; m < 12; ++m) acc = fma(mat[1][r * 12 + m], mat[1][m * 12 + k], acc);
+            __syncthreads();
+            if (tid < 144) mat[1][tid] = acc;
+            __syncthreads();
+        }
+    }
+    // ---- chunk scan: s_in[c+1] = Phi s_in[c] + z_c  (lanes 0..11 of wave 0, one row each) ------
+    if (tid < 64) {
+        const int i = tid < 12 ? tid : 0;
+        double phi[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) phi[k] = mat[0][i * 12 + k];
+        double si = 0.0;
+        for (int c = 0; c < EQ_NC; ++c) {
+            const double zc = zst[i][c];
+            double acc = zc;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc = fma(phi[k], __shfl(si, k), acc);
+            if (tid < 12) zst[i][c] = si;  // state entering chunk c
+            si = acc;
+        }
+    }
+    __syncthreads();
+    // ---- pass B: rerun every chunk from its true initial state, write the output -------------
+#pragma unroll
+    for (int k = 0; k < 12; ++k) z[k] = zst[k][tid];
+    for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < EQ_NC / 8; ++it) {
+            const int r = it * 8 + lr;
+            const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
+            tile[r][lj] = (pos < B && idx < L) ? x[idx] : 0.0f;
+        }
+        __syncthreads();
+        int64_t n = len - t0;
+        n = n < 0 ? 0 : (n > EQ_TS ? EQ_TS : n);
+        for (int j = 0; j < (int)n; ++j) tile[tid][j] = (float)eq_step((double)tile[tid][j], sec, z);
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < EQ_NC / 8; ++it) {
+            const int r = it * 8 + lr;
+            const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
+            if (pos < B && idx < L) y[idx] = tile[r][lj];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compressor: juce::dsp::Compressor<float> (peak ballistics + VCA), effects.py:891-897
+// ------------------------------------------------------------------------------------------------
+static constexpr int CE_T = 64;  // samples per tile
+
+// envelope: env = v + cte*(env_prev - v), cte = v > env_prev ? attack : release.  One lane per
+// stream, one wave per workgroup; tiles are transposed through LDS so HBM sees 256-B rows.
+__global__ __launch_bounds__(64) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
+                                                  int C, int64_t L, int S, const double *__restrict__ coef) {
+    __shared__ float tile[64][CE_T + 1];
+    const int lane = threadIdx.x;
+    const int s0 = blockIdx.x * 64;
+    const int s = s0 + lane;
+    const bool valid = s < S;
+    const int cand = valid ? s / C : 0, ch = valid ? s % C : 0;
+    const float *xp = in_ptr(in, cand, ch);
+    float *ep = env + (int64_t)cand * cand_stride + (int64_t)ch * L;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    const float cat = (float)cf[3], crl = (float)cf[4];
+    const int nrows = min(64, S - s0);
+    (void)xp; (void)ep;
+    // row r of the tile is stream s0 + r: wave-uniform, so these pointers live on the scalar unit
+    auto row_in = [&](int r) -> const float * {
+        const int sr_ = s0 + (r < nrows ? r : 0);
+        const int c_ = (C == 2) ? (sr_ >> 1) : (C == 1 ? sr_ : sr_ / C);
+        return in_ptr(in, c_, sr_ - c_ * C);
+    };
+    auto row_out = [&](int r) -> float * {
+        const int sr_ = s0 + (r < nrows ? r : 0);
+        const int c_ = (C == 2) ? (sr_ >> 1) : (C == 1 ? sr_ : sr_ / C);
+        return env + (int64_t)c_ * cand_stride + (int64_t)(sr_ - c_ * C) * L;
+    };
+    float yold = 0.0f;
+    float pre[64];
+    // prefetch tile 0
+#pragma unroll
+    for (int r = 0; r < 64; ++r) pre[r] = (r < nrows && lane < L) ? row_in(r)[lane] : 0.0f;
+    for (int64_t t0 = 0; t0 < L; t0 += CE_T) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 64; ++r) tile[r][lane] = pre[r];
+        __syncthreads();
+        const int64_t t1 = t0 + CE_T;
+        if (t1 < L) {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) pre[r] = (r < nrows && t1 + lane < L) ? row_in(r)[t1 + lane] : 0.0f;
+        }
+#pragma unroll 16
+        for (int j = 0; j < CE_T; ++j) {
+            const float v = fabsf(tile[lane][j]);
+            const float d = yold - v;
+            const float ya = fmaf(cat, d, v), yr = fmaf(crl, d, v);
+            yold = (d < 0.0f) ? ya : yr;  // v > yold  <=>  d < 0
+            tile[lane][j] = yold;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            if (r < nrows && t0 + lane < L) row_out(r)[t0 + lane] = tile[r][lane];
+    }
+}
+
+// VCA: gain = env < thr ? 1 : pow(env/thr, 1/ratio - 1); y = gain * x.
+__global__ __launch_bounds__(256) void k_comp_gain(InView in, float *__restrict__ out, const float *__restrict__ env,
+                                                    int64_t cand_stride, int C, int64_t L,
+                                                    const double *__restrict__ coef) {
+    const int s = blockIdx.y;
+    const int cand = s / C, ch = s % C;
+    const float *x = in_ptr(in, cand, ch);
+    const int64_t off = (int64_t)cand * cand_stride + (int64_t)ch * L;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    const float thr = (float)cf[0], thr_inv = (float)cf[1], p = (float)cf[2];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+        const float e = env[off + i];
+        const float g = (e < thr) ? 1.0f : powf(e * thr_inv, p);
+        out[off + i] = g * x[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Distortion (tanh waveshaper + output gain, effects.py:907-916) and gain (effects.py:532-542)
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pointwise(InView in, float *__restrict__ out, int64_t cand_stride, int C,
+                                                    int64_t L, const double *__restrict__ coef) {
+    const int s = blockIdx.y;
+    const int cand = s / C, ch = s % C;
+    const float *x = in_ptr(in, cand, ch);
+    float *y = out + (int64_t)cand * cand_stride + (int64_t)ch * L;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    const float g0 = (float)cf[0], g1 = (float)cf[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        if (KIND == STITO_FX_DISTORTION) y[i] = tanhf(v * g0) * g1;
+        else if (KIND == STITO_FX_GAIN) y[i] = v * g0;
+        else y[i] = v;  // copy / up-mix
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Delay: pedalboard.Delay (juce DelayLine, no interpolation), effects.py:929-934
+//   d[n] = pushed[n-D]; pushed[n] = x[n] + fb*d[n]; y[n] = x[n]*(1-mix) + mix*d[n]
+// Residue class i (mod D) is an independent recurrence over n = i, i+D, i+2D, ...
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_delay(InView in, float *__restrict__ out, int64_t cand_stride, int C,
+                                                int64_t L, const double *__restrict__ coef) {
+    const int cand = blockIdx.y;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    const int64_t D = (int64_t)cf[0];
+    const float fb = (float)cf[1], mix = (float)cf[2];
+    const float dry = 1.0f - mix;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const bool dup = (in.in_ch == 1 && C == 2);  // identical channels: compute once, write twice
+    if (D <= 0) {  // delay_seconds == 0: pedalboard passes the input through
+        for (int ch = 0; ch < C; ++ch) out[(int64_t)cand * cand_stride + (int64_t)ch * L + i] = in_ptr(in, cand, ch)[i];
+        return;
+    }
+    if (i >= D) return;
+    for (int ch = 0; ch < (dup ? 1 : C); ++ch) {
+        const float *x = in_ptr(in, cand, ch);
+        float *y = out + (int64_t)cand * cand_stride + (int64_t)ch * L;
+        float prev = 0.0f;
+        for (int64_t n = i; n < L; n += D) {
+            const float v = x[n];
+            const float o = v * dry + mix * prev;
+            prev = v + fb * prev;
+            y[n] = o;
+            if (dup) y[L + n] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Freeverb: juce::Reverb::processStereo, effects.py:952-959
+// ------------------------------------------------------------------------------------------------
+static constexpr int RV_TT = 192;       // tile length; must be <= the shortest delay line (244 @ 48 kHz)
+static constexpr int RV_THREADS = 1024; // 16 waves = 16 comb filters
+
+struct ReverbGeom {
+    int comb_size[16];  // [ch*8 + j]
+    int comb_off[16];   // float offsets into the LDS state area
+    int ap_size[8];     // [ch*4 + j]
+    int ap_off[8];
+    int state_floats;
+};
+
+__global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restrict__ out, int64_t cand_stride,
+                                                        int64_t L, const double *__restrict__ coef, ReverbGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *state = smem;                          // comb + all-pass delay lines
+    float *s_in = smem + g.state_floats;          // [RV_TT] (L+R)*gain
+    float *s_x = s_in + RV_TT;                    // [2][RV_TT] dry input
+    float *s_comb = s_x + 2 * RV_TT;              // [16][RV_TT] comb outputs
+    float *s_wet = s_comb + 16 * RV_TT;           // [2][RV_TT]
+
+    const int cand = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    const float damp = (float)cf[0], fbk = (float)cf[1], wet1 = (float)cf[2], wet2 = (float)cf[3], dry = (float)cf[4];
+    const float omd = 1.0f - damp;
+    const float *xl = in_ptr(in, cand, 0), *xr = in_ptr(in, cand, 1);
+    float *yl = out + (int64_t)cand * cand_stride, *yr = yl + L;
+
+    for (int i = tid; i < g.state_floats; i += RV_THREADS) state[i] = 0.0f;
+
+    // comb j == this wave; lane handles samples 3*lane .. 3*lane+2 of the tile
+    const int csz = g.comb_size[wv];
+    float *cbuf = state + g.comb_off[wv];
+    int cpos = 0;
+    float last_in = 0.0f;  // filterStore entering the tile
+    const float d3 = damp * damp * damp;
+    float apow[6];
+    {
+        float a = d3;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { apow[k] = a; a *= a; }
+    }
+    const float dlane = powf(d3, (float)lane);  // damp^(3*lane)
+    // all-pass positions (thread (c,t) role in phase 2)
+    int appos[4] = {0, 0, 0, 0};
+    const int c2 = tid / RV_TT, t2 = tid % RV_TT;
+
+    for (int64_t t0 = 0; t0 < L; t0 += RV_TT) {
+        const int nv = (int)min((int64_t)RV_TT, L - t0);
+        __syncthreads();
+        if (tid < RV_TT) {
+            const float a = tid < nv ? xl[t0 + tid] : 0.0f, b = tid < nv ? xr[t0 + tid] : 0.0f;
+            s_x[tid] = a; s_x[RV_TT + tid] = b;
+            s_in[tid] = (a + b) * 0.015f;
+        }
+        __syncthreads();
+        {   // ---- phase 1: 16 comb filters, one per wave ----
+            float o[3], w[3];
+            int idx[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int p = cpos + 3 * lane + i;
+                p = p >= csz ? p - csz : p;
+                idx[i] = p;
+                o[i] = cbuf[p];
+            }
+            // lane-local affine map of 3 damping steps: last_out = d3*last_in + b
+            float b = o[0] * omd;
+            b = o[1] * omd + b * damp;
+            b = o[2] * omd + b * damp;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {  // inclusive wave scan of the affine maps
+                const float up = __shfl_up(b, 1 << k);
+                if (lane >= (1 << k)) b = fmaf(apow[k], up, b);
+            }
+            float carry = __shfl_up(b, 1);
+            carry = (lane > 0 ? carry : 0.0f) + dlane * last_in;
+            float last = carry;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                last = (o[i] * omd) + (last * damp);
+                w[i] = s_in[3 * lane + i] + (last * fbk);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                cbuf[idx[i]] = w[i];
+                s_comb[wv * RV_TT + 3 * lane + i] = o[i];
+            }
+            last_in = __shfl(last, 63);
+            cpos += RV_TT;
+            cpos = cpos >= csz ? cpos - csz : cpos;
+        }
+        __syncthreads();
+        if (tid < 2 * RV_TT) {  // ---- phase 2: comb sum + 4 series all-passes, thread = (channel, t) ----
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += s_comb[(c2 * 8 + j) * RV_TT + t2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sz = g.ap_size[c2 * 4 + j];
+                float *ab = state + g.ap_off[c2 * 4 + j];
+                int p = appos[j] + t2;
+                p = p >= sz ? p - sz : p;
+                const float bv = ab[p];
+                ab[p] = acc + (bv * 0.5f);
+                acc = bv - acc;
+                appos[j] += RV_TT;
+                appos[j] = appos[j] >= sz ? appos[j] - sz : appos[j];
+            }
+            s_wet[c2 * RV_TT + t2] = acc;
+        }
+        __syncthreads();
+        if (tid < 2 * RV_TT && t2 < nv) {  // ---- phase 3: wet/dry mix ----
+            const float me = s_wet[c2 * RV_TT + t2], other = s_wet[(1 - c2) * RV_TT + t2];
+            const float v = me * wet1 + other * wet2 + s_x[c2 * RV_TT + t2] * dry;
+            (c2 == 0 ? yl : yr)[t0 + t2] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// peak / normalise (style_transfer.py:113)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_peak(const float *__restrict__ a, int64_t per_cand, float *__restrict__ peaks) {
+    __shared__ float red[4];
+    const int cand = blockIdx.y;
+    const float4 *p4 = (const float4 *)(a + (int64_t)cand * per_cand);
+    const int64_t n4 = per_cand / 4;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = p4[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax((unsigned int *)&peaks[cand], __float_as_uint(m));  // non-negative floats order as uints
+    }
+}
+
+__global__ __launch_bounds__(256) void k_peak_scalar(const float *__restrict__ a, int64_t per_cand, float *__restrict__ peaks) {
+    __shared__ float red[4];
+    const int cand = blockIdx.y;
+    const float *p = a + (int64_t)cand * per_cand;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_cand; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax((unsigned int *)&peaks[cand], __float_as_uint(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_normalize(float *__restrict__ a, int64_t per_cand, const float *__restrict__ peaks) {
+    const int cand = blockIdx.y;
+    const float d = fmaxf(peaks[cand], 1e-8f);
+    float *p = a + (int64_t)cand * per_cand;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_cand; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = p[i] / d;
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int fx_channels_after(const stito_fx_desc &fx, int c) { return (fx.num_channels == 2 && c == 1) ? 2 : c; }
+
+static void reverb_geometry(double sr, ReverbGeom &g) {
+    static const int comb_t[8] = {1116, 1188, 1277, 1356, 1422, 1491, 1557, 1617};
+    static const int ap_t[4] = {556, 441, 341, 225};
+    const int isr = (int)sr;
+    int off = 0;
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < 8; ++j) {
+            g.comb_size[c * 8 + j] = (int)(((int64_t)isr * (comb_t[j] + (c ? 23 : 0))) / 44100);
+            g.comb_off[c * 8 + j] = off;
+            off += g.comb_size[c * 8 + j];
+        }
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < 4; ++j) {
+            g.ap_size[c * 4 + j] = (int)(((int64_t)isr * (ap_t[j] + (c ? 23 : 0))) / 44100);
+            g.ap_off[c * 4 + j] = off;
+            off += g.ap_size[c * 4 + j];
+        }
+    g.state_floats = (off + 3) & ~3;
+}
+
+static int grid_x_for(int64_t L, int streams) {
+    int64_t want = (L + 255) / 256;
+    int64_t cap = (256 * 16 + streams - 1) / streams;  // ~16 blocks per CU over the whole launch
+    cap = cap < 1 ? 1 : cap;
+    return (int)(want < cap ? want : cap);
+}
+
+}  // namespace stito
+
+using namespace stito;
+
+extern "C" int stito_fx_num_params(int kind) {
+    if (kind < 0 || kind >= STITO_FX_NUM_KINDS) return STITO_E_INVALID;
+    return h_nparams[kind];
+}
+
+extern "C" int stito_chain_out_channels(const stito_fx_desc *chain, int n_fx, int in_channels) {
+    int c = in_channels;
+    for (int i = 0; i < n_fx; ++i) c = fx_channels_after(chain[i], c);
+    return c;
+}
+
+extern "C" int stito_chain_num_dims(const stito_fx_desc *chain, int n_fx) {
+    int d = 0;
+    for (int i = 0; i < n_fx; ++i) {
+        if (chain[i].kind < 0 || chain[i].kind >= STITO_FX_NUM_KINDS) return STITO_E_INVALID;
+        d += h_nparams[chain[i].kind] + (chain[i].has_bypass ? 1 : 0);
+    }
+    return d;
+}
+
+extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n_fx, int in_channels,
+                                               int64_t n_samples, int pop) {
+    const int cout = stito_chain_out_channels(chain, n_fx, in_channels);
+    size_t coef = align_up((size_t)(n_fx > 0 ? n_fx : 1) * pop * COEF_STRIDE * sizeof(double), 256);
+    bool has_comp = false;
+    for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
+    size_t env = has_comp ? align_up((size_t)pop * cout * n_samples * sizeof(float), 256) : 0;
+    return coef + env + 256;
+}
+
+extern "C" int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples, float *peaks_dev,
+                          void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    STITO_REQUIRE(pop > 0 && channels > 0 && n_samples > 0, STITO_E_INVALID, "stito_peak: empty input");
+    STITO_HIP_CHECK(hipMemsetAsync(peaks_dev, 0, sizeof(float) * pop, st));
+    const int64_t per = (int64_t)channels * n_samples;
+    if (((uintptr_t)audio_dev & 15) == 0 && per % 4 == 0) {
+        dim3 grid(grid_x_for(per / 4, pop), pop);
+        hipLaunchKernelGGL(k_peak, grid, dim3(256), 0, st, audio_dev, per, peaks_dev);
+    } else {
+        dim3 grid(grid_x_for(per, pop), pop);
+        hipLaunchKernelGGL(k_peak_scalar, grid, dim3(256), 0, st, audio_dev, per, peaks_dev);
+    }
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+extern "C" int stito_normalize_audio(float *audio_dev, int pop, int channels, int64_t n_samples,
+                                     const float *peaks_dev, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t per = (int64_t)channels * n_samples;
+    dim3 grid(grid_x_for(per, pop), pop);
+    hipLaunchKernelGGL(k_normalize, grid, dim3(256), 0, st, audio_dev, per, peaks_dev);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, const float *x_dev, int in_channels,
+                                       int64_t n_samples, const double *w_dev, int pop, int n_dims,
+                                       double sample_rate, float *audio_dev, float *peaks_dev,
+                                       void *workspace_dev, size_t workspace_bytes, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    STITO_REQUIRE(n_fx >= 0 && n_fx <= 16, STITO_E_INVALID, "chain length %d not in [0,16]", n_fx);
+    STITO_REQUIRE(in_channels == 1 || in_channels == 2, STITO_E_INVALID, "in_channels must be 1 or 2, got %d", in_channels);
+    STITO_REQUIRE(pop > 0 && n_samples > 0, STITO_E_INVALID, "empty population or audio");
+    const int dims = stito_chain_num_dims(chain, n_fx);
+    STITO_REQUIRE(dims >= 0, STITO_E_INVALID, "Plugin must contain a known effect kind");
+    STITO_REQUIRE(dims == n_dims, STITO_E_INVALID, "parameter vector has %d dims, chain consumes %d", n_dims, dims);
+    const size_t need = stito_render_workspace_bytes(chain, n_fx, in_channels, n_samples, pop);
+    STITO_REQUIRE(workspace_bytes >= need, STITO_E_WORKSPACE, "render workspace: have %zu need %zu", workspace_bytes, need);
+    const int C_out = stito_chain_out_channels(chain, n_fx, in_channels);
+    const int64_t L = n_samples;
+    const int64_t cand_stride = (int64_t)C_out * L;
+
+    char *ws = (char *)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
+    double *coef = (double *)ws;
+    float *envbuf = (float *)(ws + align_up((size_t)(n_fx > 0 ? n_fx : 1) * pop * COEF_STRIDE * sizeof(double), 256));
+
+    if (n_fx > 0) {
+        ChainArgs args;
+        args.n_fx = n_fx;
+        int off = 0;
+        for (int i = 0; i < n_fx; ++i) {
+            args.fx[i] = chain[i];
+            STITO_REQUIRE(chain[i].w_offset == off, STITO_E_INVALID, "fx %d: w_offset %d, expected %d", i, chain[i].w_offset, off);
+            STITO_REQUIRE(chain[i].num_channels == 1 || chain[i].num_channels == 2, STITO_E_INVALID, "fx %d: num_channels", i);
+            off += h_nparams[chain[i].kind] + (chain[i].has_bypass ? 1 : 0);
+        }
+        const int n = pop * n_fx;
+        hipLaunchKernelGGL(k_prepare, dim3((n + 127) / 128), dim3(128), 0, st, args, w_dev, pop, n_dims, sample_rate, coef);
+        STITO_LAUNCH_CHECK();
+    }
+
+    InView in{x_dev, 0, L, in_channels};
+    int C = in_channels;
+    bool in_buffer = false;
+    for (int i = 0; i < n_fx; ++i) {
+        const stito_fx_desc &fx = chain[i];
+        const int Cn = fx_channels_after(fx, C);
+        const double *cf = coef + (int64_t)i * pop * COEF_STRIDE;
+        const int S = pop * Cn;
+        if (Cn != C && in_buffer) {  // mono -> stereo in place: duplicate channel 0 first (style_transfer.py:94-95)
+            hipLaunchKernelGGL(k_pointwise<-1>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
+            STITO_LAUNCH_CHECK();
+            in = InView{audio_dev, cand_stride, L, Cn};
+        }
+        switch (fx.kind) {
+            case STITO_FX_PARAMETRIC_EQ:
+                hipLaunchKernelGGL(k_eq, dim3(S), dim3(EQ_NC), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
+                break;
+            case STITO_FX_COMPRESSOR:
+                hipLaunchKernelGGL(k_comp_env, dim3((S + 63) / 64), dim3(64), 0, st, in, envbuf, cand_stride, Cn, L, S, cf);
+                STITO_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_comp_gain, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
+                break;
+            case STITO_FX_DISTORTION:
+                hipLaunchKernelGGL(k_pointwise<STITO_FX_DISTORTION>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
+                break;
+            case STITO_FX_GAIN:
+                hipLaunchKernelGGL(k_pointwise<STITO_FX_GAIN>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
+                break;
+            case STITO_FX_DELAY: {
+                const int64_t dmax = (int64_t)(1.0 * sample_rate) + 1;
+                const int64_t nthreads = L < dmax ? L : dmax;
+                hipLaunchKernelGGL(k_delay, dim3((unsigned)((nthreads + 255) / 256), pop), dim3(256), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
+                break;
+            }
+            case STITO_FX_REVERB: {
+                STITO_REQUIRE(Cn == 2, STITO_E_INVALID, "Reverb must be declared with num_channels=2 (run_optim.py:401-406)");
+                ReverbGeom g;
+                reverb_geometry(sample_rate, g);
+                int mins = g.ap_size[0];
+                for (int k = 0; k < 8; ++k) mins = g.ap_size[k] < mins ? g.ap_size[k] : mins;
+                const size_t lds = (size_t)(g.state_floats + RV_TT * (1 + 2 + 16 + 2)) * sizeof(float);
+                STITO_REQUIRE(mins >= RV_TT && lds <= 160 * 1024, STITO_E_UNSUPPORTED,
+                              "Reverb: sample rate %.0f needs delay lines outside the LDS-resident design", sample_rate);
+                STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_reverb, dim3(pop), dim3(RV_THREADS), lds, st, in, audio_dev, cand_stride, L, cf, g);
+                break;
+            }
+            default:
+                STITO_REQUIRE(false, STITO_E_INVALID, "Plugin must contain a known effect kind (got %d)", fx.kind);
+        }
+        STITO_LAUNCH_CHECK();
+        C = Cn;
+        in = InView{audio_dev, cand_stride, L, C};
+        in_buffer = true;
+    }
+    if (!in_buffer) {  // empty chain: broadcast x
+        const int S = pop * C_out;
+        hipLaunchKernelGGL(k_pointwise<-1>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, C_out, L, (const double *)workspace_dev);
+        STITO_LAUNCH_CHECK();
+    }
+    if (peaks_dev) return stito_peak(audio_dev, pop, C_out, L, peaks_dev, stream);
+    return STITO_OK;
+}

@@ -1,0 +1,175 @@
+// frontend.hip -- peak-normalise + mid/side + STFT power + log-mel + input norm, fused.
+//
+// Replaces (reference file:line):
+//   x[b] /= x[b].abs().max().clamp(1e-8)                     st_ito/utils.py:473-474
+//   mid = (L+R)/2, side = (L-R)/2, view(B*C, L)              st_ito/models/panns.py:216-227
+//   torchlibrosa Spectrogram (reflect pad, Hann, |.|^2)      panns.py:147-155, 230
+//   torchlibrosa LogmelFilterBank (melW, 10 log10 clamp)     panns.py:158-168, 231
+//   input_norm {batchnorm, minmax, none}                     panns.py:233-245
+//
+// torchlibrosa evaluates the STFT as two conv1d's with a dense (1025 x 2048) windowed DFT
+// matrix (3.9 GFLOP per 10 s stream); here each frame is one real FFT: the 2048 real samples
+// are packed as 1024 complex points, transformed by a radix-2 Stockham FFT in LDS and
+// unpacked to the 1025 one-sided bins.  The mel projection uses the band structure of melW
+// (each band is one run of consecutive bins).  One workgroup = one (candidate, frame), both
+// mid and side streams; HBM traffic is the audio (read ~2x because hop = n_fft/2; the second
+// read hits L2) plus the (T, n_mels) output.
+#include "common.h"
+
+namespace stito {
+
+struct FrontendDev {
+    int n_fft, hop, n_mels, norm_mode, log2_n2;
+    const float *window;
+    const float2 *twiddle;  // exp(-2 pi i k / n_fft), k < n_fft/2
+    const int *mel_start, *mel_len, *mel_off;
+    const float *mel_w;
+    const float *bn_scale, *bn_shift;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__device__ __forceinline__ int64_t reflect_idx(int64_t i, int64_t L) {
+    if (i < 0) i = -i;
+    if (i >= L) i = 2 * (L - 1) - i;
+    return i;
+}
+
+static constexpr int FE_THREADS = 256;
+
+__global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const float *__restrict__ audio,
+                                                        const float *__restrict__ peaks, int norm_passes, int C,
+                                                        int64_t L, int64_t T, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N = fe.n_fft, N2 = N >> 1;
+    float2 *bufA = (float2 *)smem_raw;           // [C][N2]
+    float2 *bufB = bufA + C * N2;                // [C][N2]
+    float *pw = (float *)(bufB + C * N2);        // [C][N2 + 1]
+
+    const int cand = blockIdx.y;
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    // ---- normalisation divisors (process_audio's and get_param_embeds' peak norms) -----------
+    float d1 = 1.0f, d2 = 1.0f;
+    if (peaks != nullptr && norm_passes > 0) {
+        const float pk = peaks[cand];
+        d1 = fmaxf(pk, 1e-8f);
+        if (norm_passes > 1) d2 = fmaxf(pk / d1, 1e-8f);  // == 1 unless the candidate is (near) silent
+    }
+    const float *xl = audio + (int64_t)cand * C * L;
+    const float *xr = xl + L;
+    const int64_t base = t * fe.hop - N2;  // center=True: frame t covers [t*hop - n_fft/2, t*hop + n_fft/2)
+
+    // ---- load, normalise, mid/side, window, pack even/odd samples as complex ------------------
+    for (int m = tid; m < N2; m += FE_THREADS) {
+        const int64_t i0 = reflect_idx(base + 2 * m, L), i1 = reflect_idx(base + 2 * m + 1, L);
+        const float w0 = fe.window[2 * m], w1 = fe.window[2 * m + 1];
+        float a0 = xl[i0] / d1, a1 = xl[i1] / d1;
+        if (norm_passes > 1) { a0 = a0 / d2; a1 = a1 / d2; }
+        if (C == 2) {
+            float b0 = xr[i0] / d1, b1 = xr[i1] / d1;
+            if (norm_passes > 1) { b0 = b0 / d2; b1 = b1 / d2; }
+            const float m0 = (a0 + b0) / 2, m1 = (a1 + b1) / 2, s0 = (a0 - b0) / 2, s1 = (a1 - b1) / 2;
+            bufA[m] = make_float2(m0 * w0, m1 * w1);
+            bufA[N2 + m] = make_float2(s0 * w0, s1 * w1);
+        } else {
+            bufA[m] = make_float2(a0 * w0, a1 * w1);
+        }
+    }
+    __syncthreads();
+
+    // ---- radix-2 Stockham autosort FFT of N2 complex points per stream ------------------------
+    float2 *src = bufA, *dst = bufB;
+    const int half = N2 >> 1;
+    for (int p = 1, sh = fe.log2_n2; p < N2; p <<= 1, --sh) {
+        // twiddle exp(-i pi k / p) = table[k * N / (2p)] = table[k << sh], sh = log2(N2) - log2(p)
+        for (int c = 0; c < C; ++c) {
+            const float2 *s = src + c * N2;
+            float2 *d = dst + c * N2;
+            for (int i = tid; i < half; i += FE_THREADS) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 1) + k;
+                const float2 w = fe.twiddle[k << sh];
+                const float2 u0 = s[i];
+                const float2 u1 = cmul(s[i + half], w);
+                d[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                d[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+            }
+        }
+        __syncthreads();
+        float2 *tmp = src; src = dst; dst = tmp;
+    }
+
+    // ---- unpack the real transform: X[k] = E[k] + W^k O[k], power spectrum ---------------------
+    for (int c = 0; c < C; ++c) {
+        const float2 *Z = src + c * N2;
+        for (int k = tid; k <= N2; k += FE_THREADS) {
+            const float2 zk = Z[k & (N2 - 1)];
+            const float2 zn = Z[(N2 - k) & (N2 - 1)];
+            const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));  // (zk - conj(zn)) / (2i)
+            const float2 w = (k < N2) ? fe.twiddle[k] : make_float2(-1.0f, 0.0f);
+            const float2 wo = cmul(w, O);
+            const float re = E.x + wo.x, im = E.y + wo.y;
+            pw[c * (N2 + 1) + k] = re * re + im * im;
+        }
+    }
+    __syncthreads();
+
+    // ---- mel bands, 10 log10(clamp(., 1e-10)), input norm ---------------------------------------
+    const int M = fe.n_mels;
+    for (int q = tid; q < C * M; q += FE_THREADS) {
+        const int c = q / M, m = q - c * M;
+        const int st = fe.mel_start[m], ln = fe.mel_len[m];
+        const float *w = fe.mel_w + fe.mel_off[m];
+        const float *p = pw + c * (N2 + 1) + st;
+        float acc = 0.0f;
+        for (int i = 0; i < ln; ++i) acc = fmaf(p[i], w[i], acc);
+        float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
+        if (fe.norm_mode == STITO_NORM_MINMAX) {
+            v = fminf(fmaxf(v, -80.0f), 40.0f);
+            v = (v + 80.0f) / 120.0f;
+            v = (v * 2.0f) - 1.0f;
+        } else if (fe.norm_mode == STITO_NORM_BATCHNORM) {
+            v = v * fe.bn_scale[m] + fe.bn_shift[m];
+        }
+        out[((int64_t)(cand * C + c) * T + t) * M + m] = v;
+    }
+}
+
+}  // namespace stito
+
+using namespace stito;
+
+extern "C" int64_t stito_num_frames(int64_t n_samples, int hop) { return n_samples / hop + 1; }
+
+extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, const float *peaks_dev, int norm_passes,
+                            int pop, int channels, int64_t n_samples, float *logmel_dev, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    STITO_REQUIRE(fe != nullptr, STITO_E_INVALID, "stito_logmel: null front-end");
+    STITO_REQUIRE(channels == 1 || channels == 2, STITO_E_INVALID, "Invalid number of channels: %d", channels);
+    const int N = fe->n_fft;
+    STITO_REQUIRE(N >= 64 && N <= 4096 && (N & (N - 1)) == 0, STITO_E_UNSUPPORTED, "n_fft %d must be a power of two in [64, 4096]", N);
+    STITO_REQUIRE(fe->hop > 0 && fe->n_mels > 0, STITO_E_INVALID, "bad hop / n_mels");
+    STITO_REQUIRE(n_samples > N / 2, STITO_E_INVALID, "reflect padding needs n_samples > n_fft/2 (got %lld)", (long long)n_samples);
+    STITO_REQUIRE(pop > 0, STITO_E_INVALID, "empty batch");
+    FrontendDev d;
+    d.n_fft = N; d.hop = fe->hop; d.n_mels = fe->n_mels; d.norm_mode = fe->norm_mode;
+    int l2 = 0;
+    while ((1 << l2) < N / 2) ++l2;
+    d.log2_n2 = l2;
+    d.window = fe->window_dev; d.twiddle = (const float2 *)fe->twiddle_dev;
+    d.mel_start = fe->mel_start_dev; d.mel_len = fe->mel_len_dev; d.mel_off = fe->mel_off_dev; d.mel_w = fe->mel_w_dev;
+    d.bn_scale = fe->bn0_scale_dev; d.bn_shift = fe->bn0_shift_dev;
+    STITO_REQUIRE(fe->norm_mode != STITO_NORM_BATCHNORM || (d.bn_scale && d.bn_shift), STITO_E_INVALID, "batchnorm input norm needs bn0 scale/shift");
+    const int64_t T = stito_num_frames(n_samples, fe->hop);
+    const size_t lds = (size_t)channels * (N / 2) * sizeof(float2) * 2 + (size_t)channels * (N / 2 + 1) * sizeof(float);
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_logmel, dim3((unsigned)T, pop), dim3(FE_THREADS), lds, st, d, audio_dev, peaks_dev, norm_passes,
+                       channels, n_samples, T, logmel_dev);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}

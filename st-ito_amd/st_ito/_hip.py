@@ -1,0 +1,124 @@
+"""ctypes binding of libstito_hip.so (include/stito_hip.h).
+
+PyTorch owns device memory and streams; this module only passes raw pointers.  There is no
+CPU fallback: if the library is missing or no HIP device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+import torch  # noqa: F401  (must be imported first: brings in the process' libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libstito_hip.so")
+
+FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN = range(6)
+NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
+MAX_FX_PARAMS = 18
+E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
+
+
+class FxDesc(Structure):
+    _fields_ = [
+        ("kind", c_int32), ("num_channels", c_int32), ("w_offset", c_int32), ("has_bypass", c_int32),
+        ("fixed_mask", c_uint32), ("reserved", c_uint32), ("fixed_raw", c_double * MAX_FX_PARAMS),
+    ]
+
+
+class Frontend(Structure):
+    _fields_ = [
+        ("n_fft", c_int32), ("hop", c_int32), ("n_mels", c_int32), ("norm_mode", c_int32),
+        ("window_dev", c_void_p), ("twiddle_dev", c_void_p), ("mel_start_dev", c_void_p),
+        ("mel_len_dev", c_void_p), ("mel_off_dev", c_void_p), ("mel_w_dev", c_void_p),
+        ("bn0_scale_dev", c_void_p), ("bn0_shift_dev", c_void_p),
+    ]
+
+
+class Cnn14Weights(Structure):
+    _fields_ = [
+        ("embed_dim", c_int32), ("n_mels", c_int32), ("channels", c_int32 * 7), ("reserved", c_int32),
+        ("conv_w_dev", c_void_p * 12), ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
+        ("fc_mid_wt_dev", c_void_p), ("fc_mid_b_dev", c_void_p),
+        ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
+    ]
+
+
+class StitoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/stito_hip.h
+SIGNATURES = {
+    "stito_last_error": (c_char_p, []),
+    "stito_version": (c_int, []),
+    "stito_fx_num_params": (c_int, [c_int]),
+    "stito_chain_out_channels": (c_int, [POINTER(FxDesc), c_int, c_int]),
+    "stito_chain_num_dims": (c_int, [POINTER(FxDesc), c_int]),
+    "stito_render_workspace_bytes": (c_size_t, [POINTER(FxDesc), c_int, c_int, c_int64, c_int]),
+    "stito_render_population": (c_int, [POINTER(FxDesc), c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_int,
+                                        c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "stito_peak": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "stito_normalize_audio": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "stito_num_frames": (c_int64, [c_int64, c_int]),
+    "stito_logmel": (c_int, [POINTER(Frontend), c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "stito_cnn14_packed_conv_floats": (c_size_t, [c_int, c_int]),
+    "stito_cnn14_pack_conv": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "stito_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "stito_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "stito_cnn14_workspace_bytes": (c_size_t, [POINTER(Cnn14Weights), c_int, c_int64]),
+    "stito_cnn14_forward": (c_int, [POINTER(Cnn14Weights), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    "stito_embed_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def lib():
+    """Load libstito_hip.so once.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StitoError(
+                f"{LIB_PATH} not found: build it with `make -C st-ito_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for this path."
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc == 0:
+        return
+    msg = lib().stito_last_error().decode("utf-8", "replace")
+    if rc in (E_INVALID,):
+        raise ValueError(msg)
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise StitoError(f"libstito_hip error {rc}: {msg}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise StitoError("st_ito (MI355X build): no HIP device visible; this path has no CPU fallback")
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor passed to libstito_hip must be contiguous"
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,158 @@
+"""Seeded (mu/mu_w, lambda)-CMA-ES with box constraints, the optimiser behind run_es.
+
+The reference drives pycma (`cma.CMAEvolutionStrategy(w0, sigma0, {"bounds": [0, 1],
+"popsize": P})`, st_ito/style_transfer.py:614, 624, 651-652, 672-673); pycma is an un-pinned
+third-party package that is not available here, so this module implements the same interface
+(ask / tell / result / disp / stop) with the standard algorithm (Hansen, "The CMA Evolution
+Strategy: A Tutorial"): weighted recombination, CSA step-size control, rank-one + rank-mu
+covariance update, lazy eigendecomposition, and pycma's BoxConstraintsLinQuadTransformation for
+the [0, 1] bounds.  It is deterministic under `seed`, uses only fitness ranks plus the best
+value, and every rank of a multi-GPU run steps an identical replica.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+class BoundTransform:
+    """pycma BoxConstraintsLinQuadTransformation for scalar bounds [lb, ub]: identity on
+    [lb+al, ub-au], quadratic towards the bounds, periodic mirroring outside [lb-al, ub+au]."""
+
+    def __init__(self, lb: float, ub: float):
+        self.lb, self.ub = float(lb), float(ub)
+        self.al = min((self.ub - self.lb) / 2.0, (1.0 + abs(self.lb)) / 20.0)
+        self.au = min((self.ub - self.lb) / 2.0, (1.0 + abs(self.ub)) / 20.0)
+
+    def __call__(self, y: np.ndarray) -> np.ndarray:
+        lb, ub, al, au = self.lb, self.ub, self.al, self.au
+        y = np.array(y, dtype=np.float64, copy=True)
+        lo, hi = lb - al, ub + au
+        period = 2.0 * (hi - lo)
+        # shift into [lo, lo + period), then mirror the upper half
+        y = lo + np.mod(y - lo, period)
+        y = np.where(y > hi, 2.0 * hi - y, y)
+        x = y.copy()
+        low = y < lb + al
+        x[low] = lb + (y[low] - (lb - al)) ** 2 / (4.0 * al)
+        up = y > ub - au
+        x[up] = ub - (y[up] - (ub + au)) ** 2 / (4.0 * au)
+        return x
+
+
+class _Result(tuple):
+    """es.result: indexable like pycma's (xbest, fbest, evals_best, evaluations, iterations, xmean, stds)."""
+
+    xbest = property(lambda s: s[0])
+    fbest = property(lambda s: s[1])
+
+
+class CMAEvolutionStrategy:
+    def __init__(self, x0: Sequence[float], sigma0: float, inopts: Optional[dict] = None):
+        opts = dict(inopts or {})
+        self.N = N = len(x0)
+        self.lam = int(opts.get("popsize", 4 + int(3 * math.log(N))))
+        if self.lam < 2:
+            raise ValueError("popsize must be >= 2")
+        seed = opts.get("seed", None)
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        b = opts.get("bounds", None)
+        self.boundary = BoundTransform(b[0], b[1]) if b is not None and b[0] is not None else None
+        self.mean = np.asarray(x0, dtype=np.float64).copy()
+        self.sigma = float(sigma0)
+        self.sigma0 = float(sigma0)
+        self.mu = self.lam // 2
+        w = math.log((self.lam + 1) / 2.0) - np.log(np.arange(1, self.mu + 1))
+        self.weights = w / w.sum()
+        self.mueff = 1.0 / np.sum(self.weights ** 2)
+        self.cc = (4 + self.mueff / N) / (N + 4 + 2 * self.mueff / N)
+        self.cs = (self.mueff + 2) / (N + self.mueff + 5)
+        self.c1 = 2 / ((N + 1.3) ** 2 + self.mueff)
+        self.cmu = min(1 - self.c1, 2 * (self.mueff - 2 + 1 / self.mueff) / ((N + 2) ** 2 + self.mueff))
+        self.damps = 1 + 2 * max(0.0, math.sqrt((self.mueff - 1) / (N + 1)) - 1) + self.cs
+        self.chiN = math.sqrt(N) * (1 - 1.0 / (4 * N) + 1.0 / (21 * N * N))
+        self.pc = np.zeros(N)
+        self.ps = np.zeros(N)
+        self.B = np.eye(N)
+        self.D = np.ones(N)
+        self.C = np.eye(N)
+        self.invsqrtC = np.eye(N)
+        self.eigeneval = 0
+        self.counteval = 0
+        self.countiter = 0
+        self.best_x: Optional[np.ndarray] = None
+        self.best_f = float("inf")
+        self.best_evals = 0
+        self._geno: Optional[np.ndarray] = None
+        self._stop = {}
+        self.maxiter = opts.get("maxiter", None)
+
+    # -- pycma-like surface ------------------------------------------------------------------
+    @property
+    def popsize(self):
+        return self.lam
+
+    def ask(self) -> List[np.ndarray]:
+        """lambda candidate solutions (phenotypes, inside the bounds)."""
+        z = self.rng.standard_normal((self.lam, self.N))
+        y = z * self.D[None, :] @ self.B.T
+        self._geno = self.mean[None, :] + self.sigma * y
+        ph = self._geno if self.boundary is None else self.boundary(self._geno)
+        return [ph[i].copy() for i in range(self.lam)]
+
+    def tell(self, solutions: Sequence[np.ndarray], function_values: Sequence[float]):
+        f = np.asarray(function_values, dtype=np.float64)
+        if len(f) != self.lam or self._geno is None:
+            raise ValueError("tell() needs the fitness of the lambda solutions of the last ask()")
+        N = self.N
+        self.counteval += self.lam
+        self.countiter += 1
+        order = np.argsort(f, kind="stable")
+        if f[order[0]] < self.best_f:
+            self.best_f = float(f[order[0]])
+            self.best_x = np.asarray(solutions[order[0]], dtype=np.float64).copy()
+            self.best_evals = self.counteval - self.lam + int(order[0]) + 1
+        X = self._geno[order[: self.mu]]
+        old = self.mean
+        self.mean = self.weights @ X
+        ymean = (self.mean - old) / self.sigma
+        self.ps = (1 - self.cs) * self.ps + math.sqrt(self.cs * (2 - self.cs) * self.mueff) * (self.invsqrtC @ ymean)
+        hsig = (np.linalg.norm(self.ps) / math.sqrt(1 - (1 - self.cs) ** (2 * self.countiter)) / self.chiN) < (1.4 + 2 / (N + 1))
+        self.pc = (1 - self.cc) * self.pc + (math.sqrt(self.cc * (2 - self.cc) * self.mueff) * ymean if hsig else 0.0)
+        Y = (X - old[None, :]) / self.sigma
+        c1a = self.c1 * (1 - (0 if hsig else 1) * self.cc * (2 - self.cc))
+        self.C = (1 - c1a - self.cmu) * self.C + self.c1 * np.outer(self.pc, self.pc) + self.cmu * (Y.T * self.weights[None, :]) @ Y
+        self.sigma *= math.exp(min(1.0, (self.cs / self.damps) * (np.linalg.norm(self.ps) / self.chiN - 1)))
+        if self.counteval - self.eigeneval > self.lam / (self.c1 + self.cmu) / N / 10:
+            self.eigeneval = self.counteval
+            self.C = np.triu(self.C) + np.triu(self.C, 1).T
+            d2, self.B = np.linalg.eigh(self.C)
+            self.D = np.sqrt(np.maximum(d2, 1e-30))
+            self.invsqrtC = (self.B / self.D[None, :]) @ self.B.T
+        self._geno = None
+        self._last_f = f[order]
+
+    @property
+    def result(self):
+        xm = self.mean if self.boundary is None else self.boundary(self.mean[None, :])[0]
+        return _Result((self.best_x, self.best_f, self.best_evals, self.counteval, self.countiter, xm,
+                        self.sigma * np.sqrt(np.diag(self.C))))
+
+    def stop(self):
+        d = {}
+        if self.maxiter is not None and self.countiter >= self.maxiter:
+            d["maxiter"] = self.maxiter
+        if self.sigma * float(self.D.max()) < 1e-11:
+            d["tolx"] = 1e-11
+        return d
+
+    def disp(self, modulo: int = 1):
+        if self.countiter == 1:
+            print("Iterat #Fevals   function value  axis ratio  sigma  min&max std")
+        if modulo and self.countiter % modulo == 0:
+            stds = self.sigma * np.sqrt(np.diag(self.C))
+            fbest_it = float(self._last_f[0]) if hasattr(self, "_last_f") else float("nan")
+            print(f"{self.countiter:5d} {self.counteval:6d} {fbest_it: .15e} {self.D.max() / self.D.min():.1e} "
+                  f"{self.sigma:.2e}  {stds.min():.0e}  {stds.max():.0e}")

@@ -1,0 +1,182 @@
+"""VST-like effect wrapper classes of the reference (st_ito/effects.py:783-985), as chain
+descriptors for the HIP renderer.
+
+Each Basic* class keeps the reference's duck-typed plugin protocol -- `.parameters`
+(name -> Parameter with raw_value in [0,1], set_value, get_value) and
+`.process(x, sample_rate)` on a (chs, n) float32 array -- but `.process` renders on the GPU
+through libstito_hip (stito_render_population with a population of one).  Inside run_es the
+instances are never called per candidate: the plugin dict is compiled once into a chain
+descriptor (st_ito.engine.compile_chain) and the whole population is rendered at once.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _hip
+
+
+class Parameter:
+    """reference st_ito/effects.py:784-797."""
+
+    def __init__(self, init_value: float, min_value: float, max_value: float):
+        self.min_value = min_value
+        self.max_value = max_value
+        self.set_value(init_value)
+
+    def set_value(self, value: float):
+        """Normalize the value to the range [0, 1] and store it as raw_value."""
+        assert self.min_value <= value <= self.max_value
+        self.raw_value = (value - self.min_value) / (self.max_value - self.min_value)
+
+    def get_value(self):
+        """Denormalize the value to the range [min_value, max_value]."""
+        return self.raw_value * (self.max_value - self.min_value) + self.min_value
+
+
+class _BasicEffect:
+    KIND = -1
+    NUM_CHANNELS = 1  # what run_optim.py:376-406 declares for this plugin
+
+    def process(self, x: np.ndarray, sample_rate: float) -> np.ndarray:
+        from .engine import render_single
+
+        return render_single(self, np.asarray(x), sample_rate)
+
+
+class BasicParametricEQ(_BasicEffect):
+    """reference effects.py:800-873 -> parametric_eq (453-512) -> biqaud (395-450)."""
+
+    KIND = _hip.FX_PARAMETRIC_EQ
+
+    def __init__(
+        self,
+        low_shelf_gain_db: float = 0.0, low_shelf_cutoff_freq: float = 80.0, low_shelf_q_factor: float = 0.707,
+        band0_gain_db: float = 0.0, band0_cutoff_freq: float = 300.0, band0_q_factor: float = 0.707,
+        band1_gain_db: float = 0.0, band1_cutoff_freq: float = 1000.0, band1_q_factor: float = 0.707,
+        band2_gain_db: float = 0.0, band2_cutoff_freq: float = 3000.0, band2_q_factor: float = 0.707,
+        band3_gain_db: float = 0.0, band3_cutoff_freq: float = 10000.0, band3_q_factor: float = 0.707,
+        high_shelf_gain_db: float = 0.0, high_shelf_cutoff_freq: float = 1000.0, high_shelf_q_factor: float = 0.707,
+    ):
+        self.parameters = OrderedDict([
+            ("low_shelf_gain_db", Parameter(low_shelf_gain_db, -24.0, 24.0)),
+            ("low_shelf_cutoff_freq", Parameter(low_shelf_cutoff_freq, 20.0, 4000.0)),
+            ("low_shelf_q_factor", Parameter(low_shelf_q_factor, 0.1, 4.0)),
+            ("band0_gain_db", Parameter(band0_gain_db, -24.0, 24.0)),
+            ("band0_cutoff_freq", Parameter(band0_cutoff_freq, 20.0, 10000.0)),
+            ("band0_q_factor", Parameter(band0_q_factor, 0.1, 4.0)),
+            ("band1_gain_db", Parameter(band1_gain_db, -24.0, 24.0)),
+            ("band1_cutoff_freq", Parameter(band1_cutoff_freq, 20.0, 10000.0)),
+            ("band1_q_factor", Parameter(band1_q_factor, 0.1, 4.0)),
+            ("band2_gain_db", Parameter(band2_gain_db, -24.0, 24.0)),
+            ("band2_cutoff_freq", Parameter(band2_cutoff_freq, 20.0, 10000.0)),
+            ("band2_q_factor", Parameter(band2_q_factor, 0.1, 4.0)),
+            ("band3_gain_db", Parameter(band3_gain_db, -24.0, 24.0)),
+            ("band3_cutoff_freq", Parameter(band3_cutoff_freq, 20.0, 10000.0)),
+            ("band3_q_factor", Parameter(band3_q_factor, 0.1, 4.0)),
+            ("high_shelf_gain_db", Parameter(high_shelf_gain_db, -24.0, 24.0)),
+            ("high_shelf_cutoff_freq", Parameter(high_shelf_cutoff_freq, 200.0, 18000.0)),
+            ("high_shelf_q_factor", Parameter(high_shelf_q_factor, 0.1, 4.0)),
+        ])
+
+
+class BasicCompressor(_BasicEffect):
+    """reference effects.py:876-897 (pedalboard.Compressor = juce::dsp::Compressor<float>)."""
+
+    KIND = _hip.FX_COMPRESSOR
+
+    def __init__(self, threshold_db: float = 0.0, ratio: float = 4.0, attack_ms: float = 1.0,
+                 release_ms: float = 100.0):
+        self.parameters = OrderedDict([
+            ("threshold_db", Parameter(threshold_db, -80.0, 0.0)),
+            ("ratio", Parameter(ratio, 1.0, 20.0)),
+            ("attack_ms", Parameter(attack_ms, 0.1, 100.0)),
+            ("release_ms", Parameter(release_ms, 10.0, 1000.0)),
+        ])
+
+
+class BasicDistortion(_BasicEffect):
+    """reference effects.py:900-916; like the reference the constructor ignores its arguments."""
+
+    KIND = _hip.FX_DISTORTION
+
+    def __init__(self, drive_db: float = 0.0, output_gain_db: float = 0.0):
+        self.parameters = OrderedDict([
+            ("drive_db", Parameter(0.0, -48.0, 48.0)),
+            ("output_gain_db", Parameter(0.0, -24.0, 24.0)),
+        ])
+
+
+class BasicDelay(_BasicEffect):
+    """reference effects.py:919-934 (pedalboard.Delay)."""
+
+    KIND = _hip.FX_DELAY
+    NUM_CHANNELS = 2
+
+    def __init__(self, delay_seconds: float = 0.5, feedback: float = 0.5, mix: float = 0.5):
+        self.parameters = OrderedDict([
+            ("delay_seconds", Parameter(delay_seconds, 0.01, 1.0)),
+            ("feedback", Parameter(feedback, 0.05, 1.0)),
+            ("mix", Parameter(mix, 0.0, 1.0)),
+        ])
+
+
+class BasicReverb(_BasicEffect):
+    """reference effects.py:937-959 (pedalboard.Reverb = juce::Reverb, Freeverb)."""
+
+    KIND = _hip.FX_REVERB
+    NUM_CHANNELS = 2
+
+    def __init__(self, room_size: float = 0.5, damping: float = 0.5, wet_dry: float = 0.5, width: float = 0.5):
+        self.parameters = OrderedDict([
+            ("room_size", Parameter(room_size, 0.0, 1.0)),
+            ("damping", Parameter(damping, 0.0, 1.0)),
+            ("wet_dry", Parameter(wet_dry, 0.0, 1.0)),
+            ("width", Parameter(width, 0.0, 1.0)),
+        ])
+
+
+class BasicGain(_BasicEffect):
+    """The 'gain' stage of the benchmark chain EQ/comp/reverb/EQ/gain: x * 10^(gain_db/20) with
+    gain_db in [-48, 48] as in the reference's apply_gain (effects.py:532-542)."""
+
+    KIND = _hip.FX_GAIN
+
+    def __init__(self, gain_db: float = 0.0):
+        self.parameters = OrderedDict([("gain_db", Parameter(gain_db, -48.0, 48.0))])
+
+
+class BasicChorus(_BasicEffect):
+    """reference effects.py:962-985 -- not on the ES path of run_optim.py; not built here."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("BasicChorus is outside the hot path built here (SURVEY.md section 8)")
+
+
+BASIC_CHAINS = {
+    # scripts/run_optim.py:375-407 (--effect-type basic)
+    "basic": [("ParametricEQ", BasicParametricEQ, 1), ("Compressor", BasicCompressor, 1),
+              ("Distortion", BasicDistortion, 1), ("Delay", BasicDelay, 2), ("Reverb", BasicReverb, 2)],
+    # BASELINE.json configs[0]: 2-effect chain
+    "eq-comp": [("ParametricEQ", BasicParametricEQ, 1), ("Compressor", BasicCompressor, 1)],
+    # BASELINE.json configs[1]: 5-effect chain EQ/comp/reverb/EQ/gain (D = 45)
+    "bench5": [("ParametricEQ", BasicParametricEQ, 1), ("Compressor", BasicCompressor, 1),
+               ("Reverb", BasicReverb, 2), ("ParametricEQ2", BasicParametricEQ, 1), ("Gain", BasicGain, 1)],
+    "eq": [("ParametricEQ", BasicParametricEQ, 1)],
+}
+
+
+def make_plugins(chain="basic", with_bypass: bool = False):
+    """Build a plugin dict in the reference's schema.  with_bypass=False follows
+    run_optim.py:409-437; with_bypass=True follows load_plugins (style_transfer.py:17-42)."""
+    spec = BASIC_CHAINS[chain] if isinstance(chain, str) else chain
+    plugins = OrderedDict()
+    for name, cls, nch in spec:
+        inst = cls()
+        names = list(inst.parameters.keys())
+        if with_bypass:
+            names = ["our_bypass"] + names
+        plugins[name] = {"class_path": cls, "num_params": len(names), "num_channels": nch,
+                         "fixed_parameters": {}, "instance": inst, "parameter_names": names}
+    return plugins

@@ -1,0 +1,213 @@
+"""Host-side orchestration of the HIP hot path: plugin dict -> chain descriptor, population
+rendering, embedding, loss.  Everything numeric happens in libstito_hip; torch only owns the
+buffers and the stream.
+
+Reference call sites replaced: the loop `for w in W: process_audio(...)`, the `embed_func` call
+and the cosine loss in run_es.evaluate (st_ito/style_transfer.py:504-573).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _hip
+
+CROP_LEN = 262144  # style_transfer.py:505
+
+
+# --------------------------------------------------------------------------------------------
+# plugin dict (reference schema) -> stito_fx_desc[]
+# --------------------------------------------------------------------------------------------
+def _instance_of(plugin: dict):
+    if "instance" not in plugin:
+        if "vst_filepath" in plugin:
+            raise NotImplementedError("VST plugins (pedalboard.load_plugin) are not supported in this build; "
+                                      "use --effect-type basic")
+        elif "class_path" in plugin:
+            plugin["instance"] = plugin["class_path"]()
+        else:
+            raise ValueError("Plugin must contain 'vst_filepath' or 'class_path'.")
+    return plugin["instance"]
+
+
+def compile_chain(plugins: Dict[str, dict]) -> Tuple[ctypes.Array, int]:
+    """Compile the reference's `plugins` dict into the C chain descriptor.
+
+    Mirrors how process_audio walks the dict (style_transfer.py:65-92): every name in
+    plugin["parameter_names"] consumes one slot of w; "our_bypass" is consumed and ignored;
+    names listed in plugin["fixed_parameters"] take the fixed value (via Parameter.set_value)
+    but still consume their slot."""
+    descs = (_hip.FxDesc * max(1, len(plugins)))()
+    off = 0
+    for i, (plugin_name, plugin) in enumerate(plugins.items()):
+        if "vst_filepath" in plugin and "class_path" not in plugin:
+            raise NotImplementedError("VST plugins are not supported in this build; use --effect-type basic")
+        inst = _instance_of(plugin)
+        kind = getattr(inst, "KIND", -1)
+        if kind < 0:
+            raise ValueError(f"Plugin {plugin_name}: {type(inst).__name__} is not an effect of this build")
+        names = list(plugin.get("parameter_names") or list(inst.parameters.keys()))
+        has_bypass = 1 if (names and names[0] == "our_bypass") else 0
+        real = names[has_bypass:]
+        if "our_bypass" in real or real != list(inst.parameters.keys()):
+            raise ValueError(f"Plugin {plugin_name}: parameter_names {names} do not match {list(inst.parameters)}")
+        d = descs[i]
+        d.kind, d.num_channels, d.w_offset, d.has_bypass = kind, int(plugin["num_channels"]), off, has_bypass
+        if d.num_channels not in (1, 2):
+            raise ValueError(f"Plugin {plugin_name}: num_channels must be 1 or 2")
+        mask = 0
+        for p, name in enumerate(real):
+            if name in plugin.get("fixed_parameters", {}):
+                prm = inst.parameters[name]
+                prm.set_value(plugin["fixed_parameters"][name])  # asserts the range like the reference
+                d.fixed_raw[p] = prm.raw_value
+                mask |= 1 << p
+        d.fixed_mask = mask
+        off += len(names)
+    return descs, off
+
+
+class _Workspace:
+    """Grow-only device scratch buffers keyed by name (torch owns the memory)."""
+
+    def __init__(self):
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, nbytes: int, device) -> torch.Tensor:
+        b = self._bufs.get(name)
+        if b is None or b.numel() < nbytes or b.device != device:
+            b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[name] = b
+        return b
+
+
+_WS = _Workspace()
+
+
+def render_population(plugins: Dict[str, dict], x: torch.Tensor, W: torch.Tensor, sample_rate: float,
+                      chain=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x (C, L) float32 on the GPU, W (P, D) float64 on the GPU -> (audio (P, C', L) before peak
+    normalisation, peaks (P,))."""
+    _hip.require_gpu()
+    L = _hip.lib()
+    descs, ndims = chain if chain is not None else compile_chain(plugins)
+    n_fx = len(plugins)
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    assert W.is_cuda and W.dtype == torch.float64 and W.dim() == 2
+    x = x.contiguous()
+    W = W.contiguous()
+    if W.shape[1] != ndims:
+        raise ValueError(f"parameter vector has {W.shape[1]} dims, chain consumes {ndims}")
+    C, n = x.shape
+    P = W.shape[0]
+    c_out = L.stito_chain_out_channels(descs, n_fx, C)
+    audio = torch.empty((P, c_out, n), dtype=torch.float32, device=x.device)
+    peaks = torch.empty((P,), dtype=torch.float32, device=x.device)
+    need = L.stito_render_workspace_bytes(descs, n_fx, C, n, P)
+    ws = _WS.get("render", need, x.device)
+    _hip.check(L.stito_render_population(descs, n_fx, _hip.ptr(x), C, n, _hip.ptr(W), P, ndims, float(sample_rate),
+                                         _hip.ptr(audio), _hip.ptr(peaks), _hip.ptr(ws), ws.numel(),
+                                         _hip.stream_ptr()))
+    return audio, peaks
+
+
+def normalize_audio_(audio: torch.Tensor, peaks: torch.Tensor) -> torch.Tensor:
+    """In place: audio[p] /= clip(peaks[p], 1e-8)  (style_transfer.py:113)."""
+    P, C, n = audio.shape
+    _hip.check(_hip.lib().stito_normalize_audio(_hip.ptr(audio), P, C, n, _hip.ptr(peaks), _hip.stream_ptr()))
+    return audio
+
+
+def render_single(instance, x: np.ndarray, sample_rate: float) -> np.ndarray:
+    """Basic*.process(x, sample_rate): one effect, current parameter values, (chs, n) -> (chs', n)."""
+    _hip.require_gpu()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.ndim != 2:
+        raise ValueError("process expects a (chs, n) array")
+    # .process() is called with exactly the channels the effect should see; a stereo effect
+    # called with mono audio is fed the mono signal as in pedalboard (no up-mix here).
+    nch = 2 if (x.shape[0] == 2 and instance.NUM_CHANNELS == 2) else 1
+    plugins = {"fx": {"class_path": type(instance), "instance": instance, "num_channels": nch,
+                      "fixed_parameters": {}, "parameter_names": list(instance.parameters.keys()),
+                      "num_params": len(instance.parameters)}}
+    w = np.array([[p.raw_value for p in instance.parameters.values()]], dtype=np.float64)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    audio, _ = render_population(plugins, torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), sample_rate)
+    return audio[0].cpu().numpy()
+
+
+def process_audio_gpu(x: np.ndarray, w: np.ndarray, sr: int, plugins: Dict[str, dict]) -> np.ndarray:
+    """process_audio for one parameter vector (style_transfer.py:45-115)."""
+    _hip.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+    wt = torch.as_tensor(np.asarray(w, dtype=np.float64)[None, :]).to(dev)
+    audio, peaks = render_population(plugins, xt, wt, sr)
+    normalize_audio_(audio, peaks)
+    return audio[0].cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# population evaluation
+# --------------------------------------------------------------------------------------------
+class PopulationEvaluator:
+    """GPU replacement of run_es.evaluate (style_transfer.py:474-573) for the AFx-Rep metric.
+
+    One instance per run_es call: holds the (padded) input on the device, the compiled chain
+    and the target embeddings.  evaluate(W) returns the fitness list; embeddings and (lazily)
+    normalised audio are available for --savepop."""
+
+    def __init__(self, x: torch.Tensor, sample_rate: int, plugins: Dict[str, dict], model, target_embeds: dict,
+                 device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None):
+        _hip.require_gpu()
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.sample_rate = sample_rate
+        self.plugins = plugins
+        self.model = model
+        self.chain = compile_chain(plugins)
+        self.ndims = self.chain[1]
+        assert x.dim() == 3 and x.shape[0] == 1, "evaluate assumes a batch of one input (style_transfer.py:520)"
+        self.x_full = x[0].to(self.device, torch.float32).contiguous()
+        self.tmid = target_embeds["mid"].to(self.device, torch.float32).contiguous().view(-1)
+        self.tside = target_embeds["side"].to(self.device, torch.float32).contiguous().view(-1)
+        self.max_cand = max_candidates_per_pass
+        self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+    def _input(self, random_crop: bool, rng) -> torch.Tensor:
+        """Length policy of style_transfer.py:505-518."""
+        x = self.x_full
+        n = x.shape[-1]
+        if n > CROP_LEN:
+            if random_crop and (n - CROP_LEN) > 16384:
+                start = int(rng.randint(16384, n - CROP_LEN))
+                return x[:, start:start + CROP_LEN].contiguous()
+            return x
+        return torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
+
+    def evaluate(self, W, random_crop: bool = False, rng=np.random, want_audio: bool = False, dropout: float = 0.0):
+        Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
+        if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
+            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
+        x = self._input(random_crop, rng)
+        P = Wt.shape[0]
+        step = self.max_cand or P
+        losses, mids, sides, audios = [], [], [], []
+        for p0 in range(0, P, step):
+            Wc = Wt[p0:p0 + step].contiguous()
+            audio, peaks = render_population(self.plugins, x, Wc, self.sample_rate, chain=self.chain)
+            mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
+            if dropout > 0.0:
+                raise NotImplementedError("embedding dropout inside evaluate is not built (run_optim default is 0.0)")
+            loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
+            _hip.check(_hip.lib().stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1],
+                                                   _hip.ptr(self.tmid), _hip.ptr(self.tside), _hip.ptr(loss),
+                                                   _hip.ptr(self.flags), _hip.stream_ptr()))
+            losses.append(loss); mids.append(mid); sides.append(side)
+            if want_audio:
+                audios.append(normalize_audio_(audio, peaks))
+        loss = torch.cat(losses)
+        embeds = {"mid": torch.cat(mids), "side": torch.cat(sides)}
+        return loss, embeds, (torch.cat(audios) if want_audio else None)

@@ -1,0 +1,289 @@
+"""AFx-Rep encoder (Cnn14) of the reference (st_ito/models/panns.py:121-281) with the forward
+pass on hand-written HIP kernels.
+
+The module keeps the reference's constructor signature and state_dict keys (including
+torchlibrosa's frozen front-end parameters `spectrogram_extractor.stft.conv_{real,imag}.weight`
+and `logmel_extractor.melW`) so that `load_param_model` can load the published afx-rep.ckpt with
+strict=True.  forward() has no PyTorch implementation: it calls libstito_hip and raises when no
+GPU / library is available.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+
+
+def _hann_periodic(n: int) -> np.ndarray:
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def _dft_conv_kernels(n_fft: int, window: np.ndarray):
+    """torchlibrosa STFT kernels: Re/Im of the windowed DFT matrix, (n_fft//2+1, 1, n_fft) float32."""
+    nb = n_fft // 2 + 1
+    k = np.arange(nb)[:, None]
+    n = np.arange(n_fft)[None, :]
+    ang = -2.0 * np.pi * ((k * n) % n_fft) / n_fft
+    real = (np.cos(ang) * window[None, :]).astype(np.float32)[:, None, :]
+    imag = (np.sin(ang) * window[None, :]).astype(np.float32)[:, None, :]
+    return torch.from_numpy(real), torch.from_numpy(imag)
+
+
+def _mel_filterbank(sr: float, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """librosa.filters.mel (Slaney scale, slaney norm) -> (n_mels, n_fft//2+1) float32; what
+    torchlibrosa's LogmelFilterBank stores (transposed) as melW (panns.py:158-168)."""
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz2mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+
+    def mel2hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, float(sr) / 2, 1 + n_fft // 2)
+    mel_f = mel2hz(np.linspace(hz2mel(fmin), hz2mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+class _Holder(nn.Module):
+    """Namespace module so that parameter names match torchlibrosa's."""
+
+
+class ConvBlock(nn.Module):
+    """Parameter container for reference panns.py:25-80 (conv1/bn1/conv2/bn2)."""
+
+    def __init__(self, in_channels: int, out_channels: int, use_batchnorm: bool = True):
+        super().__init__()
+        self.use_batchnorm = use_batchnorm
+        self.conv1 = nn.Conv2d(in_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels) if use_batchnorm else nn.Identity()
+        self.bn2 = nn.BatchNorm2d(out_channels) if use_batchnorm else nn.Identity()
+        nn.init.xavier_uniform_(self.conv1.weight)
+        nn.init.xavier_uniform_(self.conv2.weight)
+
+
+class Cnn14(nn.Module):
+    def __init__(self, embed_dim: int, sample_rate: float, window_size: int, hop_size: int, mel_bins: int,
+                 fmin: float, fmax: float, use_batchnorm: bool = False, input_norm: str = "batchnorm"):
+        super().__init__()
+        if input_norm not in ("batchnorm", "minmax", "none"):
+            raise ValueError(f"Invalid input_norm: {input_norm}")
+        self.embed_dim, self.use_batchnorm, self.input_norm = embed_dim, use_batchnorm, input_norm
+        self.sample_rate, self.window_size, self.hop_size, self.mel_bins = sample_rate, window_size, hop_size, mel_bins
+
+        # torchlibrosa-compatible frozen front-end parameters
+        self.spectrogram_extractor = _Holder()
+        self.spectrogram_extractor.stft = _Holder()
+        nb = window_size // 2 + 1
+        self.spectrogram_extractor.stft.conv_real = nn.Conv1d(1, nb, window_size, stride=hop_size, bias=False)
+        self.spectrogram_extractor.stft.conv_imag = nn.Conv1d(1, nb, window_size, stride=hop_size, bias=False)
+        r, i = _dft_conv_kernels(window_size, _hann_periodic(window_size))
+        self.spectrogram_extractor.stft.conv_real.weight.data = r
+        self.spectrogram_extractor.stft.conv_imag.weight.data = i
+        self.logmel_extractor = _Holder()
+        self.logmel_extractor.melW = nn.Parameter(
+            torch.from_numpy(_mel_filterbank(sample_rate, window_size, mel_bins, fmin, fmax).T.copy()))
+        for p in list(self.spectrogram_extractor.parameters()) + list(self.logmel_extractor.parameters()):
+            p.requires_grad = False
+
+        self.bn0 = nn.BatchNorm2d(mel_bins)
+        chans = [1, 64, 128, 256, 512, 1024, 2048]
+        for b in range(6):
+            setattr(self, f"conv_block{b + 1}", ConvBlock(chans[b], chans[b + 1], use_batchnorm))
+        self.fc_mid = nn.Linear(2048, embed_dim, bias=True)
+        self.fc_side = nn.Linear(2048, embed_dim, bias=True)
+        nn.init.xavier_uniform_(self.fc_mid.weight)
+        nn.init.xavier_uniform_(self.fc_side.weight)
+        self.fc_mid.bias.data.fill_(0.0)
+        self.fc_side.bias.data.fill_(0.0)
+
+        self._packed = None      # device-side packed weights, built lazily
+        self._packed_key = None
+        self._ws = None
+        self.max_streams_per_pass = int(os.environ.get("STITO_MAX_STREAMS", "128"))
+
+    # ------------------------------------------------------------------------------------
+    def _invalidate(self):
+        self._packed = None
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return out
+
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def prepare(self):
+        """Pack conv weights, fold BN, transpose FC weights and build the front-end tables on
+        the device (all through libstito_hip kernels / tiny host tables)."""
+        _hip.require_gpu()
+        dev = self._device()
+        if dev.type != "cuda":
+            raise _hip.StitoError("Cnn14 (MI355X build) must live on the GPU: call load_param_model(use_gpu=True) "
+                                  "or model.cuda(); there is no CPU forward")
+        if self.training:
+            raise NotImplementedError("Cnn14 (MI355X build) is inference-only (model.eval())")
+        L = _hip.lib()
+        st = _hip.stream_ptr()
+        keep = []
+        W = _hip.Cnn14Weights()
+        W.embed_dim, W.n_mels = self.embed_dim, self.mel_bins
+        chans = [1, 64, 128, 256, 512, 1024, 2048]
+        for i, c in enumerate(chans):
+            W.channels[i] = c
+        for b in range(6):
+            blk = getattr(self, f"conv_block{b + 1}")
+            for j, (conv, bn) in enumerate(((blk.conv1, blk.bn1), (blk.conv2, blk.bn2))):
+                w = conv.weight.detach().to(torch.float32).contiguous()
+                cout, cin = w.shape[0], w.shape[1]
+                packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin), dtype=torch.float32, device=dev)
+                _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.ptr(packed), st))
+                scale = torch.empty(cout, dtype=torch.float32, device=dev)
+                shift = torch.empty(cout, dtype=torch.float32, device=dev)
+                if isinstance(bn, nn.BatchNorm2d):
+                    args = [t.detach().to(torch.float32).contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+                    _hip.check(L.stito_bn_fold(*[_hip.ptr(t) for t in args], float(bn.eps), cout, _hip.ptr(scale), _hip.ptr(shift), st))
+                    keep += args
+                else:
+                    _hip.check(L.stito_bn_fold(None, None, None, None, 0.0, cout, _hip.ptr(scale), _hip.ptr(shift), st))
+                idx = 2 * b + j
+                W.conv_w_dev[idx], W.bn_scale_dev[idx], W.bn_shift_dev[idx] = packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
+                keep += [w, packed, scale, shift]
+        for name in ("mid", "side"):
+            fc = getattr(self, f"fc_{name}")
+            w = fc.weight.detach().to(torch.float32).contiguous()           # (E, 2048)
+            wt = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float32, device=dev)
+            _hip.check(L.stito_transpose(_hip.ptr(w), w.shape[0], w.shape[1], _hip.ptr(wt), st))
+            b = fc.bias.detach().to(torch.float32).contiguous()
+            setattr(W, f"fc_{name}_wt_dev", wt.data_ptr())
+            setattr(W, f"fc_{name}_b_dev", b.data_ptr())
+            keep += [w, wt, b]
+
+        # ---- front end tables ---------------------------------------------------------------
+        n_fft = self.window_size
+        cr = self.spectrogram_extractor.stft.conv_real.weight.detach().cpu().numpy()[:, 0, :]
+        ci = self.spectrogram_extractor.stft.conv_imag.weight.detach().cpu().numpy()[:, 0, :]
+        window = cr[0].astype(np.float64)  # bin 0: cos(0) * window
+        # the FFT path assumes the stored kernels ARE a windowed DFT; verify on a few bins
+        nn_ = np.arange(n_fft)
+        for kbin in (1, 7, n_fft // 4, n_fft // 2):
+            ang = -2.0 * np.pi * ((kbin * nn_) % n_fft) / n_fft
+            if (np.abs(cr[kbin] - np.cos(ang) * window).max() > 1e-4 or np.abs(ci[kbin] - np.sin(ang) * window).max() > 1e-4):
+                raise NotImplementedError("checkpoint STFT kernels are not a windowed DFT; unsupported front-end")
+        FE = _hip.Frontend()
+        FE.n_fft, FE.hop, FE.n_mels = n_fft, self.hop_size, self.mel_bins
+        FE.norm_mode = {"none": _hip.NORM_NONE, "minmax": _hip.NORM_MINMAX, "batchnorm": _hip.NORM_BATCHNORM}[self.input_norm]
+        win_t = torch.from_numpy(window.astype(np.float32)).to(dev)
+        kk = np.arange(n_fft // 2)
+        tw = np.stack([np.cos(-2 * np.pi * kk / n_fft), np.sin(-2 * np.pi * kk / n_fft)], 1).astype(np.float32)
+        tw_t = torch.from_numpy(tw).to(dev).contiguous()
+        melW = self.logmel_extractor.melW.detach().cpu().numpy()  # (n_bins, n_mels)
+        starts, lens, offs, packed_w = [], [], [], []
+        for m in range(self.mel_bins):
+            nz = np.nonzero(melW[:, m])[0]
+            s, e = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 0)
+            starts.append(s); lens.append(e - s); offs.append(sum(len(a) for a in packed_w))
+            packed_w.append(melW[s:e, m].astype(np.float32))
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)  # noqa: E731
+        ms, ml, mo = i32(starts), i32(lens), i32(offs)
+        mw = torch.from_numpy(np.concatenate(packed_w + [np.zeros(1, np.float32)])).to(dev)
+        FE.window_dev, FE.twiddle_dev = win_t.data_ptr(), tw_t.data_ptr()
+        FE.mel_start_dev, FE.mel_len_dev, FE.mel_off_dev, FE.mel_w_dev = ms.data_ptr(), ml.data_ptr(), mo.data_ptr(), mw.data_ptr()
+        keep += [win_t, tw_t, ms, ml, mo, mw]
+        if self.input_norm == "batchnorm":
+            bn = self.bn0
+            sc = torch.empty(self.mel_bins, dtype=torch.float32, device=dev)
+            sh = torch.empty(self.mel_bins, dtype=torch.float32, device=dev)
+            args = [t.detach().to(torch.float32).contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+            _hip.check(L.stito_bn_fold(*[_hip.ptr(t) for t in args], float(bn.eps), self.mel_bins, _hip.ptr(sc), _hip.ptr(sh), st))
+            FE.bn0_scale_dev, FE.bn0_shift_dev = sc.data_ptr(), sh.data_ptr()
+            keep += args + [sc, sh]
+        self._packed = (W, FE, keep)
+        return self._packed
+
+    def _ensure(self):
+        if self._packed is None:
+            self.prepare()
+        return self._packed
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self._device():
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._device())
+        return self._ws
+
+    # ------------------------------------------------------------------------------------
+    def logmel(self, audio: torch.Tensor, peaks: Optional[torch.Tensor] = None, norm_passes: int = 0) -> torch.Tensor:
+        """(B, C, L) float32 on the GPU -> normalised log-mel (B*C, T, M) (panns.py:213-245)."""
+        W, FE, _ = self._ensure()
+        B, C, n = audio.shape
+        if C not in (1, 2):
+            raise ValueError(f"Invalid number of channels: {C}")
+        L = _hip.lib()
+        T = L.stito_num_frames(n, self.hop_size)
+        out = torch.empty((B * C, T, self.mel_bins), dtype=torch.float32, device=audio.device)
+        _hip.check(L.stito_logmel(FE, _hip.ptr(audio), _hip.ptr(peaks), norm_passes, B, C, n, _hip.ptr(out), _hip.stream_ptr()))
+        return out
+
+    def trunk(self, logmel: torch.Tensor, n_cand: int, channels: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """log-mel (n_cand*channels, T, M) -> raw (mid, side) fc outputs (panns.py:250-281)."""
+        W, FE, _ = self._ensure()
+        L = _hip.lib()
+        T = logmel.shape[1]
+        dev = logmel.device
+        mid = torch.empty((n_cand, self.embed_dim), dtype=torch.float32, device=dev)
+        side = torch.empty((n_cand, self.embed_dim), dtype=torch.float32, device=dev)
+        need = L.stito_cnn14_workspace_bytes(W, n_cand * channels, T)
+        ws = self._workspace(need)
+        _hip.check(L.stito_cnn14_forward(W, _hip.ptr(logmel), n_cand, channels, T, _hip.ptr(mid), _hip.ptr(side),
+                                         _hip.ptr(ws), ws.numel(), _hip.stream_ptr()))
+        return mid, side
+
+    def embed_raw(self, audio: torch.Tensor, peaks: Optional[torch.Tensor], norm_passes: int):
+        """audio (B, C, L) on the GPU (+ per-item peaks) -> raw (mid, side), sub-batched so that the
+        activation workspace stays bounded."""
+        audio = audio.contiguous()
+        B, C, _ = audio.shape
+        step = max(1, self.max_streams_per_pass // C)
+        mids, sides = [], []
+        for b0 in range(0, B, step):
+            a = audio[b0:b0 + step]
+            p = peaks[b0:b0 + step].contiguous() if peaks is not None else None
+            lm = self.logmel(a, p, norm_passes)
+            m, s = self.trunk(lm, a.shape[0], C)
+            mids.append(m); sides.append(s)
+        return (torch.cat(mids), torch.cat(sides)) if len(mids) > 1 else (mids[0], sides[0])
+
+    def forward(self, x: torch.Tensor):
+        """input: waveform (batch_size, chs, seq_len) -> (mid_embed, side_embed)  (panns.py:209-281)."""
+        _hip.require_gpu()
+        if x.dim() != 3:
+            raise ValueError("expected (batch, chs, seq_len)")
+        if x.shape[1] not in (1, 2):
+            raise ValueError(f"Invalid number of channels: {x.shape[1]}")
+        dev = self._device()
+        xin = x.detach().to(dev, torch.float32)
+        mid, side = self.embed_raw(xin, None, 0)
+        return mid, side

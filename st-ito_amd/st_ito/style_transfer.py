@@ -1,0 +1,268 @@
+"""Inference-time optimisation (ES) of the reference, st_ito/style_transfer.py: `load_plugins`
+(17-42), `process_audio` (45-115), `parameters_to_dict` (324-359), `savepop_to_disk` (362-396)
+and `run_es` (399-692), with the evaluate-population step on the MI355X.
+
+Only the ES path is built; the baselines of the reference file (run_input, run_random,
+run_rule_based, run_deepafx_st) are outside this build's scope.
+"""
+from __future__ import annotations
+
+import os
+from typing import List
+
+import numpy as np
+import torch
+
+from . import cmaes as cma
+from . import engine
+
+
+# ------- audio processing methods -------
+def load_plugins(plugins: dict):
+    """reference style_transfer.py:17-42: instantiate, prepend the (dead) "our_bypass" slot."""
+    total_num_params = 0
+    init_params = []
+    for plugin_name, plugin in plugins.items():
+        if "vst_filepath" in plugin:
+            raise NotImplementedError("VST plugins (pedalboard.load_plugin) are not supported in this build")
+        elif "class_path" in plugin:
+            plugin_instance = plugin["class_path"]()
+        else:
+            raise ValueError(f"Plugin must contain 'vst_filepath' or 'class_path'.")
+        plugin["parameter_names"] = ["our_bypass"]
+        init_params.append(0.0)
+        num_params = 1
+        for name, parameter in plugin_instance.parameters.items():
+            num_params += 1
+            print(f"{plugin_name}: {name} = {parameter.raw_value}")
+            init_params.append(parameter.raw_value)
+            plugin["parameter_names"].append(name)
+        print()
+        plugin["num_params"] = num_params
+        plugin["instance"] = plugin_instance
+        total_num_params += num_params
+    return plugins, total_num_params, init_params
+
+
+def process_audio(x: np.ndarray, w: np.ndarray, sr: int, plugins: List[dict], normalize_stages: bool = False):
+    """Process audio with plugins and provided parameters on [0, 1] (reference
+    style_transfer.py:45-115).  x: (chs, num_samples) float32, w: (num_params,).  Rendered on the
+    GPU by stito_render_population + stito_normalize_audio."""
+    if normalize_stages:
+        raise NotImplementedError("normalize_stages=True is not built (run_es never forwards it, "
+                                  "style_transfer.py:419-420)")
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    if isinstance(w, torch.Tensor):
+        w = w.detach().cpu().numpy()
+    return engine.process_audio_gpu(x, w, sr, plugins)
+
+
+def parameters_to_dict(w: np.ndarray, plugins: List[dict]):
+    """Convert parameter vector to dictionary (reference style_transfer.py:324-359), including the
+    side effect of writing the values into the plugin instances."""
+    widx = 0
+    w_dict = {}
+    for plugin_name, plugin in plugins.items():
+        if plugin_name not in w_dict:
+            w_dict[plugin_name] = {}
+        for name in plugin["parameter_names"]:
+            if name == "our_bypass":
+                w_dict[plugin_name][name] = w[widx]
+                widx += 1
+                continue
+            parameter = engine._instance_of(plugin).parameters[name]
+            if name in plugin["fixed_parameters"]:
+                parameter.set_value(plugin["fixed_parameters"][name])
+                widx += 1
+            else:
+                parameter.raw_value = w[widx]
+                widx += 1
+            if hasattr(parameter, "get_value"):
+                w_dict[plugin_name][name] = parameter.get_value()
+            else:
+                w_dict[plugin_name][name] = parameter.raw_value
+    return w_dict
+
+
+def savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir: str, sample_rate: int):
+    """reference style_transfer.py:362-396: one wav per candidate, sorted by fitness."""
+    from .audio_io import save_wav
+
+    pop_dir = os.path.join(run_dir, f"pop_{iteration}")
+    os.makedirs(pop_dir, exist_ok=True)
+    order = sorted(range(len(fvals)), key=lambda i: fvals[i])
+    for idx, i in enumerate(order):
+        audio = output_audios[i]
+        audio = audio / torch.max(torch.abs(audio)).clamp(min=1e-8)
+        save_wav(os.path.join(pop_dir, f"output_audio_pop_{idx}_fval_{fvals[i]:0.4e}.wav"), audio.cpu(), sample_rate)
+
+
+# ----------- Evolutionary Strategies ------------
+def _dist_info():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def shard_bounds(popsize: int, rank: int, world: int):
+    """Candidates [lo, hi) of the ask() batch owned by `rank` (contiguous, near-equal shards)."""
+    base, rem = divmod(popsize, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_fitness(local: torch.Tensor, popsize: int) -> torch.Tensor:
+    """All-gather the per-rank fitness shards into candidate order (RCCL when the tensors are on
+    the GPU, gloo on CPU).  Shards may differ by one element, so pad to the largest."""
+    dist, rank, world = _dist_info()
+    if world == 1:
+        return local
+    per = (popsize + world - 1) // world
+    buf = torch.full((per,), float("inf"), dtype=local.dtype, device=local.device)
+    buf[: local.numel()] = local
+    out = torch.empty((world, per), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), buf)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(popsize, r, world)
+        parts.append(out[r, : hi - lo])
+    return torch.cat(parts)
+
+
+def run_es(
+    input_audio: torch.Tensor,
+    target_audio: torch.Tensor,
+    sample_rate: int,
+    plugins: List[dict],
+    model: torch.nn.Module,
+    embed_func: callable,
+    content_model: torch.nn.Module = None,
+    content_embed_func: callable = None,
+    max_iters: int = 100,
+    w0: torch.Tensor = None,
+    find_w0: bool = True,
+    sigma0: float = 0.1,
+    distance: str = "cosine",
+    random_crop: bool = False,
+    popsize: int = 32,
+    parallel: bool = False,
+    dropout: float = 0.0,
+    savepop: bool = False,
+    run_dir: str = ".",
+    seed: int = None,
+    early_stop: bool = True,
+    *args,
+    **kwargs,
+):
+    """Run CMA-ES optimization to find the best parameters (reference style_transfer.py:399-692).
+
+    Same arguments and result dict as the reference (`parallel` is accepted and ignored: the whole
+    population is rendered on the GPU at once).  Extensions: `seed` (CMA-ES + find_w0 RNG; the
+    reference is unseeded) and `early_stop` (False disables the break of lines 655-670 for fixed
+    work benchmarks).  Under torch.distributed each rank evaluates a contiguous shard of the
+    population and the fitness scalars are all-gathered; the CMA-ES state is replicated."""
+    if distance != "cosine":
+        raise ValueError(f"Unknown distance: {distance}")
+    if content_model is not None:
+        raise NotImplementedError("content_model is not built (unused by run_optim.py)")
+    total_num_params = sum([plugin["num_params"] for plugin in plugins.values()])
+    bs, chs, seq_len = input_audio.shape
+    rng = np.random.RandomState(seed) if seed is not None else np.random
+
+    # peak normalize (in place like the reference, 452-453)
+    input_audio /= torch.max(torch.abs(input_audio)).clamp(min=1e-8)
+    target_audio /= torch.max(torch.abs(target_audio)).clamp(min=1e-8)
+
+    # compute target embedding (only once)
+    target_embed = embed_func(target_audio, model, sample_rate)
+
+    evaluator = engine.PopulationEvaluator(input_audio, sample_rate, plugins, model, target_embed)
+    if evaluator.ndims != total_num_params:
+        raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
+    _, rank, world = _dist_info()
+
+    def evaluate(W, dropout: float = 0.0, want_audio: bool = False):
+        """GPU replacement of the reference's evaluate closure (474-573)."""
+        P = len(W)
+        lo, hi = shard_bounds(P, rank, world)
+        loss, embeds, audios = evaluator.evaluate(W[lo:hi], random_crop=random_crop, rng=rng,
+                                                  want_audio=want_audio, dropout=dropout)
+        loss = gather_fitness(loss, P)
+        return loss.tolist(), embeds, audios
+
+    # setup CMA-ES
+    if find_w0:
+        print("Finding the best w0...")
+        tmp_w0s = [rng.rand(total_num_params) for _ in range(popsize)]
+        fvals, output_embeds, output_audios = evaluate(tmp_w0s, dropout=dropout, want_audio=savepop)
+        print(fvals)
+        w0 = tmp_w0s[int(np.argmin(fvals))]
+        if savepop and rank == 0:
+            savepop_to_disk(-1, fvals, output_embeds, output_audios, run_dir, sample_rate)
+    else:
+        if w0 is None:
+            w0 = np.ones(total_num_params) * 0.5
+        else:
+            w0 = w0.numpy() if isinstance(w0, torch.Tensor) else np.asarray(w0)
+
+    init_param_dict = parameters_to_dict(w0, plugins)
+    print(init_param_dict)
+
+    opts = {"bounds": [0, 1], "popsize": popsize}
+    if seed is not None:
+        opts["seed"] = seed
+    es = cma.CMAEvolutionStrategy(w0, sigma0, opts)
+
+    fval_history = []
+    wopt_history = []
+    iters_without_improvement = 0
+    n_evals = popsize if find_w0 else 0
+
+    for iteration in range(max_iters):
+        W = es.ask()
+        fvals, output_embeds, output_audios = evaluate(
+            W, dropout=(dropout if (iteration + 1) < max_iters else 0.0), want_audio=savepop)
+        n_evals += len(W)
+
+        # save best (pre-tell result, like the reference: index 0 is (None, inf))
+        wopt_history.append(es.result[0])
+        fval_history.append(es.result[1])
+
+        if savepop and rank == 0:
+            savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir, sample_rate)
+        es.tell(W, fvals)
+        if rank == 0:
+            es.disp()
+
+        if iteration > 0:
+            fval_delta = min(fvals) - min(fval_history)
+        else:
+            fval_delta = -0.02
+        if fval_delta > -0.01:
+            iters_without_improvement += 1
+            if rank == 0:
+                print(f"Solution has not improved for {iters_without_improvement} iterations.")
+        else:
+            iters_without_improvement = 0
+        if early_stop and iters_without_improvement > 10:
+            print("Stopping early due to no improvement.")
+            break
+
+    wopt = es.result[0]
+    fopt = es.result[1]
+
+    # render the current solution on the full (un-padded) input, like the reference (676-678)
+    output_audio = torch.from_numpy(process_audio(input_audio.squeeze(0).cpu().numpy(), wopt, sample_rate, plugins))
+    param_dict = parameters_to_dict(wopt, plugins)
+    return {
+        "output_audio": output_audio,
+        "params": param_dict,
+        "fopt": fopt,
+        "wopt": wopt,
+        "fval_history": fval_history,
+        "wopt_history": wopt_history,
+        "num_evals": n_evals,
+    }

@@ -1,0 +1,128 @@
+"""Loader / embedding-function pair of the AFx-Rep metric: the reference's
+st_ito/utils.py:444-551 (`get_param_embeds`, `load_param_model`) plus `apply_fade_in` (31-43).
+The other metrics of the reference's utils.py (CLAP, BEATs, wav2vec2, ...) are outside this
+build's scope."""
+from __future__ import annotations
+
+import os
+from importlib import import_module
+
+import torch
+import yaml
+
+from . import _hip
+
+
+def apply_fade_in(x: torch.Tensor, num_samples: int = 16384):
+    """reference utils.py:31-43."""
+    fade = torch.linspace(0, 1, num_samples, device=x.device)
+    x[..., :num_samples] = x[..., :num_samples] * fade
+    return x
+
+
+def get_param_embeds(
+    x: torch.Tensor,
+    model: torch.nn.Module,
+    sample_rate: float,
+    requires_grad: bool = False,
+    peak_normalize: bool = False,
+    dropout: float = 0.0,
+):
+    """reference utils.py:444-508.  x: (bs, chs, seq_len) on any device -> {"mid","side"}: (bs, E)
+    L2-normalised, returned with x's device/dtype.
+
+    The per-item peak normalisation (utils.py:473-474) is fused into the STFT loader of the HIP
+    front-end instead of rewriting x; the NaN scrub and F.normalize run in stito_embed_loss."""
+    if x.dim() != 3:
+        raise ValueError("expected (bs, chs, seq_len)")
+    if requires_grad:
+        raise NotImplementedError("get_param_embeds(requires_grad=True) (the autodiff path) is not built here")
+    if sample_rate != 48000:
+        raise NotImplementedError("resampling to 48 kHz (torchaudio) is not part of this build; pass 48 kHz audio")
+    _hip.require_gpu()
+    from .models.panns import Cnn14
+
+    if not isinstance(model, Cnn14):
+        raise TypeError("get_param_embeds (MI355X build) needs the Cnn14 returned by load_param_model")
+    x_device = x
+    dev = next(model.parameters()).device
+    xin = x.detach().to(dev, torch.float32).contiguous()
+    bs, chs, n = xin.shape
+    L = _hip.lib()
+    st = _hip.stream_ptr()
+    peaks = torch.empty(bs, dtype=torch.float32, device=dev)
+    _hip.check(L.stito_peak(_hip.ptr(xin), bs, chs, n, _hip.ptr(peaks), st))
+    mid, side = model.embed_raw(xin, peaks, norm_passes=1)
+    if dropout > 0.0:
+        mid = torch.nn.functional.dropout(mid, p=dropout, training=True)
+        side = torch.nn.functional.dropout(side, p=dropout, training=True)
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), bs, mid.shape[1], None, None, None, _hip.ptr(flags), st))
+    fl = flags.cpu()
+    if fl[0]:
+        print("Warning: NaNs found in mid_embeddings")
+    elif fl[1]:
+        print("Warning: NaNs found in side_embeddings")
+    return {"mid": mid.type_as(x_device), "side": side.type_as(x_device)}
+
+
+def load_param_model(ckpt_path: str = None, use_gpu: bool = False):
+    """reference utils.py:511-551.  Reads config.yaml next to the checkpoint, builds the encoder
+    (class path `lcap.*`/`st_ito.*` -> this package), loads the `encoder.*` weights strictly.
+
+    There is no network here: the reference's wget of afx-rep.ckpt is not attempted.  The HIP
+    forward only exists on the GPU, so the model is moved to the current HIP device whenever one
+    is visible (use_gpu=False then only changes where get_param_embeds returns its result,
+    exactly like the reference: embeddings come back on the input's device)."""
+    if ckpt_path is None:
+        ckpt_path = os.path.join(os.getcwd(), "tmp", "afx-rep.ckpt")
+    if not os.path.isfile(ckpt_path):
+        raise FileNotFoundError(
+            f"{ckpt_path} not found.  Download afx-rep.ckpt and config.yaml from "
+            "https://huggingface.co/csteinmetz1/afx-rep into that directory (no network access here), "
+            "or use st_ito.utils.make_synthetic_param_model() for benchmarking.")
+    config_path = os.path.join(os.path.dirname(ckpt_path), "config.yaml")
+    with open(config_path) as f:
+        config = yaml.safe_load(f)
+    encoder_configs = config["model"]["init_args"]["encoder"]
+    module_path, class_name = encoder_configs["class_path"].rsplit(".", 1)
+    module_path = module_path.replace("lcap", "st_ito")
+    module = import_module(module_path)
+    model = getattr(module, class_name)(**encoder_configs["init_args"])
+    checkpoint = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    state_dict = {}
+    for k, v in checkpoint["state_dict"].items():
+        if k.startswith("encoder"):
+            state_dict[k.replace("encoder.", "", 1)] = v
+    model.load_state_dict(state_dict)
+    model.eval()
+    if use_gpu or torch.cuda.is_available():
+        model.cuda()
+    return model
+
+
+def make_synthetic_param_model(seed: int = 0, input_norm: str = "minmax", embed_dim: int = 512, fill=None):
+    """Random-init AFx-Rep stand-in with the published architecture (cfg/model/pretext/
+    param-panns-concat-l2.yaml:14-25) for benchmarks when the checkpoint is unavailable.
+    `fill(model, seed)` may overwrite the weights (tests pass the oracle's deterministic fill)."""
+    from .models.panns import Cnn14
+
+    torch.manual_seed(seed)
+    model = Cnn14(embed_dim, 48000, 2048, 1024, 128, 20, 20000, use_batchnorm=True, input_norm=input_norm)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                n = mod.num_features
+                mod.running_mean.copy_(0.1 * torch.randn(n, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(n, generator=g))
+                mod.weight.copy_(0.75 + 0.5 * torch.rand(n, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(n, generator=g))
+            elif isinstance(mod, torch.nn.Conv2d):
+                mod.weight.mul_(2.0 ** 0.5)  # keep activations O(1) through 12 ReLU layers
+    if fill is not None:
+        fill(model, seed)
+    model.eval()
+    if torch.cuda.is_available():
+        model.cuda()
+    return model

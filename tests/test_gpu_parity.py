@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP path (through the C ABI, via st_ito's ctypes binding) against the
+CPU oracle on the same seeded inputs and against the golden vectors generated from the
+reference.  Tolerances: bit-level for index/shape logic, float tolerances stated per test
+(north_star: embeddings and losses within 1e-4 relative fp32).
+
+Run with:  python -m pytest tests -m gpu
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import st_ito_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from st_ito import _hip
+    _hip.lib()  # must load: no silent fallback
+    return torch.device("cuda", 0)
+
+
+def _plugins_pair(kinds, with_bypass=False):
+    """Same chain as oracle plugins and as product plugins."""
+    from st_ito import effects as E
+    cls = {"ParametricEQ": (E.BasicParametricEQ, 1), "Compressor": (E.BasicCompressor, 1),
+           "Distortion": (E.BasicDistortion, 1), "Delay": (E.BasicDelay, 2), "Reverb": (E.BasicReverb, 2),
+           "Gain": (E.BasicGain, 1)}
+    spec, seen = [], {}
+    for k in kinds:
+        seen[k] = seen.get(k, 0) + 1
+        name = k if seen[k] == 1 else f"{k}{seen[k]}"
+        spec.append((name, cls[k][0], cls[k][1]))
+    return O.make_plugins(kinds, with_bypass), E.make_plugins(spec, with_bypass)
+
+
+def _render_gpu(pp, x, W, dev, normalize=True):
+    from st_ito import engine
+    audio, peaks = engine.render_population(pp, torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev), SR)
+    if normalize:
+        engine.normalize_audio_(audio, peaks)
+    return audio.cpu().numpy(), peaks.cpu().numpy()
+
+
+def _oracle_chain_raw(op, x, w):
+    """Oracle chain output WITHOUT the final peak normalisation."""
+    widx, y = 0, x
+    for name, plugin in op.items():
+        for pn in plugin["parameter_names"]:
+            if pn != "our_bypass":
+                plugin["instance"].parameters[pn].raw_value = w[widx]
+            widx += 1
+        if plugin["num_channels"] == 2 and y.shape[0] == 1:
+            y = np.concatenate((y, y), 0)
+        if plugin["num_channels"] == 1 and y.shape[0] == 2:
+            y = np.concatenate((plugin["instance"].process(y[0:1], SR), plugin["instance"].process(y[1:2], SR)), 0)
+        else:
+            y = plugin["instance"].process(y, SR)
+    return y
+
+
+SINGLE_FX = [
+    ("ParametricEQ", 1, 2e-6), ("ParametricEQ", 2, 2e-6), ("Compressor", 2, 2e-5), ("Distortion", 1, 2e-6),
+    ("Gain", 2, 1e-6), ("Delay", 1, 2e-6), ("Delay", 2, 2e-6), ("Reverb", 2, 2e-5), ("Reverb", 1, 2e-5),
+]
+
+
+@pytest.mark.parametrize("kind,chs,tol", SINGLE_FX)
+def test_single_effect_vs_oracle(dev, kind, chs, tol):
+    rng = np.random.default_rng(abs(hash((kind, chs))) % 1000)
+    n, P = 30011, 5
+    x = O.synth_audio(5, chs, n).numpy()
+    op, pp = _plugins_pair([kind])
+    D = sum(p["num_params"] for p in op.values())
+    W = rng.random((P, D))
+    W[0] = 0.0; W[1] = 1.0  # range extremes
+    got, _ = _render_gpu(pp, x, W, dev, normalize=False)
+    for p in range(P):
+        ref = _oracle_chain_raw(op, x, W[p])
+        assert got[p].shape == ref.shape
+        scale = max(1.0, np.abs(ref).max())
+        err = np.abs(got[p] - ref).max() / scale
+        print(f"{kind} {chs}ch cand {p}: max rel-to-peak err {err:.3e}")
+        assert err < tol, f"{kind} cand {p}: max err {err:.3e}"
+
+
+def test_eq_golden_reference_vectors(dev, golden_dir):
+    """HIP EQ against outputs of the reference's own parametric_eq (tests/golden/eq_parametric.npz)."""
+    from st_ito import effects as E
+    g = np.load(os.path.join(golden_dir, "eq_parametric.npz"))
+    inst = E.BasicParametricEQ()
+    names = list(inst.parameters.keys())
+    lo = np.array([inst.parameters[k].min_value for k in names])
+    hi = np.array([inst.parameters[k].max_value for k in names])
+    W = (g["params"] - lo) / (hi - lo)
+    pp = E.make_plugins("eq")
+    for sig, key in ((g["noise"], "y_noise"), (None, "y_impulse")):
+        if sig is None:
+            sig = np.zeros_like(g["noise"]); sig[0, 0] = 1.0
+        got, _ = _render_gpu(pp, sig, W, dev, normalize=False)
+        ref = g[key]
+        for p in range(len(W)):
+            scale = max(1.0, np.abs(ref[p]).max())
+            assert np.abs(got[p] - ref[p]).max() / scale < 2e-6
+
+
+def test_process_audio_golden(dev, golden_dir):
+    """process_audio channel rules, dead bypass dimension, fixed parameters, joint peak norm
+    against the reference's own process_audio (tests/golden/process_audio.npz)."""
+    from st_ito import effects as E
+    from st_ito.style_transfer import process_audio, parameters_to_dict
+    g = np.load(os.path.join(golden_dir, "process_audio.npz"))
+    for ci, (nplug, bypass, chs) in enumerate(g["cases"]):
+        spec = [("ParametricEQ" if i == 0 else f"ParametricEQ{i + 1}", E.BasicParametricEQ, 1) for i in range(int(nplug))]
+        pp = E.make_plugins(spec, bool(bypass))
+        y = process_audio(g[f"x{ci}"].copy(), g[f"w{ci}"], SR, pp)
+        np.testing.assert_allclose(y, g[f"y{ci}"], rtol=0, atol=3e-6)
+        d = parameters_to_dict(g[f"w{ci}"], pp)
+        flat = np.array([v for pn in d for v in d[pn].values()])
+        np.testing.assert_allclose(flat, g[f"d{ci}"], rtol=1e-15)
+    pp = E.make_plugins("eq")
+    pp["ParametricEQ"]["fixed_parameters"] = {"band1_gain_db": 12.0, "band1_cutoff_freq": 2500.0}
+    y = process_audio(g["xf"].copy(), g["wf"], SR, pp)
+    np.testing.assert_allclose(y, g["yf"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("chain,chs", [
+    (["ParametricEQ", "Compressor", "Reverb", "ParametricEQ", "Gain"], 2),
+    (["ParametricEQ", "Compressor", "Distortion", "Delay", "Reverb"], 1),
+    (["ParametricEQ", "Compressor"], 1),
+])
+def test_chain_vs_oracle(dev, chain, chs):
+    rng = np.random.default_rng(3)
+    n, P = 48000, 4
+    x = O.synth_audio(9, chs, n).numpy()
+    op, pp = _plugins_pair(chain, with_bypass=(chs == 1))
+    D = sum(p["num_params"] for p in op.values())
+    W = rng.random((P, D))
+    got, peaks = _render_gpu(pp, x, W, dev)
+    for p in range(P):
+        ref = O.process_audio(x.copy(), W[p], SR, op)
+        assert got[p].shape == ref.shape
+        err = np.abs(got[p] - ref).max()
+        print(f"chain {chs}ch cand {p}: max abs err {err:.3e}")
+        # five cascaded float32 effects: rounding noise of an early stage is amplified by later
+        # EQ boosts (up to +24 dB per band) in the oracle and in the HIP path alike
+        assert err < 3e-4, f"cand {p}: {err:.3e}"
+        assert abs(np.abs(got[p]).max() - 1.0) < 1e-6
+
+
+def _models(dev, norm="minmax", seed=0):
+    from st_ito.models.panns import Cnn14
+    om = O.make_synthetic_model(seed, input_norm=norm)
+    pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, norm)
+    pm.load_state_dict(om.state_dict())
+    pm.eval().to(dev)
+    return om, pm
+
+
+@pytest.mark.parametrize("norm", ["minmax", "batchnorm", "none"])
+def test_logmel_vs_oracle_and_golden(dev, golden_dir, norm):
+    g = np.load(os.path.join(golden_dir, f"cnn14_trunk_{norm}.npz"))
+    om, pm = _models(dev, norm)
+    x = torch.from_numpy(g["x"]).to(dev)
+    lm = pm.logmel(x).cpu().numpy().reshape(g["logmel"].shape)
+    # log-mel values live on a ~[-100, 40] dB scale (minmax: [-1, 1]); the oracle evaluates the
+    # DFT as a float32 matrix product, the HIP path as a float32 FFT: agreement to ~1e-4 dB
+    tol = 2e-5 if norm == "minmax" else 2e-3
+    assert np.abs(lm - g["logmel"]).max() < tol
+    xm = torch.from_numpy(g["x_mono"]).to(dev)
+    lmm = pm.logmel(xm).cpu().numpy()
+    with torch.no_grad():
+        ref = om.logmel(torch.from_numpy(g["x_mono"])).numpy().reshape(lmm.shape)
+    assert np.abs(lmm - ref).max() < tol
+
+
+CONV_CASES = [  # (n, H, W, cin, cout, pool)
+    (2, 33, 128, 1, 64, 0), (2, 33, 128, 64, 64, 1), (3, 16, 64, 64, 128, 0), (2, 17, 32, 128, 128, 1),
+    (2, 9, 16, 256, 256, 1), (3, 4, 8, 128, 256, 0), (5, 2, 4, 256, 128, 0), (3, 14, 4, 64, 128, 0), (1, 7, 4, 64, 64, 0),
+    (2, 29, 8, 64, 128, 1),
+]
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
+def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool):
+    from st_ito import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(H * 1000 + W + cin)
+    x = torch.randn((n, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)
+    scale = 0.5 + torch.rand(cout, generator=g)
+    shift = 0.2 * torch.randn(cout, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double()[None, :, None, None]
+                     + shift.double()[None, :, None, None])
+    if pool:
+        ref = torch.nn.functional.avg_pool2d(ref, 2)
+    ref = ref.permute(0, 2, 3, 1).contiguous()  # NHWC
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.contiguous().to(dev)
+    packed = torch.empty(cout * cin * 9, device=dev)
+    st = _hip.stream_ptr()
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, _hip.ptr(packed), st))
+    out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
+    sd, hd = scale.to(dev), shift.to(dev)
+    _hip.check(L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
+                                       n, H, W, cin, cout, pool, st))
+    got = out.cpu().double()
+    assert not torch.isnan(got).any(), "unwritten outputs"
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
+
+
+@pytest.mark.parametrize("norm", ["minmax", "batchnorm", "none"])
+def test_model_vs_golden_reference(dev, golden_dir, norm):
+    """Full Cnn14 forward + get_param_embeds against the reference's conv stack output."""
+    from st_ito.utils import get_param_embeds
+    g = np.load(os.path.join(golden_dir, f"cnn14_trunk_{norm}.npz"))
+    om, pm = _models(dev, norm)
+    x = torch.from_numpy(g["x"])
+    mid, side = pm(x.to(dev))
+    for got, key in ((mid, "mid"), (side, "side")):
+        ref = g[key]
+        rel = np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert rel < 1e-4, f"{key}: {rel:.3e}"
+    midm, sidem = pm(torch.from_numpy(g["x_mono"]).to(dev))
+    assert np.abs(midm.cpu().numpy() - g["mid_mono"]).max() / np.abs(g["mid_mono"]).max() < 1e-4
+    assert torch.equal(midm, sidem)
+    e = get_param_embeds(x.clone(), pm, SR)
+    assert e["mid"].device == x.device and e["mid"].dtype == x.dtype
+    for key in ("mid", "side"):
+        ref = g[f"embed_{key}"]
+        assert np.abs(e[key].numpy() - ref).max() / np.abs(ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["stereo", "mono"])
+def test_evaluate_losses_golden(dev, golden_dir, tag):
+    """run_es.evaluate end to end (pad to 262144, render, embed, cosine) against the losses the
+    reference's own run_es produced for the same population (tests/golden/evaluate_*.npz)."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds
+    from st_ito.style_transfer import process_audio
+    g = np.load(os.path.join(golden_dir, f"evaluate_{tag}.npz"))
+    _, pm = _models(dev, "minmax", int(g["seed"]))
+    pp = E.make_plugins("eq")
+    x = torch.from_numpy(g["x"].copy()); tgt = torch.from_numpy(g["target"].copy())
+    x /= x.abs().max().clamp(min=1e-8); tgt /= tgt.abs().max().clamp(min=1e-8)
+    te = get_param_embeds(tgt, pm, SR)
+    ev = PopulationEvaluator(x, SR, pp, pm, te)
+    loss, embeds, audio = ev.evaluate(list(g["W"]), want_audio=True)
+    fv = loss.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(fv, g["fvals"], rtol=1e-4, atol=2e-6)
+    assert audio.shape[-1] == 262144 and audio.shape[0] == len(g["W"])
+    assert int(np.argmin(fv)) == int(np.argmin(g["fvals"]))
+    out = process_audio(x.squeeze(0).numpy(), g["wopt"], SR, pp)
+    np.testing.assert_allclose(out, g["output_audio"], rtol=0, atol=3e-6)
+
+
+def test_full_chain_losses_vs_oracle(dev):
+    """BASELINE chain (EQ/comp/reverb/EQ/gain), stereo: per-candidate losses HIP vs oracle."""
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds
+    chain = ["ParametricEQ", "Compressor", "Reverb", "ParametricEQ", "Gain"]
+    op, pp = _plugins_pair(chain)
+    om, pm = _models(dev, "minmax")
+    rng = np.random.default_rng(8)
+    n, P = 300000, 4
+    x = O.synth_audio(41, 2, n)[None]
+    D = sum(p["num_params"] for p in op.values())
+    assert D == 45
+    wt = np.random.default_rng(7).random(D)
+    tgt = torch.from_numpy(O.process_audio(x[0].numpy().copy(), wt, SR, op))[None]
+    W = rng.random((P, D))
+    te_o = O.get_param_embeds(tgt.clone(), om, SR)
+    f_ref, e_ref, _ = O.evaluate(list(W), x, SR, op, te_o, om)
+    te = get_param_embeds(tgt.clone(), pm, SR)
+    for k in ("mid", "side"):
+        assert (te[k] - te_o[k]).abs().max() / te_o[k].abs().max() < 1e-4
+    ev = PopulationEvaluator(x, SR, pp, pm, te)
+    loss, embeds, _ = ev.evaluate(list(W))
+    np.testing.assert_allclose(loss.cpu().numpy(), np.array(f_ref), rtol=1e-4, atol=5e-6)
+    for k in ("mid", "side"):
+        rel = (embeds[k].cpu() - e_ref[k]).abs().max() / e_ref[k].abs().max()
+        assert rel < 1e-4, f"{k} embeddings: {rel:.3e}"
