@@ -23,6 +23,8 @@
 // M index -> pixel mapping: 4 consecutive GEMM rows = one 2x2 pooling window, which the MFMA
 // C layout leaves in 4 consecutive accumulator registers of one lane, so BN+ReLU+avg-pool
 // happen in registers.
+#include <string>
+
 #include "common.h"
 
 namespace stito {
@@ -39,7 +41,11 @@ struct ConvGeom {
     int Ho, Wo;
 };
 
-template <int WM, int WN, int TW, bool POOL>
+// MODE 0: one LDS buffer, two barriers per chunk, 2 workgroups per CU cover each other's staging.
+// MODE 1: two LDS buffers (128 KB, 1 workgroup per CU): the next chunk is written to the other
+//         buffer in the middle of the MFMA stream, one barrier per chunk.
+// MODE 2: timing ablation only (no staging after chunk 0; wrong results).
+template <int WM, int WN, int TW, bool POOL, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restrict__ in, const float *__restrict__ wpk,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, float *__restrict__ out,
@@ -55,6 +61,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sB = smem;                       // [9][BN][CPAD]
     float *sA = smem + 9 * BN * CPAD;       // [NSLOT*(HS+2)][PW][CPAD]
+    const int buf_floats = 9 * BN * CPAD + g.NSLOT * (g.HS + 2) * PW * CPAD;  // MODE 1: second buffer follows
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv % WM, wn = wv / WM;
@@ -135,37 +142,59 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
     };
 
     const int n_chunks = g.Cin / CK;
-    prefetch(0);
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        __syncthreads();  // previous chunk's fragment reads are done
+    auto stage_write = [&](int boff) {
 #pragma unroll
         for (int it = 0; it < A_ITEMS; ++it)
-            if (a_inrange[it]) *(float4 *)(sA + a_loff[it]) = a_reg[it];
+            if (a_inrange[it]) *(float4 *)(sA + boff + a_loff[it]) = a_reg[it];
 #pragma unroll
         for (int it = 0; it < B_ITEMS; ++it)
-            if (b_valid[it]) *(float4 *)(sB + b_loff[it]) = b_reg[it];
-        __syncthreads();
-        if (chunk + 1 < n_chunks) prefetch(chunk + 1);  // in flight during the MFMA block
+            if (b_valid[it]) *(float4 *)(sB + boff + b_loff[it]) = b_reg[it];
+    };
+    auto mfma_tap = [&](int boff, int tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        float4 av[2], bv[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) av[mb] = *(const float4 *)(sA + boff + a_frag[mb] + (kh * PW + kw) * CPAD);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bv[nb] = *(const float4 *)(sB + boff + b_frag[nb] + tap * BN * CPAD);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float a0 = kk == 0 ? av[0].x : kk == 1 ? av[0].y : kk == 2 ? av[0].z : av[0].w;
+            const float a1 = kk == 0 ? av[1].x : kk == 1 ? av[1].y : kk == 2 ? av[1].z : av[1].w;
+            const float b0 = kk == 0 ? bv[0].x : kk == 1 ? bv[0].y : kk == 2 ? bv[0].z : bv[0].w;
+            const float b1 = kk == 0 ? bv[1].x : kk == 1 ? bv[1].y : kk == 2 ? bv[1].z : bv[1].w;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
 
+    prefetch(0);
+    if (MODE == 1) {
+        stage_write(0);
+        __syncthreads();
+        if (n_chunks > 1) prefetch(1);
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const int cur = (chunk & 1) * buf_floats, nxt = buf_floats - cur;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap % 3;
-            float4 av[2], bv[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) av[mb] = *(const float4 *)(sA + a_frag[mb] + (kh * PW + kw) * CPAD);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) bv[nb] = *(const float4 *)(sB + b_frag[nb] + tap * BN * CPAD);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float a0 = kk == 0 ? av[0].x : kk == 1 ? av[0].y : kk == 2 ? av[0].z : av[0].w;
-                const float a1 = kk == 0 ? av[1].x : kk == 1 ? av[1].y : kk == 2 ? av[1].z : av[1].w;
-                const float b0 = kk == 0 ? bv[0].x : kk == 1 ? bv[0].y : kk == 2 ? bv[0].z : bv[0].w;
-                const float b1 = kk == 0 ? bv[1].x : kk == 1 ? bv[1].y : kk == 2 ? bv[1].z : bv[1].w;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int tap = 0; tap < 9; ++tap) {
+                mfma_tap(cur, tap);
+                if (tap == 4 && chunk + 1 < n_chunks) stage_write(nxt);  // chunk+1 -> the idle buffer
             }
+            __syncthreads();
+            if (chunk + 2 < n_chunks) prefetch(chunk + 2);
+        }
+    } else {
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            if (MODE == 0 || chunk == 0) {
+                __syncthreads();  // previous chunk's fragment reads are done
+                stage_write(0);
+                __syncthreads();
+                if (MODE == 0 && chunk + 1 < n_chunks) prefetch(chunk + 1);  // in flight during the MFMA block
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) mfma_tap(0, tap);
         }
     }
 
@@ -425,8 +454,10 @@ __global__ void k_transpose(const float *__restrict__ in, int rows, int cols, fl
 // ================================================================================================
 // host side
 // ================================================================================================
-template <int WM, int WN, int TW, bool POOL>
-static int launch_conv(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
+static int g_conv_mode = 0;
+
+template <int WM, int WN, int TW, bool POOL, int MODE>
+static int launch_conv_mode(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
                        ConvGeom g, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN, TH = BM / TW, PW = TW + 2;
     int hs = TH, nslot = 1;
@@ -442,13 +473,22 @@ static int launch_conv(const float *in, const float *wpk, const float *scale, co
     g.Ho = g.H / 2; g.Wo = g.W / 2;
     const int npix = nslot * (hs + 2) * PW;
     STITO_REQUIRE(npix * 2 <= ((WM == 4) ? 4 : 3) * 64 * WM * WN, STITO_E_UNSUPPORTED, "conv tile: halo patch of %d pixels exceeds the staging budget", npix);
-    const size_t lds = (size_t)(9 * BN * CPAD + npix * CPAD) * sizeof(float);
-    auto kern = k_conv3x3<WM, WN, TW, POOL>;
+    const size_t lds = (size_t)(9 * BN * CPAD + npix * CPAD) * sizeof(float) * (MODE == 1 ? 2 : 1);
+    STITO_REQUIRE(lds <= 160 * 1024, STITO_E_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
+    auto kern = k_conv3x3<WM, WN, TW, POOL, MODE>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (int64_t)g.n_m_tiles * (g.Cout / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WM * WN), lds, st, in, wpk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
+}
+
+template <int WM, int WN, int TW, bool POOL>
+static int launch_conv(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
+                       const ConvGeom &g, hipStream_t st) {
+    if (g_conv_mode == 1) return launch_conv_mode<WM, WN, TW, POOL, 1>(in, wpk, scale, shift, out, g, st);
+    if (g_conv_mode == 2) return launch_conv_mode<WM, WN, TW, POOL, 2>(in, wpk, scale, shift, out, g, st);
+    return launch_conv_mode<WM, WN, TW, POOL, 0>(in, wpk, scale, shift, out, g, st);
 }
 
 template <int WM, int WN, bool POOL>
@@ -475,6 +515,15 @@ static int conv_first(const float *in, const float *w, const float *scale, const
 }  // namespace stito
 
 using namespace stito;
+
+extern "C" int stito_set_option(const char *name, int value) {
+    if (name != nullptr && std::string(name) == "conv_mode") {
+        STITO_REQUIRE(value >= 0 && value <= 2, STITO_E_INVALID, "conv_mode must be 0, 1 or 2");
+        g_conv_mode = value;
+        return STITO_OK;
+    }
+    STITO_REQUIRE(false, STITO_E_INVALID, "unknown option %s", name ? name : "(null)");
+}
 
 extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin) { return (size_t)cout * cin * 9; }
 

@@ -288,63 +288,127 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
 // ------------------------------------------------------------------------------------------------
 // Compressor: juce::dsp::Compressor<float> (peak ballistics + VCA), effects.py:891-897
 // ------------------------------------------------------------------------------------------------
-static constexpr int CE_T = 64;  // samples per tile
+static constexpr int CE_T = 128;           // samples per tile
+static constexpr int CE_LD = CE_T + 4;     // LDS row stride (16-B aligned rows, conflict-free b128 column walks)
+static constexpr int CE_THREADS = 256;     // wave 0: recurrence; waves 1-3: global <-> LDS movers
+static constexpr int CE_MOVERS = CE_THREADS - 64;
 
-// envelope: env = v + cte*(env_prev - v), cte = v > env_prev ? attack : release.  One lane per
-// stream, one wave per workgroup; tiles are transposed through LDS so HBM sees 256-B rows.
-__global__ __launch_bounds__(64) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
-                                                  int C, int64_t L, int S, const double *__restrict__ coef) {
-    __shared__ float tile[64][CE_T + 1];
-    const int lane = threadIdx.x;
+// envelope: env = v + cte*(env_prev - v), cte = v > env_prev ? attack : release.
+// The recurrence is serial in time, so the time axis cannot be split; what can be done is to make
+// the serial wave do nothing but the recurrence.  One workgroup = 64 streams: lane l of wave 0
+// owns stream l and walks its row of an LDS tile (4 samples per ds_read_b128); waves 1-3 stream
+// tile k+1 in from HBM and tile k-1 out (coalesced float4 rows), double-buffered, one barrier
+// per 128 samples.
+template <bool VEC>
+__global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
+                                                          int C, int64_t L, int S, const double *__restrict__ coef) {
+    extern __shared__ __attribute__((aligned(16))) float ce_smem[];
+    float *xin = ce_smem;                      // [2][64][CE_LD]
+    float *eout = ce_smem + 2 * 64 * CE_LD;    // [2][64][CE_LD]
+    const float **row_in = (const float **)(ce_smem + 4 * 64 * CE_LD);  // [64]
+    float **row_out = (float **)(row_in + 64);                          // [64]
+
+    const int tid = threadIdx.x;
     const int s0 = blockIdx.x * 64;
-    const int s = s0 + lane;
-    const bool valid = s < S;
-    const int cand = valid ? s / C : 0, ch = valid ? s % C : 0;
-    const float *xp = in_ptr(in, cand, ch);
-    float *ep = env + (int64_t)cand * cand_stride + (int64_t)ch * L;
-    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
-    const float cat = (float)cf[3], crl = (float)cf[4];
     const int nrows = min(64, S - s0);
-    (void)xp; (void)ep;
-    // row r of the tile is stream s0 + r: wave-uniform, so these pointers live on the scalar unit
-    auto row_in = [&](int r) -> const float * {
-        const int sr_ = s0 + (r < nrows ? r : 0);
-        const int c_ = (C == 2) ? (sr_ >> 1) : (C == 1 ? sr_ : sr_ / C);
-        return in_ptr(in, c_, sr_ - c_ * C);
-    };
-    auto row_out = [&](int r) -> float * {
-        const int sr_ = s0 + (r < nrows ? r : 0);
-        const int c_ = (C == 2) ? (sr_ >> 1) : (C == 1 ? sr_ : sr_ / C);
-        return env + (int64_t)c_ * cand_stride + (int64_t)(sr_ - c_ * C) * L;
-    };
-    float yold = 0.0f;
-    float pre[64];
-    // prefetch tile 0
-#pragma unroll
-    for (int r = 0; r < 64; ++r) pre[r] = (r < nrows && lane < L) ? row_in(r)[lane] : 0.0f;
-    for (int64_t t0 = 0; t0 < L; t0 += CE_T) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 64; ++r) tile[r][lane] = pre[r];
-        __syncthreads();
-        const int64_t t1 = t0 + CE_T;
-        if (t1 < L) {
-#pragma unroll
-            for (int r = 0; r < 64; ++r) pre[r] = (r < nrows && t1 + lane < L) ? row_in(r)[t1 + lane] : 0.0f;
-        }
-#pragma unroll 16
-        for (int j = 0; j < CE_T; ++j) {
-            const float v = fabsf(tile[lane][j]);
-            const float d = yold - v;
-            const float ya = fmaf(cat, d, v), yr = fmaf(crl, d, v);
-            yold = (d < 0.0f) ? ya : yr;  // v > yold  <=>  d < 0
-            tile[lane][j] = yold;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 64; ++r)
-            if (r < nrows && t0 + lane < L) row_out(r)[t0 + lane] = tile[r][lane];
+    float cat = 0.f, crl = 0.f;
+    if (tid < 64) {
+        const int s = s0 + (tid < nrows ? tid : 0);
+        const int cand = s / C, ch = s % C;
+        row_in[tid] = in_ptr(in, cand, ch);
+        row_out[tid] = env + (int64_t)cand * cand_stride + (int64_t)ch * L;
+        const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+        cat = (float)cf[3];
+        crl = (float)cf[4];
     }
+    __syncthreads();
+    const int64_t ntiles = (L + CE_T - 1) / CE_T;
+    const int m = tid - 64;  // mover index
+
+    // every mover thread serves the same (row, float4 column) items in every tile: keep their
+    // global pointers in registers so that a tile's loads are all in flight at once
+    constexpr int NIT = (64 * (CE_T / 4) + CE_MOVERS - 1) / CE_MOVERS;
+    const float *gsrc[NIT];
+    float *gdst[NIT];
+    int loff[NIT], qcol[NIT];
+    bool ok[NIT];
+    if (VEC && tid >= 64) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = m + u * CE_MOVERS;
+            const int r = (i / (CE_T / 4)) & 63, q = i % (CE_T / 4);
+            ok[u] = i < 64 * (CE_T / 4) && r < nrows;
+            gsrc[u] = row_in[r] + 4 * q;
+            gdst[u] = row_out[r] + 4 * q;
+            loff[u] = r * CE_LD + 4 * q;
+            qcol[u] = 4 * q;
+        }
+    }
+    auto load_tile = [&](int64_t k) {
+        float *dst = xin + (k & 1) * 64 * CE_LD;
+        const int64_t t0 = k * CE_T;
+        if (VEC) {
+            float4 v[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u)
+                v[u] = (ok[u] && t0 + qcol[u] + 3 < L) ? *(const float4 *)(gsrc[u] + t0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < NIT; ++u)
+                if (m + u * CE_MOVERS < 64 * (CE_T / 4)) *(float4 *)(dst + loff[u]) = v[u];
+        } else {
+            for (int i = m; i < 64 * CE_T; i += CE_MOVERS) {
+                const int r = i / CE_T, j = i % CE_T;
+                dst[r * CE_LD + j] = (r < nrows && t0 + j < L) ? row_in[r][t0 + j] : 0.0f;
+            }
+        }
+    };
+    auto store_tile = [&](int64_t k) {
+        const float *src = eout + (k & 1) * 64 * CE_LD;
+        const int64_t t0 = k * CE_T;
+        if (VEC) {
+            float4 v[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) v[u] = *(const float4 *)(src + (ok[u] ? loff[u] : 0));
+#pragma unroll
+            for (int u = 0; u < NIT; ++u)
+                if (ok[u] && t0 + qcol[u] + 3 < L) *(float4 *)(gdst[u] + t0) = v[u];
+        } else {
+            for (int i = m; i < 64 * CE_T; i += CE_MOVERS) {
+                const int r = i / CE_T, j = i % CE_T;
+                if (r < nrows && t0 + j < L) row_out[r][t0 + j] = src[r * CE_LD + j];
+            }
+        }
+    };
+
+    if (tid >= 64) load_tile(0);
+    __syncthreads();
+    float yold = 0.0f;
+    for (int64_t k = 0; k < ntiles; ++k) {
+        if (tid >= 64) {
+            if (k + 1 < ntiles) load_tile(k + 1);
+            if (k > 0) store_tile(k - 1);
+        } else {
+            __builtin_amdgcn_s_setprio(3);
+            const float *xr = xin + (k & 1) * 64 * CE_LD + tid * CE_LD;
+            float *er = eout + (k & 1) * 64 * CE_LD + tid * CE_LD;
+#pragma unroll 4
+            for (int j = 0; j < CE_T; j += 4) {
+                const float4 x4 = *(const float4 *)(xr + j);
+                float xs[4] = {x4.x, x4.y, x4.z, x4.w}, es[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = fabsf(xs[u]), d = yold - v;
+                    const float ya = fmaf(cat, d, v), yr = fmaf(crl, d, v);
+                    yold = (d < 0.0f) ? ya : yr;  // v > yold  <=>  d < 0
+                    es[u] = yold;
+                }
+                *(float4 *)(er + j) = make_float4(es[0], es[1], es[2], es[3]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+    }
+    if (tid >= 64) store_tile(ntiles - 1);
 }
 
 // VCA: gain = env < thr ? 1 : pow(env/thr, 1/ratio - 1); y = gain * x.
@@ -736,8 +800,15 @@ extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, con
                 hipLaunchKernelGGL(k_eq, dim3(S), dim3(EQ_NC), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
                 break;
             case STITO_FX_COMPRESSOR:
-                hipLaunchKernelGGL(k_comp_env, dim3((S + 63) / 64), dim3(64), 0, st, in, envbuf, cand_stride, Cn, L, S, cf);
+            {
+                const size_t lds = (size_t)4 * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *);
+                // float4 rows need 16-B aligned stream starts: every stream offset is a multiple of L
+                const bool vec = (L % 4 == 0) && (((uintptr_t)in.base & 15) == 0) && (((uintptr_t)envbuf & 15) == 0);
+                auto kern = vec ? k_comp_env<true> : k_comp_env<false>;
+                STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((S + 63) / 64), dim3(CE_THREADS), lds, st, in, envbuf, cand_stride, Cn, L, S, cf);
                 STITO_LAUNCH_CHECK();
+            }
                 hipLaunchKernelGGL(k_comp_gain, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
                 break;
             case STITO_FX_DISTORTION:

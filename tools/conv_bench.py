@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Per-layer timing of the Cnn14 conv stack for the available conv kernel variants.
+    python tools/conv_bench.py [--streams 128] [--modes 0,1,2] [--frames 469]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "st-ito_amd"))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from bench import conv_layer_table
+from st_ito import _hip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=128)
+    ap.add_argument("--frames", type=int, default=469)
+    ap.add_argument("--modes", default="0,1")
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    L = _hip.lib()
+    dev = torch.device("cuda", 0)
+    st = _hip.stream_ptr()
+    rows = [r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 0]
+    modes = [int(m) for m in a.modes.split(",")]
+    res = {m: [] for m in modes}
+    ref_out = {}
+    for li, r in enumerate(rows):
+        g = torch.Generator(device="cpu").manual_seed(li)
+        x = torch.randn((a.streams, r["H"], r["W"], r["cin"]), generator=g).to(dev)
+        w = (torch.randn((r["cout"], r["cin"], 3, 3), generator=g) / np.sqrt(9 * r["cin"])).to(dev)
+        packed = torch.empty(w.numel(), device=dev)
+        _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), r["cout"], r["cin"], _hip.ptr(packed), st))
+        sc = (0.5 + torch.rand(r["cout"], generator=g)).to(dev)
+        sh = (0.1 * torch.randn(r["cout"], generator=g)).to(dev)
+        Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
+        for m in modes:
+            _hip.check(L.stito_set_option(b"conv_mode", m))
+            out = torch.empty((a.streams, Ho, Wo, r["cout"]), device=dev)
+            args = (_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), a.streams, r["H"], r["W"],
+                    r["cin"], r["cout"], r["pool"], st)
+            _hip.check(L.stito_conv3x3_bn_relu(*args))
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+            for s, e in ev:
+                s.record(); _hip.check(L.stito_conv3x3_bn_relu(*args)); e.record()
+            torch.cuda.synchronize()
+            ms = float(np.median([s.elapsed_time(e) for s, e in ev]))
+            res[m].append((ms, r["flops"] * a.streams / ms / 1e9))
+            if m == modes[0]:
+                ref_out[li] = out.clone()
+            elif m != 2:
+                assert torch.equal(out, ref_out[li]), f"layer {li}: mode {m} differs from mode {modes[0]}"
+    print(f"{'layer':28s}" + "".join(f"  mode{m}: ms   TF/s" for m in modes))
+    for li, r in enumerate(rows):
+        name = f"{r['H']}x{r['W']} {r['cin']}->{r['cout']}{' pool' if r['pool'] else ''}"
+        print(f"{name:28s}" + "".join(f"  {res[m][li][0]:9.3f} {res[m][li][1]:6.1f}" for m in modes))
+    tot_fl = sum(r["flops"] for r in rows) * a.streams
+    for m in modes:
+        t = sum(x[0] for x in res[m])
+        print(f"mode {m}: total {t:.2f} ms  {tot_fl / t / 1e9:.1f} TFLOP/s  ({tot_fl / t / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
+    _hip.check(L.stito_set_option(b"conv_mode", 0))
+
+
+if __name__ == "__main__":
+    main()
