@@ -68,8 +68,6 @@ typedef struct {
 
 const char *stito_last_error(void);
 int stito_version(void);
-/* Tuning knobs ("conv_mode": 0 single LDS buffer / 2 workgroups per CU, 1 double buffer). */
-int stito_set_option(const char *name, int value);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
 int stito_fx_num_params(int kind);

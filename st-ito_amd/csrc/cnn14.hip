@@ -11,117 +11,146 @@
 //
 // Layout: activations NHWC (stream, time, mel, channel) so that one pixel's channels are
 // contiguous (im2col K-runs are contiguous, the epilogue stores 128 B per pixel per half-wave).
-// Weights are pre-packed as [cin/8][tap][cout][8].
+// Weights are pre-packed as [cin/4][tap][cout][4].
 //
 // Tiling: a workgroup computes BM = 64*WM output pixels x BN = 64*WN output channels; each of its
 // WM*WN waves owns a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks (64 accumulator VGPRs).  The BM
-// pixels are a TH x TW spatial patch of one stream (or of several streams when the feature map
-// is smaller than the patch).  Per 8-input-channel chunk the (TH+2) x (TW+2) x 8 halo patch and
-// the 9 x BN x 8 weight slab go to LDS once and are reused by all 9 taps: 9*4 = 36 k-steps of
-// 4 MFMAs per wave (9216 MFMA cycles) between barriers; the next chunk's global loads are
-// issued before the MFMA block and land in registers meanwhile.
+// pixels are TH rows x TW columns; rows are counted in "virtual row" space (the output rows of all
+// streams concatenated) so every tile is full even when a feature map has 14 or 29 rows.
 // M index -> pixel mapping: 4 consecutive GEMM rows = one 2x2 pooling window, which the MFMA
 // C layout leaves in 4 consecutive accumulator registers of one lane, so BN+ReLU+avg-pool
-// happen in registers.
-#include <string>
-
+// happen in registers.  Details of the data movement are at k_conv3x3.
 #include "common.h"
 
 namespace stito {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int CK = 8;      // input channels per chunk
-static constexpr int CPAD = 12;   // floats per LDS pixel / weight row (8 + 4 pad: conflict-free b128 reads)
+static constexpr int CK = 4;      // input channels per chunk (16 B per pixel / per weight row)
 
+struct ConvShape {
+    int S, H, W, Cin, Cout;
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_conv3x3: 3x3 conv (pad 1) + per-channel scale/shift + ReLU (+ 2x2 average pool).
+//   * rows are tiled in "virtual row" space (all streams' output rows concatenated), so tiles
+//     are always full (no padding of 14-, 29-, 58-row maps to 16/32/64); a tile may straddle
+//     streams, and the zero padding above/below a stream is applied per lane when the A fragment
+//     is read (kh = 0 / 2 taps only).
+//   * 4 input channels per chunk; the halo patch and the 9 x BN x 4 weight slab are copied
+//     HBM/L2 -> LDS by global_load_lds (16 B per lane, no VGPR round trip, no ds_write), double
+//     buffered: the copies for chunk c+1 are issued right after the single barrier of chunk c and
+//     land while its 72 MFMAs per wave run.  ~45 KB LDS per workgroup -> 3 workgroups per CU.
+// Weights: [cin/4][tap][cout][4].
+// ------------------------------------------------------------------------------------------------
 struct ConvGeom {
     int S, H, W, Cin, Cout;
-    int HS, NSLOT;            // rows per stream slot, stream slots per tile
-    int n_row_tiles, n_col_tiles, n_m_tiles;
+    int Heff;        // output rows per stream (POOL: 2*(H/2), else H)
+    int64_t VR;      // S * Heff
+    int64_t IVR;     // S * H input virtual rows
+    int n_col_tiles, n_m_tiles;
+    int PR, na_i;    // patch rows, A wave-instructions per chunk
     int Ho, Wo;
 };
 
-// MODE 0: one LDS buffer, two barriers per chunk, 2 workgroups per CU cover each other's staging.
-// MODE 1: two LDS buffers (128 KB, 1 workgroup per CU): the next chunk is written to the other
-//         buffer in the middle of the MFMA stream, one barrier per chunk.
-// MODE 2: timing ablation only (no staging after chunk 0; wrong results).
-template <int WM, int WN, int TW, bool POOL, int MODE>
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int WM, int WN, int TW, bool POOL>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restrict__ in, const float *__restrict__ wpk,
-                                                          const float *__restrict__ scale,
-                                                          const float *__restrict__ shift, float *__restrict__ out,
-                                                          ConvGeom g) {
-    constexpr int NT = 64 * WM * WN;
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, float *__restrict__ out,
+                                                             ConvGeom g) {
+    constexpr int NW = WM * WN;
+    constexpr int NT = 64 * NW;
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int TH = BM / TW;
     constexpr int GW = TW / 2;
     constexpr int PW = TW + 2;
-    constexpr int B_ITEMS = (9 * BN * 2 + NT - 1) / NT;
-    constexpr int A_ITEMS = (WM == 4) ? 4 : 3;
+    constexpr int CK4 = CK;
+    constexpr int NB_I = 9 * BN * CK4 / 256;   // weight-slab wave-instructions per chunk (1 KB each)
+    constexpr int MAX_A_I = 8;
+    constexpr int MAXI = (NB_I + MAX_A_I + NW - 1) / NW;
+    constexpr int B_FLOATS = 9 * BN * CK4;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sB = smem;                       // [9][BN][CPAD]
-    float *sA = smem + 9 * BN * CPAD;       // [NSLOT*(HS+2)][PW][CPAD]
-    const int buf_floats = 9 * BN * CPAD + g.NSLOT * (g.HS + 2) * PW * CPAD;  // MODE 1: second buffer follows
+    const int buf_floats = B_FLOATS + g.na_i * 256;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv % WM, wn = wv / WM;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // block -> (n tile, m tile); m fastest so that co-running blocks share one weight slab in L2
     const int m_tile = blockIdx.x % g.n_m_tiles;
     const int n_tile = blockIdx.x / g.n_m_tiles;
     const int n0 = n_tile * BN;
     const int ct = m_tile % g.n_col_tiles;
-    const int rt = (m_tile / g.n_col_tiles) % g.n_row_tiles;
-    const int sg = m_tile / (g.n_col_tiles * g.n_row_tiles);
-    const int s_base = sg * g.NSLOT;
-    const int h0 = rt * TH, w0 = ct * TW;
-    const int HSP = g.HS + 2;
-    const int npix = g.NSLOT * HSP * PW;
+    const int64_t rt = m_tile / g.n_col_tiles;
+    const int64_t vr0 = rt * TH;
+    const int w0 = ct * TW;
+    const int64_t iv_lo = (vr0 / g.Heff) * g.H + (vr0 % g.Heff) - 1;
+    const int npix = g.PR * PW;
 
-    // ---- per-thread staging descriptors (invariant over the K loop) ---------------------------
-    int64_t a_goff[A_ITEMS];
-    int a_loff[A_ITEMS];
-    bool a_valid[A_ITEMS], a_inrange[A_ITEMS];
-#pragma unroll
-    for (int it = 0; it < A_ITEMS; ++it) {
-        const int q = tid + it * NT;
-        const int pix = q >> 1, hf = q & 1;
-        a_inrange[it] = pix < npix;
-        const int pcol = pix % PW;
-        const int prow_all = pix / PW;
-        const int slot = prow_all / HSP, prow = prow_all % HSP;
-        const int s = s_base + slot, h = h0 + prow - 1, w = w0 + pcol - 1;
-        a_valid[it] = a_inrange[it] && s < g.S && h >= 0 && h < g.H && w >= 0 && w < g.W;
-        a_goff[it] = (((int64_t)s * g.H + h) * g.W + w) * g.Cin + hf * 4;
-        a_loff[it] = pix * CPAD + hf * 4;
+    // ---- zero both A regions once: padding / out-of-range pixels are never overwritten ---------
+    for (int i = tid; i < g.na_i * 256; i += NT) {
+        smem[B_FLOATS + i] = 0.0f;
+        smem[buf_floats + B_FLOATS + i] = 0.0f;
     }
-    int64_t b_goff[B_ITEMS];
-    int b_loff[B_ITEMS];
-    bool b_valid[B_ITEMS];
-#pragma unroll
-    for (int it = 0; it < B_ITEMS; ++it) {
-        const int q = tid + it * NT;
-        b_valid[it] = q < 9 * BN * 2;
-        const int tap = q / (2 * BN), r = q % (2 * BN);
-        const int co = r >> 1, hf = r & 1;
-        b_goff[it] = ((int64_t)tap * g.Cout + n0 + co) * CK + hf * 4;
-        b_loff[it] = (tap * BN + co) * CPAD + hf * 4;
-    }
-    const int64_t b_chunk_stride = (int64_t)9 * g.Cout * CK;
 
-    // ---- per-lane fragment addresses ----------------------------------------------------------
+    // ---- per-thread copy descriptors ----------------------------------------------------------------
+    const float *gsrc[MAXI];
+    int ldso[MAXI], gstep[MAXI];
+    bool gval[MAXI];
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int ii = wv + k * NW;  // wave-uniform
+        if (ii < NB_I) {
+            const int q = ii * 64 + lane;
+            const int tap = q / BN, co = q % BN;
+            gsrc[k] = wpk + ((int64_t)tap * g.Cout + n0 + co) * CK4;
+            gstep[k] = 9 * g.Cout * CK4;
+            ldso[k] = ii * 256;
+            gval[k] = true;
+        } else {
+            const int a = ii - NB_I;
+            const int pix = a * 64 + lane;
+            const int p = pix / PW, pcol = pix % PW;
+            const int64_t iv = iv_lo + p;
+            const int w = w0 + pcol - 1;
+            gval[k] = a < g.na_i && pix < npix && iv >= 0 && iv < g.IVR && w >= 0 && w < g.W;
+            gsrc[k] = in + (gval[k] ? (iv * g.W + w) * (int64_t)g.Cin : 0);
+            gstep[k] = CK4;
+            ldso[k] = B_FLOATS + (a < g.na_i ? a : 0) * 256;
+        }
+    }
+    auto issue = [&](int chunk, int boff) {
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            if (gval[k])
+                __builtin_amdgcn_global_load_lds((glb_void *)(gsrc[k] + (int64_t)chunk * gstep[k]),
+                                                 (lds_void *)(smem + boff + ldso[k]), 16, 0, 0);
+        }
+    };
+
+    // ---- per-lane fragment addresses and row masks ---------------------------------------------------
     int a_frag[2], b_frag[2];
+    bool m_up[2], m_dn[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int gi = (wm * 2 + mb) * 8 + (l31 >> 2);
         const int gr = gi / GW, gc = gi % GW;
-        const int ph = 2 * gr + ((l31 >> 1) & 1), pw_ = 2 * gc + (l31 & 1);
-        const int slot = ph / g.HS, prow = ph % g.HS;
-        a_frag[mb] = ((slot * HSP + prow) * PW + pw_) * CPAD + half * 4;
+        int64_t vr = vr0 + 2 * gr + ((l31 >> 1) & 1);
+        vr = vr < g.VR ? vr : g.VR - 1;  // overhang lanes: any in-range row (result discarded)
+        const int64_t s = vr / g.Heff;
+        const int h = (int)(vr % g.Heff);
+        const int pc = (int)(s * g.H + h - iv_lo);  // patch row of the centre tap (>= 1)
+        const int pw_ = 2 * gc + (l31 & 1);
+        a_frag[mb] = B_FLOATS + ((pc - 1) * PW + pw_) * CK4 + half * 2;
+        m_up[mb] = h >= 1;
+        m_dn[mb] = h + 1 < g.H;
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) b_frag[nb] = (wn * 64 + nb * 32 + l31) * CPAD + half * 4;
+    for (int nb = 0; nb < 2; ++nb) b_frag[nb] = (wn * 64 + nb * 32 + l31) * CK4 + half * 2;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -131,101 +160,77 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
-    float4 a_reg[A_ITEMS], b_reg[B_ITEMS];
-    auto prefetch = [&](int chunk) {
+    const int n_chunks = g.Cin / CK4;
+    __syncthreads();  // zero fill visible before any copy can land next to it
+    issue(0, 0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int cur = (chunk & 1) * buf_floats;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies for `chunk` have landed
+        __syncthreads();                                   // ... everyone's; and chunk-1's reads are done
+        if (chunk + 1 < n_chunks) issue(chunk + 1, buf_floats - cur);
+        const float *sb = smem + cur;
 #pragma unroll
-        for (int it = 0; it < A_ITEMS; ++it)
-            a_reg[it] = a_valid[it] ? *(const float4 *)(in + a_goff[it] + chunk * CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            float2 av[2], bv[2];
 #pragma unroll
-        for (int it = 0; it < B_ITEMS; ++it)
-            b_reg[it] = b_valid[it] ? *(const float4 *)(wpk + b_goff[it] + chunk * b_chunk_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-
-    const int n_chunks = g.Cin / CK;
-    auto stage_write = [&](int boff) {
-#pragma unroll
-        for (int it = 0; it < A_ITEMS; ++it)
-            if (a_inrange[it]) *(float4 *)(sA + boff + a_loff[it]) = a_reg[it];
-#pragma unroll
-        for (int it = 0; it < B_ITEMS; ++it)
-            if (b_valid[it]) *(float4 *)(sB + boff + b_loff[it]) = b_reg[it];
-    };
-    auto mfma_tap = [&](int boff, int tap) {
-        const int kh = tap / 3, kw = tap % 3;
-        float4 av[2], bv[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) av[mb] = *(const float4 *)(sA + boff + a_frag[mb] + (kh * PW + kw) * CPAD);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bv[nb] = *(const float4 *)(sB + boff + b_frag[nb] + tap * BN * CPAD);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float a0 = kk == 0 ? av[0].x : kk == 1 ? av[0].y : kk == 2 ? av[0].z : av[0].w;
-            const float a1 = kk == 0 ? av[1].x : kk == 1 ? av[1].y : kk == 2 ? av[1].z : av[1].w;
-            const float b0 = kk == 0 ? bv[0].x : kk == 1 ? bv[0].y : kk == 2 ? bv[0].z : bv[0].w;
-            const float b1 = kk == 0 ? bv[1].x : kk == 1 ? bv[1].y : kk == 2 ? bv[1].z : bv[1].w;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    };
-
-    prefetch(0);
-    if (MODE == 1) {
-        stage_write(0);
-        __syncthreads();
-        if (n_chunks > 1) prefetch(1);
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            const int cur = (chunk & 1) * buf_floats, nxt = buf_floats - cur;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                mfma_tap(cur, tap);
-                if (tap == 4 && chunk + 1 < n_chunks) stage_write(nxt);  // chunk+1 -> the idle buffer
-            }
-            __syncthreads();
-            if (chunk + 2 < n_chunks) prefetch(chunk + 2);
-        }
-    } else {
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            if (MODE == 0 || chunk == 0) {
-                __syncthreads();  // previous chunk's fragment reads are done
-                stage_write(0);
-                __syncthreads();
-                if (MODE == 0 && chunk + 1 < n_chunks) prefetch(chunk + 1);  // in flight during the MFMA block
+            for (int mb = 0; mb < 2; ++mb) {
+                av[mb] = *(const float2 *)(sb + a_frag[mb] + (kh * PW + kw) * CK4);
+                if (kh == 0 && !m_up[mb]) av[mb] = make_float2(0.f, 0.f);
+                if (kh == 2 && !m_dn[mb]) av[mb] = make_float2(0.f, 0.f);
             }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) mfma_tap(0, tap);
+            for (int nb = 0; nb < 2; ++nb) bv[nb] = *(const float2 *)(sb + b_frag[nb] + tap * BN * CK4);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].x, bv[0].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].x, bv[1].x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].x, bv[0].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].x, bv[1].x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].y, bv[0].y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].y, bv[1].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].y, bv[0].y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].y, bv[1].y, acc[1][1], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: BN (scale/shift) + ReLU (+ 2x2 average pool), NHWC store ----------------------
+    // ---- epilogue: BN + ReLU (+ 2x2 average pool), NHWC store ------------------------------------------
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int co = n0 + wn * 64 + nb * 32 + l31;
-        const float sc = scale[co], sh = shift[co];
+    for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int q = 0; q < 4; ++q) {
+            const int gi = (wm * 2 + mb) * 8 + 2 * q + half;
+            const int gr = gi / GW, gc = gi % GW;
+            const int64_t vr = vr0 + 2 * gr;
+            int64_t obase[2];
+            bool ok[2];
+            if (POOL) {
+                const int64_t s = vr / g.Heff;
+                const int oh = (int)(vr % g.Heff) >> 1, ow = (w0 >> 1) + gc;
+                ok[0] = vr < g.VR && ow < g.Wo;
+                obase[0] = ((s * g.Ho + oh) * g.Wo + ow) * g.Cout;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // accumulator rows 8q + 4*half + {0,1,2,3} = pooling window (group) 2q + half of this block
-                const int gi = (wm * 2 + mb) * 8 + 2 * q + half;
-                const int gr = gi / GW, gc = gi % GW;
-                const int slot = (2 * gr) / g.HS, prow = (2 * gr) % g.HS;
-                const int s = s_base + slot;
-                const int h = h0 + prow, w = w0 + 2 * gc;
+                for (int e = 0; e < 2; ++e) {  // the two rows of the 2x2 register group
+                    const int64_t v = vr + e;
+                    const int64_t s = v / g.H;
+                    const int h = (int)(v % g.H);
+                    ok[e] = v < g.VR;
+                    obase[e] = ((s * g.H + h) * g.W + (w0 + 2 * gc)) * g.Cout;
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int co = n0 + wn * 64 + nb * 32 + l31;
+                const float sc = scale[co], sh = shift[co];
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(acc[mb][nb][4 * q + e], sc, sh), 0.0f);
                 if (POOL) {
-                    const int oh = h >> 1, ow = w >> 1;
-                    if (s < g.S && oh < g.Ho && ow < g.Wo)
-                        out[(((int64_t)s * g.Ho + oh) * g.Wo + ow) * g.Cout + co] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
+                    if (ok[0]) out[obase[0] + co] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int hh = h + (e >> 1), ww = w + (e & 1);
-                        if (s < g.S && hh < g.H && ww < g.W)
-                            out[(((int64_t)s * g.H + hh) * g.W + ww) * g.Cout + co] = y[e];
+                        const int ww = w0 + 2 * gc + (e & 1);
+                        if (ok[e >> 1] && ww < g.W) out[obase[e >> 1] + (int64_t)(e & 1) * g.Cout + co] = y[e];
                     }
                 }
             }
@@ -410,20 +415,20 @@ __global__ __launch_bounds__(256) void k_embed_loss(float *__restrict__ mid, flo
 // ------------------------------------------------------------------------------------------------
 // weight preparation
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ o) {
+__global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int ck, float *__restrict__ o) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)Cout * Cin * 9;
     if (i >= n) return;
-    if (Cin % CK != 0) {  // first layer: [cout][9]
+    if (Cin % ck != 0) {  // first layer: [cout][9]
         o[i] = w[i];
         return;
     }
-    // destination index i -> (chunk, tap, co, c8)
-    const int c8 = (int)(i % CK);
-    const int co = (int)((i / CK) % Cout);
-    const int tap = (int)((i / ((int64_t)CK * Cout)) % 9);
-    const int chunk = (int)(i / ((int64_t)CK * Cout * 9));
-    const int ci = chunk * CK + c8;
+    // destination index i -> (chunk, tap, co, c)
+    const int c = (int)(i % ck);
+    const int co = (int)((i / ck) % Cout);
+    const int tap = (int)((i / ((int64_t)ck * Cout)) % 9);
+    const int chunk = (int)(i / ((int64_t)ck * Cout * 9));
+    const int ci = chunk * ck + c;
     o[i] = w[((int64_t)co * Cin + ci) * 9 + tap];
 }
 
@@ -454,46 +459,36 @@ __global__ void k_transpose(const float *__restrict__ in, int rows, int cols, fl
 // ================================================================================================
 // host side
 // ================================================================================================
-static int g_conv_mode = 0;
-
-template <int WM, int WN, int TW, bool POOL, int MODE>
-static int launch_conv_mode(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
-                       ConvGeom g, hipStream_t st) {
+template <int WM, int WN, int TW, bool POOL>
+static int launch_conv(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
+                          const ConvShape &g0, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN, TH = BM / TW, PW = TW + 2;
-    int hs = TH, nslot = 1;
-    if (g.H < TH) {
-        hs = 2;
-        while (hs < g.H) hs <<= 1;
-        nslot = TH / hs;
-    }
-    g.HS = hs; g.NSLOT = nslot;
-    g.n_row_tiles = nslot > 1 ? 1 : (g.H + TH - 1) / TH;
-    g.n_col_tiles = (g.W + TW - 1) / TW;
-    g.n_m_tiles = ((g.S + nslot - 1) / nslot) * g.n_row_tiles * g.n_col_tiles;
+    ConvGeom g{};
+    g.S = g0.S; g.H = g0.H; g.W = g0.W; g.Cin = g0.Cin; g.Cout = g0.Cout;
     g.Ho = g.H / 2; g.Wo = g.W / 2;
-    const int npix = nslot * (hs + 2) * PW;
-    STITO_REQUIRE(npix * 2 <= ((WM == 4) ? 4 : 3) * 64 * WM * WN, STITO_E_UNSUPPORTED, "conv tile: halo patch of %d pixels exceeds the staging budget", npix);
-    const size_t lds = (size_t)(9 * BN * CPAD + npix * CPAD) * sizeof(float) * (MODE == 1 ? 2 : 1);
-    STITO_REQUIRE(lds <= 160 * 1024, STITO_E_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    auto kern = k_conv3x3<WM, WN, TW, POOL, MODE>;
+    g.Heff = POOL ? 2 * g.Ho : g.H;
+    g.VR = (int64_t)g.S * g.Heff;
+    g.IVR = (int64_t)g.S * g.H;
+    g.n_col_tiles = (g.W + TW - 1) / TW;
+    const int64_t n_row_tiles = (g.VR + TH - 1) / TH;
+    STITO_REQUIRE(n_row_tiles * g.n_col_tiles < (1 << 30), STITO_E_UNSUPPORTED, "conv: too many tiles");
+    g.n_m_tiles = (int)(n_row_tiles * g.n_col_tiles);
+    g.PR = TH + 2 + ((TH - 1) / g.Heff + 1) * (g.H - g.Heff);
+    g.na_i = (g.PR * PW + 63) / 64;
+    STITO_REQUIRE(g.na_i <= 8, STITO_E_UNSUPPORTED, "conv tile: halo patch of %d pixels exceeds the staging budget", g.PR * PW);
+    const size_t lds = (size_t)2 * (9 * BN * 4 + g.na_i * 256) * sizeof(float);
+    auto kern = k_conv3x3<WM, WN, TW, POOL>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (int64_t)g.n_m_tiles * (g.Cout / BN);
+    STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WM * WN), lds, st, in, wpk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
 
-template <int WM, int WN, int TW, bool POOL>
-static int launch_conv(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
-                       const ConvGeom &g, hipStream_t st) {
-    if (g_conv_mode == 1) return launch_conv_mode<WM, WN, TW, POOL, 1>(in, wpk, scale, shift, out, g, st);
-    if (g_conv_mode == 2) return launch_conv_mode<WM, WN, TW, POOL, 2>(in, wpk, scale, shift, out, g, st);
-    return launch_conv_mode<WM, WN, TW, POOL, 0>(in, wpk, scale, shift, out, g, st);
-}
-
 template <int WM, int WN, bool POOL>
 static int launch_conv_tw(const float *in, const float *wpk, const float *scale, const float *shift, float *out,
-                          const ConvGeom &g, hipStream_t st) {
+                          const ConvShape &g, hipStream_t st) {
     if (g.W >= 16) return launch_conv<WM, WN, 16, POOL>(in, wpk, scale, shift, out, g, st);
     if (g.W >= 8) return launch_conv<WM, WN, 8, POOL>(in, wpk, scale, shift, out, g, st);
     return launch_conv<WM, WN, 4, POOL>(in, wpk, scale, shift, out, g, st);
@@ -516,20 +511,11 @@ static int conv_first(const float *in, const float *w, const float *scale, const
 
 using namespace stito;
 
-extern "C" int stito_set_option(const char *name, int value) {
-    if (name != nullptr && std::string(name) == "conv_mode") {
-        STITO_REQUIRE(value >= 0 && value <= 2, STITO_E_INVALID, "conv_mode must be 0, 1 or 2");
-        g_conv_mode = value;
-        return STITO_OK;
-    }
-    STITO_REQUIRE(false, STITO_E_INVALID, "unknown option %s", name ? name : "(null)");
-}
-
 extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin) { return (size_t)cout * cin * 9; }
 
 extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, float *packed_dev, void *stream) {
     const int64_t n = (int64_t)cout * cin * 9;
-    hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, cout, cin, packed_dev);
+    hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, cout, cin, CK, packed_dev);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
@@ -558,8 +544,7 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
     }
     STITO_REQUIRE(cout % 64 == 0, STITO_E_UNSUPPORTED, "conv: cout=%d must be a multiple of 64", cout);
     STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
-    ConvGeom g{};
-    g.S = n; g.H = H; g.W = W; g.Cin = cin; g.Cout = cout;
+    ConvShape g{n, H, W, cin, cout};
     if (cout % 128 == 0) {
         return pool ? launch_conv_tw<2, 2, true>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st)
                     : launch_conv_tw<2, 2, false>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st);

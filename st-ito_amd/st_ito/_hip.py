@@ -55,7 +55,6 @@ _lib = None
 SIGNATURES = {
     "stito_last_error": (c_char_p, []),
     "stito_version": (c_int, []),
-    "stito_set_option": (c_int, [c_char_p, c_int]),
     "stito_fx_num_params": (c_int, [c_int]),
     "stito_chain_out_channels": (c_int, [POINTER(FxDesc), c_int, c_int]),
     "stito_chain_num_dims": (c_int, [POINTER(FxDesc), c_int]),

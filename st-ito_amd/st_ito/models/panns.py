@@ -116,7 +116,7 @@ class Cnn14(nn.Module):
         self._packed = None      # device-side packed weights, built lazily
         self._packed_key = None
         self._ws = None
-        self.max_streams_per_pass = int(os.environ.get("STITO_MAX_STREAMS", "128"))
+        self.max_streams_per_pass = int(os.environ.get("STITO_MAX_STREAMS", "512"))
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
