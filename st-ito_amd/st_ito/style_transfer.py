@@ -132,6 +132,19 @@ def gather_fitness(local: torch.Tensor, popsize: int) -> torch.Tensor:
     return torch.cat(parts)
 
 
+def sharded_evaluate(W, eval_local):
+    """Evaluate a population across the ranks of the default process group.
+
+    `eval_local(W_shard) -> (loss tensor (n_local,), embeds, audios)` is called with this rank's
+    contiguous shard of W; the per-rank fitness vectors are all-gathered into candidate order, so
+    every rank returns the same full fitness list (and its own shard's embeds/audios)."""
+    _, rank, world = _dist_info()
+    P = len(W)
+    lo, hi = shard_bounds(P, rank, world)
+    loss, embeds, audios = eval_local(W[lo:hi])
+    return gather_fitness(loss, P).tolist(), embeds, audios
+
+
 def run_es(
     input_audio: torch.Tensor,
     target_audio: torch.Tensor,
@@ -186,12 +199,8 @@ def run_es(
 
     def evaluate(W, dropout: float = 0.0, want_audio: bool = False):
         """GPU replacement of the reference's evaluate closure (474-573)."""
-        P = len(W)
-        lo, hi = shard_bounds(P, rank, world)
-        loss, embeds, audios = evaluator.evaluate(W[lo:hi], random_crop=random_crop, rng=rng,
-                                                  want_audio=want_audio, dropout=dropout)
-        loss = gather_fitness(loss, P)
-        return loss.tolist(), embeds, audios
+        return sharded_evaluate(W, lambda Ws: evaluator.evaluate(Ws, random_crop=random_crop, rng=rng,
+                                                                 want_audio=want_audio, dropout=dropout))
 
     # setup CMA-ES
     if find_w0:

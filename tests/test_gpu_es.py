@@ -1,0 +1,132 @@
+"""GPU: the ES driver end to end (run_es, CLI) -- BASELINE.json configs[0] shape -- and the
+selected-parameter-vector determinism claim of north_star."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import st_ito_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from st_ito import _hip
+    _hip.lib()
+    return torch.device("cuda", 0)
+
+
+def _product_model(dev, om):
+    from st_ito.models.panns import Cnn14
+    pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "minmax")
+    pm.load_state_dict(om.state_dict())
+    return pm.eval().to(dev)
+
+
+def test_config0_run_es_matches_cpu_es_bit_exact_wopt(dev, capsys):
+    """configs[0]: 48 kHz mono 2 s, EQ+comp chain (D = 22), pop = 8, 5 iterations.
+    The same seeded CMA-ES is driven once by the oracle's CPU evaluate and once by the HIP
+    evaluate: the selected parameter vector must be bit-identical, fopt within 1e-4."""
+    from st_ito import effects as E, cmaes
+    from st_ito.style_transfer import run_es
+    from st_ito.utils import get_param_embeds
+    om = O.make_synthetic_model(0)
+    pm = _product_model(dev, om)
+    n, P, iters, seed = 96000, 8, 5, 42
+    x = O.synth_audio(1234, 1, n)[None]
+    op = O.make_plugins(["ParametricEQ", "Compressor"])
+    D = 22
+    tgt = torch.from_numpy(O.process_audio(O.synth_audio(4321, 1, n).numpy(), np.random.default_rng(7).random(D), SR, op))[None]
+
+    # CPU ES (oracle evaluate)
+    xc, tc = x.clone(), tgt.clone()
+    xc /= xc.abs().max().clamp(min=1e-8); tc /= tc.abs().max().clamp(min=1e-8)
+    te = O.get_param_embeds(tc, om, SR)
+    es = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P, "seed": seed})
+    f_hist = []
+    for _ in range(iters):
+        W = es.ask()
+        f, _, _ = O.evaluate(W, xc, SR, op, te, om)
+        es.tell(W, f)
+        f_hist.append(sorted(f))
+    w_cpu, f_cpu = es.result[0], es.result[1]
+
+    res = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq-comp"), pm, get_param_embeds, max_iters=iters,
+                 popsize=P, find_w0=False, sigma0=0.33, seed=seed, early_stop=False)
+    assert set(res) >= {"output_audio", "params", "fopt", "wopt", "fval_history", "wopt_history"}
+    assert res["fval_history"][0] == float("inf") and res["wopt_history"][0] is None  # pre-tell sentinel
+    assert res["num_evals"] == P * iters
+    np.testing.assert_array_equal(res["wopt"], w_cpu)
+    assert abs(res["fopt"] - f_cpu) < 1e-4 * max(1.0, abs(f_cpu))
+    assert res["output_audio"].shape == (1, n)       # mono in, mono out (1-channel plugins only)
+    ref_audio = O.process_audio(xc[0].numpy(), w_cpu, SR, op)
+    assert np.abs(res["output_audio"].numpy() - ref_audio).max() < 5e-5
+    assert res["params"]["Compressor"]["ratio"] == w_cpu[19] * 19.0 + 1.0
+
+
+def test_find_w0_and_early_stop_paths(dev):
+    from st_ito import effects as E
+    from st_ito.style_transfer import run_es
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    x = O.synth_audio(5, 2, 70000)[None]
+    tgt = O.synth_audio(6, 2, 70000)[None]
+    r1 = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, max_iters=2, popsize=4,
+                find_w0=True, sigma0=0.33, seed=1)
+    r2 = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, max_iters=2, popsize=4,
+                find_w0=True, sigma0=0.33, seed=1)
+    np.testing.assert_array_equal(r1["wopt"], r2["wopt"])  # seeded: reproducible
+    assert r1["num_evals"] == 4 + 2 * 4                     # the find_w0 batch counts
+    assert -1.0 <= r1["fopt"] <= 1.0
+    with pytest.raises(ValueError):
+        run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, distance="l2")
+
+
+def test_cli_end_to_end(dev, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import run_optim
+    from st_ito.audio_io import save_wav, load_wav
+    save_wav(str(tmp_path / "in.wav"), O.synth_audio(11, 2, 60000), SR)
+    save_wav(str(tmp_path / "tgt.wav"), O.synth_audio(12, 2, 60000), SR)
+    out = tmp_path / "out"
+    res = run_optim.main([str(tmp_path / "in.wav"), str(tmp_path / "tgt.wav"), "--effect-type", "basic", "--algorithm", "es",
+                          "--metric", "param", "--max-iters", "2", "--popsize", "4", "--max-length", "48000", "--synthetic",
+                          "--seed", "3", "--output-dir", str(out), "--savepop"])
+    run_dir = out / "in_to_tgt_es"
+    for f in ("input_audio.wav", "target_audio.wav", "output_audio_sigma=0.33.wav", "parameters_sigma=0.33.json"):
+        assert (run_dir / f).exists(), f
+    params = json.load(open(run_dir / "parameters_sigma=0.33.json"))
+    assert list(params) == ["ParametricEQ", "Compressor", "Distortion", "Delay", "Reverb"]
+    assert sum(len(v) for v in params.values()) == 31   # run_optim.py basic chain: 18+4+2+3+4
+    y, sr = load_wav(str(run_dir / "output_audio_sigma=0.33.wav"))
+    assert sr == SR and y.shape == (2, 48000) and abs(y.abs().max().item() - 1.0) < 1e-6
+    assert (run_dir / "pop_0").is_dir() and len(list((run_dir / "pop_0").iterdir())) == 4
+    assert res["num_evals"] == 4 + 2 * 4
+
+
+def test_fitness_independent_of_batch_position_and_size(dev):
+    """a candidate's fitness must not depend on where in the batch (or on which
+    rank) it was evaluated -- bitwise."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    x = O.synth_audio(21, 2, 100000)[None]
+    tgt = O.synth_audio(22, 2, 100000)[None]
+    pp = E.make_plugins("bench5")
+    te = get_param_embeds(tgt, pm, SR)
+    ev = PopulationEvaluator(x, SR, pp, pm, te)
+    W = np.random.default_rng(0).random((6, 45))
+    full = ev.evaluate(W)[0].cpu().numpy()
+    rev = ev.evaluate(W[::-1].copy())[0].cpu().numpy()[::-1]
+    one = np.array([ev.evaluate(W[i:i + 1])[0].item() for i in range(6)], dtype=np.float32)
+    np.testing.assert_array_equal(full, rev)
+    np.testing.assert_array_equal(full, one)

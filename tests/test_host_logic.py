@@ -1,0 +1,218 @@
+"""CPU tests of the host side: C-ABI surface, chain compilation, CMA-ES, population sharding
+(world_size-2 gloo), and the no-fallback rule."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from st_ito import _hip
+    hdr = open(os.path.join(ROOT, "include", "stito_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(stito_\w+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = _hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/stito_hip.h but not exported"
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    assert lib.stito_version() >= 1
+    for kind, n in enumerate([18, 4, 2, 3, 4, 1]):
+        assert lib.stito_fx_num_params(kind) == n
+    assert lib.stito_fx_num_params(99) < 0
+
+
+def test_compile_chain_offsets_bypass_fixed():
+    from st_ito import effects as E, _hip
+    from st_ito.engine import compile_chain
+    lib = _hip.lib()
+    pl = E.make_plugins("bench5")
+    d, n = compile_chain(pl)
+    assert n == 45 == lib.stito_chain_num_dims(d, 5)
+    assert [x.w_offset for x in d][:5] == [0, 18, 22, 26, 44]
+    assert lib.stito_chain_out_channels(d, 5, 1) == 2 and lib.stito_chain_out_channels(d, 5, 2) == 2
+    pl = E.make_plugins("basic", with_bypass=True)  # load_plugins layout: +1 dead slot per plugin
+    d, n = compile_chain(pl)
+    assert n == 31 + 5 and all(x.has_bypass == 1 for x in list(d)[:5])
+    pl = E.make_plugins("eq-comp")
+    pl["Compressor"]["fixed_parameters"] = {"ratio": 4.0}
+    d, n = compile_chain(pl)
+    assert n == 22 and d[1].fixed_mask == 0b10
+    assert abs(d[1].fixed_raw[1] - (4.0 - 1.0) / 19.0) < 1e-15
+    assert lib.stito_chain_out_channels(d, 2, 1) == 1  # mono stays mono (BASELINE config 0)
+    with pytest.raises(AssertionError):  # Parameter.set_value range assert (effects.py:792)
+        pl["Compressor"]["fixed_parameters"] = {"ratio": 40.0}
+        compile_chain(pl)
+    with pytest.raises(ValueError):
+        compile_chain({"x": {"num_channels": 1, "fixed_parameters": {}}})
+    with pytest.raises(NotImplementedError):
+        compile_chain({"x": {"vst_filepath": "a.vst3", "num_channels": 1, "fixed_parameters": {}}})
+    ws = lib.stito_render_workspace_bytes(compile_chain(E.make_plugins("bench5"))[0], 5, 2, 480000, 256)
+    assert ws > 256 * 2 * 480000 * 4  # envelope buffer for the compressor
+
+
+def test_parameter_protocol_and_load_plugins(capsys):
+    from st_ito import effects as E
+    from st_ito.style_transfer import load_plugins, parameters_to_dict
+    p = E.Parameter(80.0, 20.0, 4000.0)
+    assert p.raw_value == (80.0 - 20.0) / 3980.0 and p.get_value() == p.raw_value * 3980.0 + 20.0
+    with pytest.raises(AssertionError):
+        p.set_value(1.0)
+    plugins = {"ParametricEQ": {"class_path": E.BasicParametricEQ, "num_params": None, "num_channels": 1,
+                                "fixed_parameters": {}}}
+    plugins, total, init = load_plugins(plugins)
+    assert total == 19 and init[0] == 0.0 and plugins["ParametricEQ"]["parameter_names"][0] == "our_bypass"
+    w = np.linspace(0.1, 0.9, 19)
+    d = parameters_to_dict(w, plugins)
+    assert d["ParametricEQ"]["our_bypass"] == w[0]
+    assert d["ParametricEQ"]["low_shelf_gain_db"] == w[1] * 48.0 - 24.0
+    with pytest.raises(NotImplementedError):
+        E.BasicChorus()
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly, never route through the oracle."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from st_ito import effects as E, _hip
+    from st_ito.style_transfer import process_audio
+    from st_ito.utils import make_synthetic_param_model, get_param_embeds
+    with pytest.raises(_hip.StitoError):
+        process_audio(np.zeros((1, 4096), np.float32), np.full(18, 0.5), 48000, E.make_plugins("eq"))
+    with pytest.raises(_hip.StitoError):
+        E.BasicCompressor().process(np.zeros((1, 4096), np.float32), 48000)
+    for mod in ("engine", "utils", "style_transfer", "effects", "cmaes", "models/panns", "_hip"):
+        src = open(os.path.join(ROOT, "st-ito_amd", "st_ito", mod + ".py")).read()
+        assert "st_ito_oracle" not in src and "oracle" not in src.replace("oracle's deterministic fill", ""), mod
+
+
+def test_bound_transform():
+    from st_ito.cmaes import BoundTransform
+    bt = BoundTransform(0.0, 1.0)
+    assert bt.al == 0.05 and bt.au == 0.1
+    y = np.linspace(-3, 4, 2001)
+    x = bt(y)
+    assert x.min() >= 0.0 and x.max() <= 1.0
+    inner = (y >= 0.05) & (y <= 0.9)
+    np.testing.assert_allclose(x[inner], y[inner], atol=1e-15)  # identity in the interior
+    assert abs(bt(np.array([-0.05]))[0]) < 1e-15 and abs(bt(np.array([1.1]))[0] - 1.0) < 1e-15
+    assert np.abs(np.diff(x)).max() < 2 * (y[1] - y[0])  # continuous, slope <= 1
+
+
+def test_cmaes_deterministic_and_converges():
+    from st_ito.cmaes import CMAEvolutionStrategy
+    f = lambda x: float(np.sum((x - np.linspace(0.1, 0.9, 12)) ** 2))
+
+    def run(seed):
+        es = CMAEvolutionStrategy(np.full(12, 0.5), 0.33, {"bounds": [0, 1], "popsize": 24, "seed": seed})
+        assert es.result[0] is None and es.result[1] == float("inf")  # pre-tell sentinel, like pycma
+        for _ in range(120):
+            X = es.ask()
+            assert all((x >= 0).all() and (x <= 1).all() for x in X) and len(X) == 24
+            es.tell(X, [f(x) for x in X])
+        return es.result
+    a, b, c = run(3), run(3), run(4)
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[1] == b[1] and not np.array_equal(a[0], c[0])
+    assert a[1] < 1e-8
+    # rank-based: any strictly monotone transform of the fitness gives the same trajectory
+    es1 = CMAEvolutionStrategy(np.full(5, 0.5), 0.3, {"bounds": [0, 1], "popsize": 10, "seed": 1})
+    es2 = CMAEvolutionStrategy(np.full(5, 0.5), 0.3, {"bounds": [0, 1], "popsize": 10, "seed": 1})
+    for _ in range(20):
+        X1, X2 = es1.ask(), es2.ask()
+        es1.tell(X1, [np.sum(x ** 2) for x in X1])
+        es2.tell(X2, [np.exp(np.sum(x ** 2)) for x in X2])
+    np.testing.assert_array_equal(es1.result[0], es2.result[0])
+
+
+def test_shard_bounds_cover_population():
+    from st_ito.style_transfer import shard_bounds
+    for P in (1, 7, 8, 256, 2048, 1023):
+        for G in (1, 2, 3, 8):
+            spans = [shard_bounds(P, r, G) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == P
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert shard_bounds(2048, 3, 8) == (768, 1024)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.path.join({root!r}, "st-ito_amd"))
+import numpy as np, torch, torch.distributed as dist
+from st_ito.cmaes import CMAEvolutionStrategy
+from st_ito.style_transfer import sharded_evaluate
+rank = int(sys.argv[1]); world = int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+P, D = 13, 6                      # odd population: uneven shards
+es = CMAEvolutionStrategy(np.full(D, 0.5), 0.33, {{"bounds": [0, 1], "popsize": P, "seed": 42}})
+calls = []
+def eval_local(Ws):
+    calls.append(len(Ws))
+    return torch.tensor([float(np.sum((w - 0.25) ** 2)) for w in Ws], dtype=torch.float32), None, None
+for it in range(15):
+    W = es.ask()
+    f, _, _ = sharded_evaluate(W, eval_local)
+    assert len(f) == P
+    es.tell(W, f)
+out = np.concatenate([es.result[0], [es.result[1], calls[0]]])
+np.save(sys.argv[4] + f".{{rank}}.npy", out)
+dist.destroy_process_group()
+"""
+
+
+def test_population_sharding_world_size_2_gloo(tmp_path):
+    """N > 1 path on CPU: two ranks, replicated seeded CMA-ES, sharded evaluation, gloo
+    all-gather of the fitness scalars -> identical selected vector on both ranks and the same
+    trajectory as the single-process run."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(tmp_path / "o")]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    o0, o1 = np.load(tmp_path / "o.0.npy"), np.load(tmp_path / "o.1.npy")
+    np.testing.assert_array_equal(o0[:-1], o1[:-1])     # bit-identical wopt / fopt on both ranks
+    assert (o0[-1], o1[-1]) == (7, 6)                    # 13 candidates -> shards of 7 and 6
+    # single-process reference
+    from st_ito.cmaes import CMAEvolutionStrategy
+    es = CMAEvolutionStrategy(np.full(6, 0.5), 0.33, {"bounds": [0, 1], "popsize": 13, "seed": 42})
+    for _ in range(15):
+        W = es.ask()
+        es.tell(W, torch.tensor([float(np.sum((w - 0.25) ** 2)) for w in W], dtype=torch.float32).tolist())
+    np.testing.assert_array_equal(o0[:6], es.result[0])
+
+
+def test_cli_parser_keeps_reference_flags():
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import importlib
+    ro = importlib.import_module("run_optim")
+    a = ro.build_parser().parse_args(["in.wav", "tgt.wav", "--max-iters", "5", "--popsize", "8", "--max-length", "96000",
+                                      "--effect-type", "basic", "--algorithm", "es", "--metric", "param", "--use-gpu",
+                                      "--parallel", "--savepop", "--normalize-stages", "--dropout", "0.1"])
+    assert (a.input, a.target_pos, a.popsize, a.max_iters, a.max_length) == ("in.wav", "tgt.wav", 8, 5, 96000)
+    d = ro.build_parser().parse_args(["in.wav", "tgt.wav"])
+    assert (d.max_iters, d.popsize, d.max_length, d.effect_type, d.algorithm, d.metric) == (300, 32, 262144, "vst", "es", "param")
+    b = ro.build_parser().parse_args(["in.wav", "--target", "t.wav"])  # README.md:18 spelling
+    assert b.target == "t.wav"
+    with pytest.raises(NotImplementedError):
+        ro.main(["in.wav", "t.wav", "--algorithm", "autodiff"])
+    with pytest.raises(NotImplementedError):
+        ro.main(["in.wav", "t.wav"])  # default --effect-type vst
+
+
+def test_audio_io_roundtrip(tmp_path):
+    from st_ito.audio_io import load_wav, save_wav, resample
+    x = torch.rand(2, 1000) * 2 - 1
+    save_wav(str(tmp_path / "a.wav"), x, 48000)
+    y, sr = load_wav(str(tmp_path / "a.wav"))
+    assert sr == 48000 and torch.equal(x, y)
+    z = resample(torch.sin(torch.arange(4410) * 0.05)[None], 44100, 48000)
+    assert z.shape == (1, 4800)
