@@ -194,18 +194,36 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
     const int lr = tid >> 5, lj = tid & 31;
 
     double z[12];
-    // ---- pass A: zero-state response of every chunk, keep only the final state -------------
+    // tile staging: every thread fetches EQ_NC/8 = 32 scattered 4-byte pieces per tile; all of them
+    // are issued together into registers one tile ahead of use so HBM latency overlaps the cascade.
+    float pre[EQ_NC / 8];
+    auto fetch = [&](int64_t t0) {  // unconditional loads (clamped), masked afterwards: no branches
 #pragma unroll
-    for (int k = 0; k < 12; ++k) z[k] = 0.0;
-    for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
-        __syncthreads();
-#pragma unroll 4
+        for (int it = 0; it < EQ_NC / 8; ++it) {
+            const int r = it * 8 + lr;
+            const int64_t idx = (int64_t)r * B + t0 + lj;
+            pre[it] = x[idx < L ? idx : L - 1];
+        }
+#pragma unroll
         for (int it = 0; it < EQ_NC / 8; ++it) {
             const int r = it * 8 + lr;
             const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
-            tile[r][lj] = (pos < B && idx < L) ? x[idx] : 0.0f;
+            if (!(pos < B && idx < L)) pre[it] = 0.0f;
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < EQ_NC / 8; ++it) tile[it * 8 + lr][lj] = pre[it];
+    };
+    // ---- pass A: zero-state response of every chunk, keep only the final state -------------
+#pragma unroll
+    for (int k = 0; k < 12; ++k) z[k] = 0.0;
+    fetch(0);
+    for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
         __syncthreads();
+        stage();
+        __syncthreads();
+        if (t0 + EQ_TS < B) fetch(t0 + EQ_TS);
         int64_t n = len - t0;
         n = n < 0 ? 0 : (n > EQ_TS ? EQ_TS : n);
         for (int j = 0; j < (int)n; ++j) (void)eq_step((double)tile[tid][j], sec, z);
@@ -263,20 +281,17 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
     // ---- pass B: rerun every chunk from its true initial state, write the output -------------
 #pragma unroll
     for (int k = 0; k < 12; ++k) z[k] = zst[k][tid];
+    fetch(0);
     for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
         __syncthreads();
-#pragma unroll 4
-        for (int it = 0; it < EQ_NC / 8; ++it) {
-            const int r = it * 8 + lr;
-            const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
-            tile[r][lj] = (pos < B && idx < L) ? x[idx] : 0.0f;
-        }
+        stage();
         __syncthreads();
+        if (t0 + EQ_TS < B) fetch(t0 + EQ_TS);
         int64_t n = len - t0;
         n = n < 0 ? 0 : (n > EQ_TS ? EQ_TS : n);
         for (int j = 0; j < (int)n; ++j) tile[tid][j] = (float)eq_step((double)tile[tid][j], sec, z);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < EQ_NC / 8; ++it) {
             const int r = it * 8 + lr;
             const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
@@ -292,21 +307,30 @@ static constexpr int CE_T = 128;           // samples per tile
 static constexpr int CE_LD = CE_T + 4;     // LDS row stride (16-B aligned rows, conflict-free b128 column walks)
 static constexpr int CE_THREADS = 256;     // wave 0: recurrence; waves 1-3: global <-> LDS movers
 static constexpr int CE_MOVERS = CE_THREADS - 64;
+static constexpr int CE_SLOTS = 3;         // LDS ring: tile being stored / computed / filled
+static constexpr int CE_NIT = (64 * (CE_T / 4) + CE_MOVERS - 1) / CE_MOVERS;  // float4 items per mover per tile
+
+__device__ __forceinline__ float env_step(float x, float &yold, float cat, float crl) {
+    const float v = fabsf(x), d = yold - v;
+    const float ya = fmaf(cat, d, v), yr = fmaf(crl, d, v);
+    yold = (d < 0.0f) ? ya : yr;  // v > yold  <=>  d < 0
+    return yold;
+}
 
 // envelope: env = v + cte*(env_prev - v), cte = v > env_prev ? attack : release.
-// The recurrence is serial in time, so the time axis cannot be split; what can be done is to make
-// the serial wave do nothing but the recurrence.  One workgroup = 64 streams: lane l of wave 0
-// owns stream l and walks its row of an LDS tile (4 samples per ds_read_b128); waves 1-3 stream
-// tile k+1 in from HBM and tile k-1 out (coalesced float4 rows), double-buffered, one barrier
-// per 128 samples.
+// The recurrence is serial in time (a switching one-pole is not associative), so the time axis
+// cannot be split; what can be done is to make the serial wave do nothing but the recurrence and
+// to keep HBM latency off its critical path.  One workgroup = 64 streams: lane l of wave 0 owns
+// stream l and rewrites its row of an LDS tile in place (x -> env, 4 samples per ds_read_b128);
+// waves 1-3 are movers: tile j+3 is in flight HBM -> registers (two register sets), tile j+1 is
+// being written to the ring, tile j-1 is being stored -- one barrier per 128 samples.
 template <bool VEC>
 __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
                                                           int C, int64_t L, int S, const double *__restrict__ coef) {
     extern __shared__ __attribute__((aligned(16))) float ce_smem[];
-    float *xin = ce_smem;                      // [2][64][CE_LD]
-    float *eout = ce_smem + 2 * 64 * CE_LD;    // [2][64][CE_LD]
-    const float **row_in = (const float **)(ce_smem + 4 * 64 * CE_LD);  // [64]
-    float **row_out = (float **)(row_in + 64);                          // [64]
+    float *ring = ce_smem;                                                       // [CE_SLOTS][64][CE_LD]
+    const float **row_in = (const float **)(ce_smem + CE_SLOTS * 64 * CE_LD);   // [64]
+    float **row_out = (float **)(row_in + 64);                                   // [64]
 
     const int tid = threadIdx.x;
     const int s0 = blockIdx.x * 64;
@@ -324,91 +348,123 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
     __syncthreads();
     const int64_t ntiles = (L + CE_T - 1) / CE_T;
     const int m = tid - 64;  // mover index
-
-    // every mover thread serves the same (row, float4 column) items in every tile: keep their
-    // global pointers in registers so that a tile's loads are all in flight at once
-    constexpr int NIT = (64 * (CE_T / 4) + CE_MOVERS - 1) / CE_MOVERS;
-    const float *gsrc[NIT];
-    float *gdst[NIT];
-    int loff[NIT], qcol[NIT];
-    bool ok[NIT];
-    if (VEC && tid >= 64) {
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = m + u * CE_MOVERS;
-            const int r = (i / (CE_T / 4)) & 63, q = i % (CE_T / 4);
-            ok[u] = i < 64 * (CE_T / 4) && r < nrows;
-            gsrc[u] = row_in[r] + 4 * q;
-            gdst[u] = row_out[r] + 4 * q;
-            loff[u] = r * CE_LD + 4 * q;
-            qcol[u] = 4 * q;
-        }
-    }
-    auto load_tile = [&](int64_t k) {
-        float *dst = xin + (k & 1) * 64 * CE_LD;
-        const int64_t t0 = k * CE_T;
-        if (VEC) {
-            float4 v[NIT];
-#pragma unroll
-            for (int u = 0; u < NIT; ++u)
-                v[u] = (ok[u] && t0 + qcol[u] + 3 < L) ? *(const float4 *)(gsrc[u] + t0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < NIT; ++u)
-                if (m + u * CE_MOVERS < 64 * (CE_T / 4)) *(float4 *)(dst + loff[u]) = v[u];
-        } else {
-            for (int i = m; i < 64 * CE_T; i += CE_MOVERS) {
-                const int r = i / CE_T, j = i % CE_T;
-                dst[r * CE_LD + j] = (r < nrows && t0 + j < L) ? row_in[r][t0 + j] : 0.0f;
-            }
-        }
-    };
-    auto store_tile = [&](int64_t k) {
-        const float *src = eout + (k & 1) * 64 * CE_LD;
-        const int64_t t0 = k * CE_T;
-        if (VEC) {
-            float4 v[NIT];
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) v[u] = *(const float4 *)(src + (ok[u] ? loff[u] : 0));
-#pragma unroll
-            for (int u = 0; u < NIT; ++u)
-                if (ok[u] && t0 + qcol[u] + 3 < L) *(float4 *)(gdst[u] + t0) = v[u];
-        } else {
-            for (int i = m; i < 64 * CE_T; i += CE_MOVERS) {
-                const int r = i / CE_T, j = i % CE_T;
-                if (r < nrows && t0 + j < L) row_out[r][t0 + j] = src[r * CE_LD + j];
-            }
-        }
-    };
-
-    if (tid >= 64) load_tile(0);
-    __syncthreads();
     float yold = 0.0f;
-    for (int64_t k = 0; k < ntiles; ++k) {
-        if (tid >= 64) {
-            if (k + 1 < ntiles) load_tile(k + 1);
-            if (k > 0) store_tile(k - 1);
-        } else {
-            __builtin_amdgcn_s_setprio(3);
-            const float *xr = xin + (k & 1) * 64 * CE_LD + tid * CE_LD;
-            float *er = eout + (k & 1) * 64 * CE_LD + tid * CE_LD;
-#pragma unroll 4
-            for (int j = 0; j < CE_T; j += 4) {
-                const float4 x4 = *(const float4 *)(xr + j);
-                float xs[4] = {x4.x, x4.y, x4.z, x4.w}, es[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v = fabsf(xs[u]), d = yold - v;
-                    const float ya = fmaf(cat, d, v), yr = fmaf(crl, d, v);
-                    yold = (d < 0.0f) ? ya : yr;  // v > yold  <=>  d < 0
-                    es[u] = yold;
-                }
-                *(float4 *)(er + j) = make_float4(es[0], es[1], es[2], es[3]);
+
+    if (!VEC) {  // unaligned fallback: synchronous scalar tiles (any L / base alignment)
+        for (int64_t k = 0; k < ntiles; ++k) {
+            const int64_t t0 = k * CE_T;
+            for (int i = tid; i < 64 * CE_T; i += CE_THREADS) {
+                const int r = i / CE_T, j = i % CE_T;
+                ring[r * CE_LD + j] = (r < nrows && t0 + j < L) ? row_in[r][t0 + j] : 0.0f;
             }
-            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            if (tid < 64)
+                for (int j = 0; j < CE_T; ++j) ring[tid * CE_LD + j] = env_step(ring[tid * CE_LD + j], yold, cat, crl);
+            __syncthreads();
+            for (int i = tid; i < 64 * CE_T; i += CE_THREADS) {
+                const int r = i / CE_T, j = i % CE_T;
+                if (r < nrows && t0 + j < L) row_out[r][t0 + j] = ring[r * CE_LD + j];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // every mover thread serves the same (row, float4 column) items in every tile: column
+    // q = m % 32, rows m / 32 + 6u (CE_MOVERS = 6 * 32).  Pointers are kept in registers as
+    // global-address-space pointers (the row tables in LDS hold generic pointers).
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f4 *gsrc_t;
+    typedef __attribute__((address_space(1))) f4 *gdst_t;
+    gsrc_t gsrc[CE_NIT];
+    gdst_t gdst[CE_NIT];
+    bool ok[CE_NIT], inr[CE_NIT];
+    const int mq = 4 * (m & 31), mr0 = m >> 5;
+    const int lbase = mr0 * CE_LD + mq;  // + u * 6 * CE_LD
+#pragma unroll
+    for (int u = 0; u < CE_NIT; ++u) {
+        const int r = mr0 + 6 * u;
+        inr[u] = tid >= 64 && r < 64;
+        ok[u] = inr[u] && r < nrows;
+        gsrc[u] = (gsrc_t)(row_in[r & 63]);
+        gdst[u] = (gdst_t)(row_out[r & 63]);
+    }
+    f4 setA[CE_NIT], setB[CE_NIT], vst[CE_NIT];
+
+    // loads are unconditional (addresses clamped into the stream) and masked afterwards: a branch
+    // around each load would make the compiler drain vmcnt between them
+#define CE_GLOAD(SET, K)                                                                      \
+    {                                                                                         \
+        const int64_t t0_ = (int64_t)(K) * CE_T + mq;                                          \
+        const int64_t tc_ = (t0_ < L - 4 ? t0_ : L - 4) >> 2;                                  \
+        const bool in_ = t0_ + 3 < L;                                                          \
+        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u) SET[u] = gsrc[u][tc_];              \
+        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
+            if (!(ok[u] && in_)) SET[u] = (f4)(0.0f);                                          \
+    }
+#define CE_LWRITE(SET, K)                                                                     \
+    {                                                                                         \
+        float *dst_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase;                       \
+        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
+            if (inr[u]) *(f4 *)(dst_ + u * 6 * CE_LD) = SET[u];                                \
+    }
+#define CE_GSTORE(K)                                                                          \
+    {                                                                                         \
+        const float *src_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase;                 \
+        const int64_t t0_ = (int64_t)(K) * CE_T + mq;                                          \
+        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
+            vst[u] = *(const f4 *)(src_ + (inr[u] ? u * 6 * CE_LD : 0));                       \
+        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
+            if (ok[u] && t0_ + 3 < L) gdst[u][t0_ >> 2] = vst[u];                              \
+    }
+    auto serial_tile = [&](int64_t k) {
+        float *row = ring + (int)(k % CE_SLOTS) * 64 * CE_LD + tid * CE_LD;
+#pragma unroll 4
+        for (int j = 0; j < CE_T; j += 4) {
+            const float4 x4 = *(const float4 *)(row + j);
+            float4 e4;
+            e4.x = env_step(x4.x, yold, cat, crl);
+            e4.y = env_step(x4.y, yold, cat, crl);
+            e4.z = env_step(x4.z, yold, cat, crl);
+            e4.w = env_step(x4.w, yold, cat, crl);
+            *(float4 *)(row + j) = e4;
+        }
+    };
+
+    if (tid >= 64) {  // prologue: tiles 0, 1 -> registers; tile 0 -> ring; tile 2 -> registers
+        CE_GLOAD(setA, 0);
+        CE_GLOAD(setB, 1);
+        CE_LWRITE(setA, 0);
+        CE_GLOAD(setA, 2);
+    } else {
+        __builtin_amdgcn_s_setprio(3);
+    }
+    __syncthreads();
+    // iteration j: wave 0 computes tile j in place; movers write tile j+1 (loaded two iterations
+    // ago), refill that register set with tile j+3 and store tile j-1.
+    for (int64_t j = 0; j < ntiles; j += 2) {
+        if (tid >= 64) {
+            if (j + 1 < ntiles) CE_LWRITE(setB, j + 1);
+            CE_GLOAD(setB, j + 3);
+            if (j > 0) CE_GSTORE(j - 1);
+        } else {
+            serial_tile(j);
+        }
+        __syncthreads();
+        if (j + 1 >= ntiles) break;
+        if (tid >= 64) {
+            if (j + 2 < ntiles) CE_LWRITE(setA, j + 2);
+            CE_GLOAD(setA, j + 4);
+            CE_GSTORE(j);
+        } else {
+            serial_tile(j + 1);
         }
         __syncthreads();
     }
-    if (tid >= 64) store_tile(ntiles - 1);
+    if (tid >= 64) CE_GSTORE(ntiles - 1);
+#undef CE_GLOAD
+#undef CE_LWRITE
+#undef CE_GSTORE
 }
 
 // VCA: gain = env < thr ? 1 : pow(env/thr, 1/ratio - 1); y = gain * x.
@@ -532,13 +588,18 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
     int appos[4] = {0, 0, 0, 0};
     const int c2 = tid / RV_TT, t2 = tid % RV_TT;
 
+    // input tile for the next iteration is fetched one tile ahead (registers) so that its HBM
+    // latency overlaps the comb / all-pass phases
+    float pa = (tid < RV_TT && tid < L) ? xl[tid] : 0.0f, pb = (tid < RV_TT && tid < L) ? xr[tid] : 0.0f;
     for (int64_t t0 = 0; t0 < L; t0 += RV_TT) {
         const int nv = (int)min((int64_t)RV_TT, L - t0);
         __syncthreads();
         if (tid < RV_TT) {
-            const float a = tid < nv ? xl[t0 + tid] : 0.0f, b = tid < nv ? xr[t0 + tid] : 0.0f;
-            s_x[tid] = a; s_x[RV_TT + tid] = b;
-            s_in[tid] = (a + b) * 0.015f;
+            s_x[tid] = pa; s_x[RV_TT + tid] = pb;
+            s_in[tid] = (pa + pb) * 0.015f;
+            const int64_t tn = t0 + RV_TT + tid;
+            pa = tn < L ? xl[tn] : 0.0f;
+            pb = tn < L ? xr[tn] : 0.0f;
         }
         __syncthreads();
         {   // ---- phase 1: 16 comb filters, one per wave ----
@@ -801,7 +862,7 @@ extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, con
                 break;
             case STITO_FX_COMPRESSOR:
             {
-                const size_t lds = (size_t)4 * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *);
+                const size_t lds = (size_t)CE_SLOTS * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *);
                 // float4 rows need 16-B aligned stream starts: every stream offset is a multiple of L
                 const bool vec = (L % 4 == 0) && (((uintptr_t)in.base & 15) == 0) && (((uintptr_t)envbuf & 15) == 0);
                 auto kern = vec ? k_comp_env<true> : k_comp_env<false>;
