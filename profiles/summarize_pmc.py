@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Per-dispatch HBM traffic of the conv kernels from two rocprofv3 --pmc runs (FETCH_SIZE and
+WRITE_SIZE collected in separate passes, as MI355X_MICROARCH.md prescribes).  Units: the counters
+are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of a wide streaming read at 64 B, so
+the read side is doubled (guide section HBM); WRITE_SIZE is taken as is (uncalibrated).
+Usage: python profiles/summarize_pmc.py <fetch.db> <write.db> <n_streams>"""
+import sqlite3
+import sys
+
+fetch_db, write_db, S = sys.argv[1], sys.argv[2], int(sys.argv[3])
+
+
+def per_dispatch(path, counter):
+    cur = sqlite3.connect(path).cursor()
+    return cur.execute("select name, counter_value, duration from pmc_events where counter_name=? and name like '%k_conv3x3%' "
+                       "order by dispatch_id", (counter,)).fetchall()
+
+
+f = per_dispatch(fetch_db, "FETCH_SIZE")
+w = per_dispatch(write_db, "WRITE_SIZE")
+assert len(f) == len(w), (len(f), len(w))
+# conv_bench runs each of the 11 layers twice (warm + 1 rep): keep the second launch of each
+chans = [64, 128, 256, 512, 1024, 2048]
+layers = []
+H, W = 469, 128
+for b in range(6):
+    for j in range(2):
+        cin = (chans[b - 1] if b else 1) if j == 0 else chans[b]
+        cout = chans[b]
+        pool = j == 1 and b < 5
+        if cin % 4 == 0:
+            Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+            alg = 4.0 * (S * H * W * cin + S * Ho * Wo * cout + 9 * cin * cout)
+            layers.append((f"{H}x{W} {cin}->{cout}{' pool' if pool else ''}", alg, 2.0 * 9 * cin * cout * H * W * S))
+    if b < 5:
+        H, W = H // 2, W // 2
+print(f"{'layer':26s} {'fetch_GB(x2)':>12s} {'write_GB':>9s} {'traffic_GB':>10s} {'algorithmic_GB':>14s} {'ratio':>6s} {'FLOP/B':>7s}")
+tf = tw = ta = 0.0
+for i, (name, alg, fl) in enumerate(layers):
+    fe = f[2 * i + 1][1] * 1024 * 2 / 1e9
+    wr = w[2 * i + 1][1] * 1024 / 1e9
+    print(f"{name:26s} {fe:12.3f} {wr:9.3f} {fe + wr:10.3f} {alg / 1e9:14.3f} {(fe + wr) / (alg / 1e9):6.2f} {fl / ((fe + wr) * 1e9):7.0f}")
+    tf += fe; tw += wr; ta += alg / 1e9
+print(f"{'total (11 launches)':26s} {tf:12.3f} {tw:9.3f} {tf + tw:10.3f} {ta:14.3f} {(tf + tw) / ta:6.2f}")
+print(f"per launch average: traffic {1e3 * (tf + tw) / 11:.1f} MB, algorithmic {1e3 * ta / 11:.1f} MB  (n_streams = {S})")
