@@ -129,6 +129,9 @@ int stito_logmel(const stito_frontend *fe, const float *audio_dev, const float *
 
 /* ---- Cnn14 trunk -------------------------------------------------------------------------- */
 #define STITO_CNN14_NUM_CONVS 12
+/* 3x3 conv algorithm: direct implicit GEMM, or Winograd F(2x2,3x3) (2.25x fewer MACs; needs
+ * cin % 8 == 0, cout % 64 == 0 and a feature map whose halo patch fits LDS). */
+enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1 };
 
 typedef struct {
     int32_t embed_dim;
@@ -137,7 +140,9 @@ typedef struct {
     int32_t reserved;
     /* conv weights in the packed layout produced by stito_cnn14_pack_conv; BN folded to
      * per-channel scale/shift applied after the convolution (eval mode, panns.py:67-68) */
-    const float *conv_w_dev[STITO_CNN14_NUM_CONVS];
+    const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
+    const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* STITO_CONV_WINOGRAD packing, or NULL: used per
+                                                          layer whenever the feature map fits that kernel */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -146,10 +151,11 @@ typedef struct {
     const float *fc_side_b_dev;  /* (embed_dim) */
 } stito_cnn14_weights;
 
-/* Number of floats of a packed conv weight for (cout, cin). */
-size_t stito_cnn14_packed_conv_floats(int cout, int cin);
-/* (cout, cin, 3, 3) PyTorch layout -> packed layout used by the MFMA kernel. */
-int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, float *packed_dev, void *stream);
+/* Number of floats of a packed conv weight for (cout, cin) and algorithm. */
+size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo);
+/* (cout, cin, 3, 3) PyTorch layout -> packed layout used by the MFMA kernel of `algo`
+ * (Winograd: the weights are transformed, U = G g G^T). */
+int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream);
 /* BN(eval) -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  gamma_dev == NULL:
  * identity (use_batchnorm=False). */
 int stito_bn_fold(const float *gamma_dev, const float *beta_dev, const float *mean_dev,
@@ -170,9 +176,11 @@ int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, i
 /* Individual layers, exposed for parity tests and profiling.
  * in (n, H, W, cin) NHWC -> out (n, H', W', cout) NHWC, y = relu(conv3x3(x) * scale + shift),
  * pool != 0: 2x2 average pooling (floor). */
+/* 1 if stito_conv3x3_bn_relu can run this shape with `algo`, else 0. */
+int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
-                          int pool, void *stream);
+                          int pool, int algo, void *stream);
 
 /* ---- embeddings -> fitness ----------------------------------------------------------------- */
 /* In place: NaN scrub (utils.py:491-497), L2-normalise mid/side (n_cand, E).  If target_mid_dev

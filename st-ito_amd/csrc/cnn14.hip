@@ -54,8 +54,20 @@ struct ConvGeom {
     int Ho, Wo;
 };
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
+// LDS-DMA: 16 B per lane, global -> LDS at (wave-uniform lds_dst) + lane * 16, no VGPR round trip.
+// Issued through inline asm on purpose: with the __builtin_amdgcn_global_load_lds form hipcc
+// cannot prove that the copy's destination (the idle buffer) does not alias the fragment reads of
+// the live buffer and drains vmcnt(0) before the first ds_read, which serialises the prefetch with
+// the MFMA block.  Hidden from its bookkeeping, the copy is waited for explicitly (s_waitcnt
+// vmcnt(0) + barrier at the top of the next chunk).  M0 is saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const float *gsrc, float *lds_dst) {
+    unsigned keep;
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds)
+                 : "memory");
+}
 
 template <int WM, int WN, int TW, bool POOL>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restrict__ in, const float *__restrict__ wpk,
@@ -126,9 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
     auto issue = [&](int chunk, int boff) {
 #pragma unroll
         for (int k = 0; k < MAXI; ++k) {
-            if (gval[k])
-                __builtin_amdgcn_global_load_lds((glb_void *)(gsrc[k] + (int64_t)chunk * gstep[k]),
-                                                 (lds_void *)(smem + boff + ldso[k]), 16, 0, 0);
+            if (gval[k]) glds16(gsrc[k] + (int64_t)chunk * gstep[k], smem + boff + ldso[k]);
         }
     };
 
@@ -231,6 +241,288 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
                     for (int e = 0; e < 4; ++e) {
                         const int ww = w0 + 2 * gc + (e & 1);
                         if (ok[e >> 1] && ww < g.W) out[obase[e >> 1] + (int64_t)(e & 1) * g.Cout + co] = y[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_conv_wino: the same 3x3 conv + BN + ReLU (+ 2x2 avg-pool) by Winograd F(2x2, 3x3)
+// (Lavin & Gray 2016): Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 4x4 input tile d.  The 16
+// element-wise products become 16 independent GEMMs  M_p[tile, cout] = V_p[tile, cin] U_p[cin, cout],
+// 16 MACs per 2x2 output tile instead of 36: 2.25x fewer MFMA cycles at float32 accuracy
+// comparable to the direct form (all transform coefficients are 0, +-1, +-1/2).
+//
+// Workgroup = 64 tiles x 64 output channels x 16 positions, 12 waves with two roles:
+//   * 8 consumer waves: wave w owns positions {2w, 2w+1} for the WHOLE 64 x 64 tile (2 x 2 x 2 MFMA
+//     32x32 blocks = 128 accumulator VGPRs); per 8-channel chunk it issues 8 ds_read_b128 and 32
+//     MFMAs and nothing else, so the matrix pipes never wait for VALU work;
+//   * 4 producer waves: copy U (pre-transformed weights, [cin/8][16][cout][8]) by LDS-DMA, load
+//     each tile's 4x4 patch straight from the NHWC activations (bounds-checked = zero padding,
+//     stream boundaries included), form B^T d B and write V for the NEXT chunk (double buffered).
+//   One barrier per chunk; 3 waves per SIMD (2 consumers + 1 producer), 128 KB LDS.
+// The 16 positions of one output meet only in the epilogue: accumulators are exchanged through LDS
+// (the whole 128 KB, half of the output channels at a time), then A^T M A, BN, ReLU and the 2x2
+// average pool (one Winograd tile == one pooling window) are applied per (tile, channel).
+// ------------------------------------------------------------------------------------------------
+struct WinoGeom {
+    int S, H, W, Cin, Cout;
+    int TR, TC;        // tile rows per stream / tile columns that produce output
+    int64_t VTR;       // S * TR
+    int n_col_blocks, n_m_blocks;
+    int Ho, Wo;
+    int PR, pa_i;      // halo patch rows; patch LDS-DMA wave-instructions per chunk
+};
+
+static constexpr int WK = 8;           // input channels per chunk
+static constexpr int WINO_THREADS = 768;
+
+template <int TTW, bool POOL>
+__global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restrict__ in, const float *__restrict__ upk,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, float *__restrict__ out,
+                                                             WinoGeom g) {
+    constexpr int TTH = 64 / TTW;
+    constexpr int U_FLOATS = 16 * 64 * WK;  // [pos][cout][8]
+    constexpr int V_FLOATS = 16 * 64 * WK;  // [pos][(tile + pos%4) % 64][8]
+    constexpr int BUF = U_FLOATS + V_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // channel tile fastest: the Cout/64 workgroups that share one halo patch run side by side, so
+    // the patch is fetched from HBM once and the concurrently streamed U slabs stay L2-resident
+    const int n_tiles = g.Cout / 64;
+    const int m_blk = blockIdx.x / n_tiles;
+    const int n0 = (blockIdx.x % n_tiles) * 64;
+    const int cb = m_blk % g.n_col_blocks;
+    const int64_t rb = m_blk / g.n_col_blocks;
+    const int64_t vtr0 = rb * TTH;
+    const int tc0 = cb * TTW;
+    const int n_chunks = g.Cin / WK;
+
+    // LDS map (floats): [0, 2*BUF) U/V double buffer | patch[2] (raw halo patch, LDS-DMA) | zero row
+    constexpr int PWC = 2 * TTW + 2;                 // patch columns
+    const int pfl = g.pa_i * 256 + 256;              // floats per patch buffer: pixels + a row of zeros
+    float *patch0 = smem + 2 * BUF;                  // (the zero row is what out-of-stream rows read)
+    // input virtual row (s*H + h) of patch row 0: one above the first tile row's centre rows
+    const int64_t iv_lo = (vtr0 / g.TR) * g.H + 2 * (vtr0 % g.TR) - 1;
+
+    if (wv >= 8) {
+        // =============================== producer waves ===============================
+        const int ptid = tid - 512;
+        // zero the patch buffers and the zero row once: padding / out-of-range pixels are never written
+        for (int i = ptid; i < 2 * pfl; i += 256) patch0[i] = 0.0f;
+
+        // ---- copy descriptors: U (32 wave-instructions / chunk) + patch (pa_i), 12 slots per wave ----
+        constexpr int MAXI = 12;
+        const float *gsrc[MAXI];
+        int ldso[MAXI], gstep[MAXI];
+        bool gval[MAXI];
+        const int npix = g.PR * PWC;
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const int ii = (wv - 8) + 4 * k;  // wave-uniform
+            if (ii < 32) {
+                const int pos = ii >> 1, q = (ii & 1) * 64 + lane;
+                gsrc[k] = upk + ((int64_t)pos * g.Cout + n0 + (q >> 1)) * WK + (q & 1) * 4;
+                gstep[k] = 16 * g.Cout * WK;
+                ldso[k] = pos * 64 * WK + (ii & 1) * 256;  // + buffer offset
+                gval[k] = true;
+            } else {
+                const int a = ii - 32;
+                const int q = a * 64 + lane, pix = q >> 1;
+                const int pr = pix / PWC, pc = pix % PWC;
+                const int64_t iv = iv_lo + pr;
+                const int w = 2 * tc0 - 1 + pc;
+                gval[k] = a < g.pa_i && pix < npix && iv >= 0 && iv < (int64_t)g.S * g.H && w >= 0 && w < g.W;
+                gsrc[k] = in + (gval[k] ? (iv * g.W + w) * (int64_t)g.Cin : 0) + (q & 1) * 4;
+                gstep[k] = WK;
+                ldso[k] = -(a * 256 + 1);  // patch slot (negative marks "patch buffer")
+            }
+        }
+        auto issue = [&](int chunk, int u_boff, float *pbuf) {  // U(chunk) -> u_boff, patch(chunk + 1) -> pbuf
+#pragma unroll
+            for (int k = 0; k < MAXI; ++k) {
+                if (ldso[k] >= 0) {
+                    if (chunk < n_chunks) glds16(gsrc[k] + (int64_t)chunk * gstep[k], smem + u_boff + ldso[k]);
+                } else if (gval[k] && chunk + 1 < n_chunks) {
+                    glds16(gsrc[k] + (int64_t)(chunk + 1) * gstep[k], pbuf + (-ldso[k] - 1));
+                }
+            }
+        };
+
+        // ---- transform items: thread = (tile, channel quad, row xi of B^T d B), two tiles per thread ----
+        const int xi = ptid & 3, p_quad = (ptid >> 2) & 1;
+        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+        const float sgn = xi == 1 ? 1.0f : -1.0f;   // T[xi] = d[ra] + sgn * d[rb]
+        int rowA[2], rowB[2], vdst[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int tile = (ptid >> 3) + 32 * it;
+            const int64_t vtr = vtr0 + tile / TTW;
+            const int tcl = tile % TTW;
+            const int64_t s_ = vtr / g.TR;
+            const int tr = (int)(vtr % g.TR);
+            const int pc0 = (int)(s_ * g.H + 2 * tr - 1 - iv_lo);  // patch row of this tile's row rr = 0
+            const int ha = 2 * tr - 1 + ra, hb = 2 * tr - 1 + rb;
+            const int zoff = g.pa_i * 256;
+            rowA[it] = ((vtr < g.VTR && ha >= 0 && ha < g.H) ? ((pc0 + ra) * PWC + 2 * tcl) * 8 : zoff) + p_quad * 4;
+            rowB[it] = ((vtr < g.VTR && hb >= 0 && hb < g.H) ? ((pc0 + rb) * PWC + 2 * tcl) * 8 : zoff) + p_quad * 4;
+            // V plane p = 4*xi + nu keeps tile t at slot (t + xi) % 64: the 4 lanes of a tile that
+            // write the same nu then hit 4 different 32-B slots instead of one bank group
+            vdst[it] = U_FLOATS + (xi * 4) * 64 * WK + ((tile + xi) & 63) * WK + p_quad * 4;
+        }
+        auto f4fma = [](float s_, float4 b, float4 a) { return make_float4(fmaf(s_, b.x, a.x), fmaf(s_, b.y, a.y), fmaf(s_, b.z, a.z), fmaf(s_, b.w, a.w)); };
+        auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+        auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+        auto transform_store = [&](const float *pbuf, int v_boff) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float4 T[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    T[j] = f4fma(sgn, *(const float4 *)(pbuf + rowB[it] + j * 8), *(const float4 *)(pbuf + rowA[it] + j * 8));
+                float *vb = smem + v_boff + vdst[it];
+                *(float4 *)(vb + 0 * 64 * WK) = f4sub(T[0], T[2]);
+                *(float4 *)(vb + 1 * 64 * WK) = f4add(T[1], T[2]);
+                *(float4 *)(vb + 2 * 64 * WK) = f4sub(T[2], T[1]);
+                *(float4 *)(vb + 3 * 64 * WK) = f4sub(T[1], T[3]);
+            }
+        };
+
+        // producers synchronise among themselves through the workgroup barrier only, so the zero fill
+        // must be complete (and drained) before any copy can land next to it: the first workgroup
+        // barrier below is that point; the first copies are issued after it.
+        __syncthreads();                     // B0: zero fill done
+        issue(0, 0, patch0);                 // U(0) -> buffer 0, patch(1) -> patch0 ... but patch(0) first:
+        // patch(0) has no earlier iteration to ride on: fetch it into patch buffer 1 right away
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k)
+            if (ldso[k] < 0 && gval[k]) glds16(gsrc[k], patch0 + pfl + (-ldso[k] - 1));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                     // B1: patch(0) (and U(0), patch(1)) visible to all producers
+        transform_store(patch0 + pfl, 0);    // V(0)
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const int cur = (chunk & 1) * BUF;
+            // patch(chunk+1) lives in patch buffer (chunk & 1); patch(chunk+2) goes to the other one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own copies for `chunk` / patch(chunk+1) landed
+            __syncthreads();                                   // X: V(chunk), U(chunk), patch(chunk+1) visible
+            if (chunk + 1 < n_chunks) {
+                issue(chunk + 1, BUF - cur, patch0 + ((chunk + 1) & 1) * pfl);
+                transform_store(patch0 + (chunk & 1) * pfl, BUF - cur);
+            }
+        }
+        // keep the barrier count of the consumers' epilogue
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) __syncthreads();
+        return;
+    }
+
+    // =============================== consumer waves ===============================
+    const int half = lane >> 5, l31 = lane & 31;
+    int a_off[2][2], b_off[2][2];  // [pp][mb / nb]
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int p = 2 * wv + pp;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a_off[pp][q] = U_FLOATS + p * 64 * WK + ((q * 32 + l31 + (p >> 2)) & 63) * WK + half * 4;
+            b_off[pp][q] = p * 64 * WK + (q * 32 + l31) * WK + half * 4;
+        }
+    }
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pp][mb][nb][r] = 0.0f;
+
+    __syncthreads();  // B0 (producers: zero fill)
+    __syncthreads();  // B1 (producers: first patch landed)
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const float *sb = smem + (chunk & 1) * BUF;
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            float4 av[2], bv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                av[q] = *(const float4 *)(sb + a_off[pp][q]);
+                bv[q] = *(const float4 *)(sb + b_off[pp][q]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float a0 = kk == 0 ? av[0].x : kk == 1 ? av[0].y : kk == 2 ? av[0].z : av[0].w;
+                const float a1 = kk == 0 ? av[1].x : kk == 1 ? av[1].y : kk == 2 ? av[1].z : av[1].w;
+                const float b0 = kk == 0 ? bv[0].x : kk == 1 ? bv[0].y : kk == 2 ? bv[0].z : bv[0].w;
+                const float b1 = kk == 0 ? bv[1].x : kk == 1 ? bv[1].y : kk == 2 ? bv[1].z : bv[1].w;
+                acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[pp][0][0], 0, 0, 0);
+                acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[pp][0][1], 0, 0, 0);
+                acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[pp][1][0], 0, 0, 0);
+                acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pp][1][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: exchange positions through LDS (all 128 KB), one half of the channels per pass:
+    // xch[pos][tile 0..63][channel 0..31]; then A^T M A, BN + ReLU (+ pool) per (tile, channel)
+    float *xch = smem;
+    const int e_co = tid & 31, e_t0 = tid >> 5;  // thread -> channel, tiles e_t0 + 16*k
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();  // main loop / previous pass done with the LDS
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float *xp = xch + (2 * wv + pp) * 64 * 32 + mb * 32 * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    xp[row * 32] = acc[pp][mb][nb][r];
+                }
+            }
+        __syncthreads();
+        const int co = n0 + nb * 32 + e_co;
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int tl = e_t0 + 16 * it;  // tile within the block
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = xch[p * 64 * 32 + tl * 32 + e_co];
+            float t0[4], t1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                t0[nu] = (m[nu] + m[4 + nu]) + m[8 + nu];
+                t1[nu] = (m[4 + nu] - m[8 + nu]) - m[12 + nu];
+            }
+            float y[4];
+            y[0] = (t0[0] + t0[1]) + t0[2];
+            y[1] = (t0[1] - t0[2]) - t0[3];
+            y[2] = (t1[0] + t1[1]) + t1[2];
+            y[3] = (t1[1] - t1[2]) - t1[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(y[e], sc, sh), 0.0f);
+            const int64_t vtr = vtr0 + tl / TTW;
+            const int tc = tc0 + tl % TTW;
+            if (vtr < g.VTR && tc < g.TC) {
+                const int64_t s = vtr / g.TR;
+                const int tr = (int)(vtr % g.TR);
+                if (POOL) {
+                    out[((s * g.Ho + tr) * g.Wo + tc) * (int64_t)g.Cout + co] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int hh = 2 * tr + (e >> 1), ww = 2 * tc + (e & 1);
+                        if (hh < g.H && ww < g.W) out[((s * g.H + hh) * g.W + ww) * (int64_t)g.Cout + co] = y[e];
                     }
                 }
             }
@@ -432,6 +724,32 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
     o[i] = w[((int64_t)co * Cin + ci) * 9 + tap];
 }
 
+// Winograd weight transform U = G g G^T (float64, rounded once), packed [cin/8][16][cout][8].
+__global__ void k_pack_wino(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    double gk[3][3], t[4][3], u[4][4];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) gk[a][b] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + b];
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = gk[0][b];
+        t[1][b] = 0.5 * (gk[0][b] + gk[1][b] + gk[2][b]);
+        t[2][b] = 0.5 * (gk[0][b] - gk[1][b] + gk[2][b]);
+        t[3][b] = gk[2][b];
+    }
+    for (int a = 0; a < 4; ++a) {
+        u[a][0] = t[a][0];
+        u[a][1] = 0.5 * (t[a][0] + t[a][1] + t[a][2]);
+        u[a][2] = 0.5 * (t[a][0] - t[a][1] + t[a][2]);
+        u[a][3] = t[a][2];
+    }
+    const int chunk = ci / WK, c8 = ci % WK;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            o[(((int64_t)chunk * 16 + a * 4 + b) * Cout + co) * WK + c8] = (float)u[a][b];
+}
+
 __global__ void k_bn_fold(const float *g, const float *b, const float *m, const float *v, float eps, int n, float *scale,
                           float *shift) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,6 +812,68 @@ static int launch_conv_tw(const float *in, const float *wpk, const float *scale,
     return launch_conv<WM, WN, 4, POOL>(in, wpk, scale, shift, out, g, st);
 }
 
+
+template <int TTW, bool POOL>
+static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t &blocks) {
+    constexpr int TTH = 64 / TTW;
+    g = WinoGeom{};
+    g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
+    g.Ho = c.H / 2; g.Wo = c.W / 2;
+    g.TR = POOL ? g.Ho : (c.H + 1) / 2;
+    g.TC = POOL ? g.Wo : (c.W + 1) / 2;
+    if (g.TR < 1 || g.TC < 1) return false;
+    g.VTR = (int64_t)g.S * g.TR;
+    g.n_col_blocks = (g.TC + TTW - 1) / TTW;
+    const int64_t nrb = (g.VTR + TTH - 1) / TTH;
+    blocks = nrb * g.n_col_blocks * (g.Cout / 64);
+    if (nrb * g.n_col_blocks >= (1 << 30) || blocks >= (1ll << 31)) return false;
+    g.n_m_blocks = (int)(nrb * g.n_col_blocks);
+    // patch rows: 2 per tile row + 2 halo, plus the rows skipped at every stream boundary a block can straddle
+    g.PR = 2 * TTH + 2 + ((TTH - 1) / g.TR + 1) * (g.H - 2 * g.TR > 0 ? g.H - 2 * g.TR : 0);
+    g.pa_i = (g.PR * (2 * TTW + 2) * 2 + 63) / 64;
+    lds = ((size_t)2 * (16 * 64 * WK * 2) + 2 * (g.pa_i * 256 + 256)) * sizeof(float);
+    return g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
+}
+
+template <int TTW, bool POOL>
+static int launch_wino(const float *in, const float *upk, const float *scale, const float *shift, float *out,
+                       const ConvShape &c, hipStream_t st) {
+    WinoGeom g;
+    size_t lds;
+    int64_t blocks;
+    STITO_REQUIRE((wino_geometry<TTW, POOL>(c, g, lds, blocks)), STITO_E_UNSUPPORTED,
+                  "conv (winograd): %dx%d map does not fit the LDS-resident halo patch", c.H, c.W);
+    auto kern = k_conv_wino<TTW, POOL>;
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WINO_THREADS), lds, st, in, upk, scale, shift, out, g);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+static int wino_ttw(const ConvShape &c, bool pool) {
+    const int tc = pool ? c.W / 2 : (c.W + 1) / 2;
+    return tc >= 8 ? 8 : (tc >= 4 ? 4 : 2);
+}
+
+static bool wino_supported(const ConvShape &c, bool pool) {
+    if (c.Cin % WK != 0 || c.Cout % 64 != 0) return false;
+    WinoGeom g;
+    size_t lds;
+    int64_t blocks;
+    const int ttw = wino_ttw(c, pool);
+    if (pool) return ttw == 8 ? wino_geometry<8, true>(c, g, lds, blocks) : ttw == 4 ? wino_geometry<4, true>(c, g, lds, blocks) : wino_geometry<2, true>(c, g, lds, blocks);
+    return ttw == 8 ? wino_geometry<8, false>(c, g, lds, blocks) : ttw == 4 ? wino_geometry<4, false>(c, g, lds, blocks) : wino_geometry<2, false>(c, g, lds, blocks);
+}
+
+template <bool POOL>
+static int launch_wino_tw(const float *in, const float *upk, const float *scale, const float *shift, float *out,
+                          const ConvShape &c, hipStream_t st) {
+    const int ttw = wino_ttw(c, POOL);
+    if (ttw == 8) return launch_wino<8, POOL>(in, upk, scale, shift, out, c, st);
+    if (ttw == 4) return launch_wino<4, POOL>(in, upk, scale, shift, out, c, st);
+    return launch_wino<2, POOL>(in, upk, scale, shift, out, c, st);
+}
+
 static int conv_first(const float *in, const float *w, const float *scale, const float *shift, float *out, int S, int H,
                       int W, int Cout, hipStream_t st) {
     STITO_REQUIRE(Cout % 4 == 0 && 256 % (Cout / 4) == 0, STITO_E_UNSUPPORTED, "first conv: cout %d", Cout);
@@ -511,11 +891,21 @@ static int conv_first(const float *in, const float *w, const float *scale, const
 
 using namespace stito;
 
-extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin) { return (size_t)cout * cin * 9; }
+static bool wino_ok(int cout, int cin) { return cin % WK == 0 && cout % 64 == 0; }
 
-extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, float *packed_dev, void *stream) {
-    const int64_t n = (int64_t)cout * cin * 9;
-    hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, cout, cin, CK, packed_dev);
+extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo) {
+    return (size_t)cout * cin * (algo == STITO_CONV_WINOGRAD ? 16 : 9);
+}
+
+extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream) {
+    if (algo == STITO_CONV_WINOGRAD) {
+        STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
+        const int64_t n = (int64_t)cout * cin;
+        hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, cout, cin, packed_dev);
+    } else {
+        const int64_t n = (int64_t)cout * cin * 9;
+        hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, cout, cin, CK, packed_dev);
+    }
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
@@ -533,9 +923,17 @@ extern "C" int stito_transpose(const float *in_dev, int rows, int cols, float *o
     return STITO_OK;
 }
 
+extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo) {
+    if (n <= 0 || H <= 0 || W <= 0 || cout % 4 != 0) return 0;
+    if (pool && (H < 2 || W < 2)) return 0;
+    if (algo == STITO_CONV_WINOGRAD) return wino_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
+    if (cin == 1) return (!pool && 256 % (cout / 4) == 0) ? 1 : 0;
+    return (cin % CK == 0 && cout % 64 == 0) ? 1 : 0;
+}
+
 extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                                      const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
-                                     int pool, void *stream) {
+                                     int pool, int algo, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
     if (cin % CK != 0) {
@@ -545,6 +943,11 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
     STITO_REQUIRE(cout % 64 == 0, STITO_E_UNSUPPORTED, "conv: cout=%d must be a multiple of 64", cout);
     STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
     ConvShape g{n, H, W, cin, cout};
+    if (algo == STITO_CONV_WINOGRAD) {
+        STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
+        return pool ? launch_wino_tw<true>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st)
+                    : launch_wino_tw<false>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st);
+    }
     if (cout % 128 == 0) {
         return pool ? launch_conv_tw<2, 2, true>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st)
                     : launch_conv_tw<2, 2, false>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st);
@@ -601,12 +1004,16 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     const float *cur = logmel_dev;
     for (int blk = 0; blk < 6; ++blk) {
         const int cin = w->channels[blk], cout = w->channels[blk + 1];
-        int rc = stito_conv3x3_bn_relu(cur, w->conv_w_dev[2 * blk], w->bn_scale_dev[2 * blk], w->bn_shift_dev[2 * blk], actA,
-                                       S, H[blk], W[blk], cin, cout, 0, stream);
-        if (rc) return rc;
-        rc = stito_conv3x3_bn_relu(actA, w->conv_w_dev[2 * blk + 1], w->bn_scale_dev[2 * blk + 1], w->bn_shift_dev[2 * blk + 1],
-                                   actB, S, H[blk], W[blk], cout, cout, blk < 5 ? 1 : 0, stream);
-        if (rc) return rc;
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * blk + j;
+            const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
+            // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
+            const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, STITO_CONV_WINOGRAD);
+            const int rc = stito_conv3x3_bn_relu(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
+                                                 w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
+                                                 wino ? STITO_CONV_WINOGRAD : STITO_CONV_DIRECT, stream);
+            if (rc) return rc;
+        }
         cur = actB;
     }
     const int C6 = w->channels[6], E = w->embed_dim;

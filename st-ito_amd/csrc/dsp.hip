@@ -197,23 +197,21 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
     // tile staging: every thread fetches EQ_NC/8 = 32 scattered 4-byte pieces per tile; all of them
     // are issued together into registers one tile ahead of use so HBM latency overlaps the cascade.
     float pre[EQ_NC / 8];
-    auto fetch = [&](int64_t t0) {  // unconditional loads (clamped), masked afterwards: no branches
+    auto fetch = [&](int64_t t0) {  // unconditional loads (clamped); masked in stage(), one tile later
 #pragma unroll
         for (int it = 0; it < EQ_NC / 8; ++it) {
             const int r = it * 8 + lr;
             const int64_t idx = (int64_t)r * B + t0 + lj;
             pre[it] = x[idx < L ? idx : L - 1];
         }
+    };
+    auto stage = [&](int64_t t0) {
 #pragma unroll
         for (int it = 0; it < EQ_NC / 8; ++it) {
             const int r = it * 8 + lr;
             const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
-            if (!(pos < B && idx < L)) pre[it] = 0.0f;
+            tile[r][lj] = (pos < B && idx < L) ? pre[it] : 0.0f;
         }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int it = 0; it < EQ_NC / 8; ++it) tile[it * 8 + lr][lj] = pre[it];
     };
     // ---- pass A: zero-state response of every chunk, keep only the final state -------------
 #pragma unroll
@@ -221,7 +219,7 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
     fetch(0);
     for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
         __syncthreads();
-        stage();
+        stage(t0);
         __syncthreads();
         if (t0 + EQ_TS < B) fetch(t0 + EQ_TS);
         int64_t n = len - t0;
@@ -284,7 +282,7 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
     fetch(0);
     for (int64_t t0 = 0; t0 < B; t0 += EQ_TS) {
         __syncthreads();
-        stage();
+        stage(t0);
         __syncthreads();
         if (t0 + EQ_TS < B) fetch(t0 + EQ_TS);
         int64_t n = len - t0;
@@ -391,22 +389,21 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
     }
     f4 setA[CE_NIT], setB[CE_NIT], vst[CE_NIT];
 
-    // loads are unconditional (addresses clamped into the stream) and masked afterwards: a branch
-    // around each load would make the compiler drain vmcnt between them
+    // loads are unconditional (addresses clamped into the stream) and masked only when they are
+    // written to LDS two iterations later: a branch around a load, or any use of its result, would
+    // make the compiler wait for it on the spot
 #define CE_GLOAD(SET, K)                                                                      \
     {                                                                                         \
         const int64_t t0_ = (int64_t)(K) * CE_T + mq;                                          \
         const int64_t tc_ = (t0_ < L - 4 ? t0_ : L - 4) >> 2;                                  \
-        const bool in_ = t0_ + 3 < L;                                                          \
         _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u) SET[u] = gsrc[u][tc_];              \
-        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            if (!(ok[u] && in_)) SET[u] = (f4)(0.0f);                                          \
     }
 #define CE_LWRITE(SET, K)                                                                     \
     {                                                                                         \
         float *dst_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase;                       \
+        const bool in_ = (int64_t)(K) * CE_T + mq + 3 < L; /* masked here, not at load time */ \
         _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            if (inr[u]) *(f4 *)(dst_ + u * 6 * CE_LD) = SET[u];                                \
+            if (inr[u]) *(f4 *)(dst_ + u * 6 * CE_LD) = (ok[u] && in_) ? SET[u] : (f4)(0.0f);  \
     }
 #define CE_GSTORE(K)                                                                          \
     {                                                                                         \

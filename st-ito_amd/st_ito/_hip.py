@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libstito_hip.so")
 
 FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN = range(6)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
+CONV_DIRECT, CONV_WINOGRAD = 0, 1
 MAX_FX_PARAMS = 18
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 
@@ -39,7 +40,7 @@ class Frontend(Structure):
 class Cnn14Weights(Structure):
     _fields_ = [
         ("embed_dim", c_int32), ("n_mels", c_int32), ("channels", c_int32 * 7), ("reserved", c_int32),
-        ("conv_w_dev", c_void_p * 12), ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
+        ("conv_w_dev", c_void_p * 12), ("conv_wino_dev", c_void_p * 12), ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
         ("fc_mid_wt_dev", c_void_p), ("fc_mid_b_dev", c_void_p),
         ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
     ]
@@ -65,15 +66,16 @@ SIGNATURES = {
     "stito_normalize_audio": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "stito_num_frames": (c_int64, [c_int64, c_int]),
     "stito_logmel": (c_int, [POINTER(Frontend), c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
-    "stito_cnn14_packed_conv_floats": (c_size_t, [c_int, c_int]),
-    "stito_cnn14_pack_conv": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "stito_cnn14_packed_conv_floats": (c_size_t, [c_int, c_int, c_int]),
+    "stito_cnn14_pack_conv": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "stito_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "stito_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "stito_cnn14_workspace_bytes": (c_size_t, [POINTER(Cnn14Weights), c_int, c_int64]),
     "stito_cnn14_forward": (c_int, [POINTER(Cnn14Weights), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                      c_int, c_int, c_void_p]),
+                                      c_int, c_int, c_int, c_void_p]),
     "stito_embed_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -117,6 +117,9 @@ class Cnn14(nn.Module):
         self._packed_key = None
         self._ws = None
         self.max_streams_per_pass = int(os.environ.get("STITO_MAX_STREAMS", "512"))
+        # 3x3 conv algorithm of the trunk: "winograd" (F(2x2,3x3), default) or "direct"
+        self.conv_algo = {"direct": _hip.CONV_DIRECT, "winograd": _hip.CONV_WINOGRAD}[
+            os.environ.get("STITO_CONV_ALGO", "winograd")]
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -158,8 +161,13 @@ class Cnn14(nn.Module):
             for j, (conv, bn) in enumerate(((blk.conv1, blk.bn1), (blk.conv2, blk.bn2))):
                 w = conv.weight.detach().to(torch.float32).contiguous()
                 cout, cin = w.shape[0], w.shape[1]
-                packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin), dtype=torch.float32, device=dev)
-                _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.ptr(packed), st))
+                packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, _hip.CONV_DIRECT), dtype=torch.float32, device=dev)
+                _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.CONV_DIRECT, _hip.ptr(packed), st))
+                if self.conv_algo == _hip.CONV_WINOGRAD and cin % 8 == 0 and cout % 64 == 0:
+                    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, _hip.CONV_WINOGRAD), dtype=torch.float32, device=dev)
+                    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.CONV_WINOGRAD, _hip.ptr(upk), st))
+                    W.conv_wino_dev[2 * b + j] = upk.data_ptr()
+                    keep.append(upk)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)
                 if isinstance(bn, nn.BatchNorm2d):

@@ -181,14 +181,16 @@ def test_logmel_vs_oracle_and_golden(dev, golden_dir, norm):
 
 
 CONV_CASES = [  # (n, H, W, cin, cout, pool)
+    (3, 29, 8, 64, 64, 0), (2, 117, 32, 64, 64, 0), (5, 7, 2, 64, 64, 0), (2, 13, 6, 8, 64, 1),
     (2, 33, 128, 1, 64, 0), (2, 33, 128, 64, 64, 1), (3, 16, 64, 64, 128, 0), (2, 17, 32, 128, 128, 1),
     (2, 9, 16, 256, 256, 1), (3, 4, 8, 128, 256, 0), (5, 2, 4, 256, 128, 0), (3, 14, 4, 64, 128, 0), (1, 7, 4, 64, 64, 0),
     (2, 29, 8, 64, 128, 1),
 ]
 
 
+@pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
-def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool):
+def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     from st_ito import _hip
     L = _hip.lib()
     g = torch.Generator().manual_seed(H * 1000 + W + cin)
@@ -203,16 +205,20 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool):
     ref = ref.permute(0, 2, 3, 1).contiguous()  # NHWC
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     wd = w.contiguous().to(dev)
-    packed = torch.empty(cout * cin * 9, device=dev)
+    if not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
+        assert algo == 1, "the direct kernel must cover every Cnn14-shaped layer"
+        pytest.skip("shape not covered by the Winograd kernel (direct is used instead)")
+    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), device=dev)
     st = _hip.stream_ptr()
-    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, _hip.ptr(packed), st))
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, algo, _hip.ptr(packed), st))
     out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
     sd, hd = scale.to(dev), shift.to(dev)
     _hip.check(L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
-                                       n, H, W, cin, cout, pool, st))
+                                       n, H, W, cin, cout, pool, algo, st))
     got = out.cpu().double()
     assert not torch.isnan(got).any(), "unwritten outputs"
     err = (got - ref).abs().max().item()
+    print(f"conv algo {algo} {n}x{H}x{W} {cin}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
 
 
