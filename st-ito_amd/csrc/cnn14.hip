@@ -25,6 +25,7 @@
 namespace stito {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int CK = 4;      // input channels per chunk (16 B per pixel / per weight row)
 
@@ -313,47 +314,54 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
 
     if (wv >= 8) {
         // =============================== producer waves ===============================
+        // Producers are the youngest waves of the workgroup: at equal priority the SIMD's issue
+        // arbiter serves the two (older) MFMA waves first and the producer only gets leftover slots,
+        // which stretches its ~150 instructions per chunk over more than a chunk period.
+        __builtin_amdgcn_s_setprio(3);
         const int ptid = tid - 512;
-        // zero the patch buffers and the zero row once: padding / out-of-range pixels are never written
-        for (int i = ptid; i < 2 * pfl; i += 256) patch0[i] = 0.0f;
+        // the row of zeros behind each patch buffer (write_p fills everything else, zeros included)
+        for (int i = ptid; i < 256; i += 256) { patch0[g.pa_i * 256 + i] = 0.0f; patch0[pfl + g.pa_i * 256 + i] = 0.0f; }
 
-        // ---- copy descriptors: U (32 wave-instructions / chunk) + patch (pa_i), 12 slots per wave ----
-        constexpr int MAXI = 12;
-        const float *gsrc[MAXI];
-        int ldso[MAXI], gstep[MAXI];
-        bool gval[MAXI];
-        const int npix = g.PR * PWC;
+        // ---- staging: U slab (16 x 64 x 8 floats per chunk, contiguous per position) and the halo patch
+        // go HBM/L2 -> registers -> LDS.  (LDS-DMA from only four waves per CU sustains too little
+        // bandwidth here: its in-flight window is small; ordinary loads pipeline two orders deeper.)
+        constexpr int NU = 8;   // float4 of U per producer thread per chunk
+        constexpr int NPL = 4;  // float4 of patch per producer thread per chunk (upper bound)
+        const f32x4 *u_src = (const f32x4 *)(upk + (int64_t)n0 * WK) + (ptid >> 7) * ((int64_t)g.Cout * WK / 4) + (ptid & 127);
+        const int64_t u_pos_stride = (int64_t)g.Cout * WK / 4, u_chunk_stride = 16 * u_pos_stride;
+        const int npix2 = g.PR * PWC * 2;
+        const f32x4 *p_src[NPL];
+        bool p_val[NPL];
 #pragma unroll
-        for (int k = 0; k < MAXI; ++k) {
-            const int ii = (wv - 8) + 4 * k;  // wave-uniform
-            if (ii < 32) {
-                const int pos = ii >> 1, q = (ii & 1) * 64 + lane;
-                gsrc[k] = upk + ((int64_t)pos * g.Cout + n0 + (q >> 1)) * WK + (q & 1) * 4;
-                gstep[k] = 16 * g.Cout * WK;
-                ldso[k] = pos * 64 * WK + (ii & 1) * 256;  // + buffer offset
-                gval[k] = true;
-            } else {
-                const int a = ii - 32;
-                const int q = a * 64 + lane, pix = q >> 1;
-                const int pr = pix / PWC, pc = pix % PWC;
-                const int64_t iv = iv_lo + pr;
-                const int w = 2 * tc0 - 1 + pc;
-                gval[k] = a < g.pa_i && pix < npix && iv >= 0 && iv < (int64_t)g.S * g.H && w >= 0 && w < g.W;
-                gsrc[k] = in + (gval[k] ? (iv * g.W + w) * (int64_t)g.Cin : 0) + (q & 1) * 4;
-                gstep[k] = WK;
-                ldso[k] = -(a * 256 + 1);  // patch slot (negative marks "patch buffer")
-            }
+        for (int j = 0; j < NPL; ++j) {
+            const int q = ptid + 256 * j, pix = q >> 1;
+            const int pr = pix / PWC, pc = pix % PWC;
+            const int64_t iv = iv_lo + pr;
+            const int w = 2 * tc0 - 1 + pc;
+            p_val[j] = q < npix2 && iv >= 0 && iv < (int64_t)g.S * g.H && w >= 0 && w < g.W;
+            p_src[j] = (const f32x4 *)(in + (p_val[j] ? (iv * g.W + w) * (int64_t)g.Cin : 0) + (q & 1) * 4);
         }
-        auto issue = [&](int chunk, int u_boff, float *pbuf) {  // U(chunk) -> u_boff, patch(chunk + 1) -> pbuf
-#pragma unroll
-            for (int k = 0; k < MAXI; ++k) {
-                if (ldso[k] >= 0) {
-                    if (chunk < n_chunks) glds16(gsrc[k] + (int64_t)chunk * gstep[k], smem + u_boff + ldso[k]);
-                } else if (gval[k] && chunk + 1 < n_chunks) {
-                    glds16(gsrc[k] + (int64_t)(chunk + 1) * gstep[k], pbuf + (-ldso[k] - 1));
-                }
-            }
-        };
+        // (macros, not lambdas: captured arrays assigned under a condition end up in scratch memory;
+        //  loads past the last chunk are clamped to it instead of being skipped)
+        f32x4 ru[NU], rp[NPL];   // native vectors: HIP's float4 struct is not promoted out of scratch here
+#define WINO_LOAD_U(CH)                                                                             \
+    {                                                                                               \
+        const int64_t cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                   \
+        _Pragma("unroll") for (int j = 0; j < NU; ++j) ru[j] = u_src[cc_ * u_chunk_stride + 2 * j * u_pos_stride]; \
+    }
+#define WINO_LOAD_P(CH)                                                                             \
+    {                                                                                               \
+        const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                       \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) rp[j] = p_src[j][cc_ * (WK / 4)];            \
+    }
+#define WINO_WRITE_U(BOFF)                                                                          \
+    { _Pragma("unroll") for (int j = 0; j < NU; ++j) *(f32x4 *)(smem + (BOFF) + (ptid + 256 * j) * 4) = ru[j]; }
+#define WINO_WRITE_P(PBUF)                                                                          \
+    {                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j)                                              \
+            if (ptid + 256 * j < npix2)                                                              \
+                *(f32x4 *)((PBUF) + (ptid + 256 * j) * 4) = p_val[j] ? rp[j] : (f32x4)(0.0f);                  \
+    }
 
         // ---- transform items: thread = (tile, channel quad, row xi of B^T d B), two tiles per thread ----
         const int xi = ptid & 3, p_quad = (ptid >> 2) & 1;
@@ -394,28 +402,33 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             }
         };
 
-        // producers synchronise among themselves through the workgroup barrier only, so the zero fill
-        // must be complete (and drained) before any copy can land next to it: the first workgroup
-        // barrier below is that point; the first copies are issued after it.
-        __syncthreads();                     // B0: zero fill done
-        issue(0, 0, patch0);                 // U(0) -> buffer 0, patch(1) -> patch0 ... but patch(0) first:
-        // patch(0) has no earlier iteration to ride on: fetch it into patch buffer 1 right away
-#pragma unroll
-        for (int k = 0; k < MAXI; ++k)
-            if (ldso[k] < 0 && gval[k]) glds16(gsrc[k], patch0 + pfl + (-ldso[k] - 1));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                     // B1: patch(0) (and U(0), patch(1)) visible to all producers
-        transform_store(patch0 + pfl, 0);    // V(0)
+        // patch(k) lives in patch buffer k & 1; U(k), V(k) in U/V buffer k & 1.
+        WINO_LOAD_U(0)
+        WINO_LOAD_P(0)
+        __syncthreads();                     // B0 (kept for symmetry with the consumers)
+        WINO_WRITE_U(0)
+        WINO_WRITE_P(patch0)
+        WINO_LOAD_P(1)
+        WINO_WRITE_P(patch0 + pfl)
+        __syncthreads();                     // B1: patch(0) visible to every producer wave
+        transform_store(patch0, 0);          // V(0)
+        WINO_LOAD_U(1)
+        WINO_LOAD_P(2)
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const int cur = (chunk & 1) * BUF;
-            // patch(chunk+1) lives in patch buffer (chunk & 1); patch(chunk+2) goes to the other one
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own copies for `chunk` / patch(chunk+1) landed
-            __syncthreads();                                   // X: V(chunk), U(chunk), patch(chunk+1) visible
+            __syncthreads();                 // X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free
             if (chunk + 1 < n_chunks) {
-                issue(chunk + 1, BUF - cur, patch0 + ((chunk + 1) & 1) * pfl);
-                transform_store(patch0 + (chunk & 1) * pfl, BUF - cur);
+                WINO_WRITE_U(BUF - cur)                               // U(chunk+1), loaded in the previous period
+                WINO_WRITE_P(patch0 + (chunk & 1) * pfl)              // patch(chunk+2)
+                WINO_LOAD_U(chunk + 2)
+                WINO_LOAD_P(chunk + 3)
+                transform_store(patch0 + ((chunk + 1) & 1) * pfl, BUF - cur);  // patch(chunk+1) -> V(chunk+1)
             }
         }
+#undef WINO_LOAD_U
+#undef WINO_LOAD_P
+#undef WINO_WRITE_U
+#undef WINO_WRITE_P
         // keep the barrier count of the consumers' epilogue
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) __syncthreads();
