@@ -80,7 +80,7 @@ def measure_conv_roofline(model, n_streams, T, reps=3):
     mfma_flops = mfma_ms = 0.0
     for i, r in enumerate(rows):
         Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
-        out = torch.empty((n_streams, Ho, Wo, r["cout"]), device=dev)
+        out = torch.empty((n_streams, r["cout"] // 8, Ho, Wo, 8), device=dev)
         wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 1)
         args = (_hip.ptr(cur), W.conv_wino_dev[i] if wino else W.conv_w_dev[i], W.bn_scale_dev[i], W.bn_shift_dev[i],
                 _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 1 if wino else 0, st)

@@ -174,8 +174,14 @@ int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, i
                         size_t workspace_bytes, void *stream);
 
 /* Individual layers, exposed for parity tests and profiling.
- * in (n, H, W, cin) NHWC -> out (n, H', W', cout) NHWC, y = relu(conv3x3(x) * scale + shift),
+ * Activations are channel-blocked: a map with C channels (C % 8 == 0) is (n, C/8, H, W, 8) float32;
+ * the 1-channel input of the first conv is (n, H, W).
+ * in (n, cin/8, H, W, 8) -> out (n, cout/8, H', W', 8), y = relu(conv3x3(x) * scale + shift),
  * pool != 0: 2x2 average pooling (floor). */
+/* Profiling aid: with buf_dev != NULL the Winograd launches use an instrumented instantiation whose
+ * workgroup 100 records s_memtime stamps of 32 chunks x 12 waves x 8 phases (int64) into buf_dev;
+ * NULL (default) restores the plain kernel.  See tools/wino_timeline.py. */
+int stito_debug_wino_trace(long long *buf_dev);
 /* 1 if stito_conv3x3_bn_relu can run this shape with `algo`, else 0. */
 int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,

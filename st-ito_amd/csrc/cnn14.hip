@@ -9,8 +9,8 @@
 // embeddings, so the contraction uses v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bitwise an
 // fmaf chain).  gfx950 has no TF32/xf32 path; the f32 MFMA peak (157.3 TFLOP/s) is the roofline.
 //
-// Layout: activations NHWC (stream, time, mel, channel) so that one pixel's channels are
-// contiguous (im2col K-runs are contiguous, the epilogue stores 128 B per pixel per half-wave).
+// Layout: activations channel-blocked NC8HW8 (see act_off): a K-chunk's halo patch is a set of dense
+// rows, 32 B per pixel.
 // Weights are pre-packed as [cin/4][tap][cout][4].
 //
 // Tiling: a workgroup computes BM = 64*WM output pixels x BN = 64*WN output channels; each of its
@@ -23,6 +23,15 @@
 #include "common.h"
 
 namespace stito {
+
+// Activation layout: channel-blocked NC8HW8 -- element (stream s, channel c, row h, column w) of a map
+// with C channels lives at (((s * C/8 + c/8) * H + h) * W + w) * 8 + c%8.  Eight consecutive
+// channels of a pixel are 32 B, and for one channel block consecutive pixels are contiguous: a
+// K-chunk's halo patch rows are dense 32-B-per-pixel runs (NHWC would touch one 32-B piece out of
+// every 4*C-byte pixel vector per chunk: 4x line over-fetch, measured as the Winograd limiter).
+__device__ __forceinline__ int64_t act_off(int64_t s, int c, int h, int w, int C, int H, int W) {
+    return ((((s * (C >> 3)) + (c >> 3)) * H + h) * (int64_t)W + w) * 8 + (c & 7);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -131,15 +140,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
             const int64_t iv = iv_lo + p;
             const int w = w0 + pcol - 1;
             gval[k] = a < g.na_i && pix < npix && iv >= 0 && iv < g.IVR && w >= 0 && w < g.W;
-            gsrc[k] = in + (gval[k] ? (iv * g.W + w) * (int64_t)g.Cin : 0);
-            gstep[k] = CK4;
+            // 4-channel chunk c: channel block c/2, half c%2 -> + (c>>1) * H*W*8 + (c&1)*4 floats
+            gsrc[k] = in + (gval[k] ? act_off(iv / g.H, 0, (int)(iv % g.H), w, g.Cin, g.H, g.W) : 0);
+            gstep[k] = -1;  // marks an activation slot (plane-strided)
             ldso[k] = B_FLOATS + (a < g.na_i ? a : 0) * 256;
         }
     }
+    const int64_t plane8 = (int64_t)g.H * g.W * 8;  // floats per channel block of one stream
     auto issue = [&](int chunk, int boff) {
 #pragma unroll
         for (int k = 0; k < MAXI; ++k) {
-            if (gval[k]) glds16(gsrc[k] + (int64_t)chunk * gstep[k], smem + boff + ldso[k]);
+            if (gval[k])
+                glds16(gsrc[k] + (gstep[k] >= 0 ? (int64_t)chunk * gstep[k] : (int64_t)(chunk >> 1) * plane8 + (chunk & 1) * 4),
+                       smem + boff + ldso[k]);
         }
     };
 
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
                 const int64_t s = vr / g.Heff;
                 const int oh = (int)(vr % g.Heff) >> 1, ow = (w0 >> 1) + gc;
                 ok[0] = vr < g.VR && ow < g.Wo;
-                obase[0] = ((s * g.Ho + oh) * g.Wo + ow) * g.Cout;
+                obase[0] = act_off(s, 0, oh, ow, g.Cout, g.Ho, g.Wo);
             } else {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {  // the two rows of the 2x2 register group
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
                     const int64_t s = v / g.H;
                     const int h = (int)(v % g.H);
                     ok[e] = v < g.VR;
-                    obase[e] = ((s * g.H + h) * g.W + (w0 + 2 * gc)) * g.Cout;
+                    obase[e] = act_off(s, 0, h, w0 + 2 * gc, g.Cout, g.H, g.W);
                 }
             }
 #pragma unroll
@@ -235,13 +248,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(acc[mb][nb][4 * q + e], sc, sh), 0.0f);
+                // channel co of the blocked layout: block co/8 is a plane of Ho*Wo (or H*W) pixels x 8
                 if (POOL) {
-                    if (ok[0]) out[obase[0] + co] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
+                    if (ok[0]) out[obase[0] + (int64_t)(co >> 3) * g.Ho * g.Wo * 8 + (co & 7)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int ww = w0 + 2 * gc + (e & 1);
-                        if (ok[e >> 1] && ww < g.W) out[obase[e >> 1] + (int64_t)(e & 1) * g.Cout + co] = y[e];
+                        if (ok[e >> 1] && ww < g.W) out[obase[e >> 1] + (int64_t)(co >> 3) * plane8 + (e & 1) * 8 + (co & 7)] = y[e];
                     }
                 }
             }
@@ -276,12 +290,17 @@ struct WinoGeom {
     int n_col_blocks, n_m_blocks;
     int Ho, Wo;
     int PR, pa_i;      // halo patch rows; patch LDS-DMA wave-instructions per chunk
+    long long *trace;  // TRACE instantiation only: s_memtime stamps of workgroup 100 (tools/wino_timeline.py)
 };
+// phase stamp: [chunk - 8][wave][slot] for chunks 8..39 of workgroup 100
+#define WINO_T(slot)                                                                       \
+    if (TRACE && blockIdx.x == 100 && chunk >= 8 && chunk < 40 && lane == 0)               \
+        g.trace[((chunk - 8) * 12 + wv) * 8 + (slot)] = __builtin_readcyclecounter();
 
 static constexpr int WK = 8;           // input channels per chunk
 static constexpr int WINO_THREADS = 768;
 
-template <int TTW, bool POOL>
+template <int TTW, bool POOL, bool TRACE = false>
 __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restrict__ in, const float *__restrict__ upk,
                                                              const float *__restrict__ scale,
                                                              const float *__restrict__ shift, float *__restrict__ out,
@@ -330,6 +349,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         const f32x4 *u_src = (const f32x4 *)(upk + (int64_t)n0 * WK) + (ptid >> 7) * ((int64_t)g.Cout * WK / 4) + (ptid & 127);
         const int64_t u_pos_stride = (int64_t)g.Cout * WK / 4, u_chunk_stride = 16 * u_pos_stride;
         const int npix2 = g.PR * PWC * 2;
+        const int64_t plane_f4 = (int64_t)g.H * g.W * 2;  // float4 per 8-channel plane of one stream
         const f32x4 *p_src[NPL];
         bool p_val[NPL];
 #pragma unroll
@@ -339,28 +359,50 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             const int64_t iv = iv_lo + pr;
             const int w = 2 * tc0 - 1 + pc;
             p_val[j] = q < npix2 && iv >= 0 && iv < (int64_t)g.S * g.H && w >= 0 && w < g.W;
-            p_src[j] = (const f32x4 *)(in + (p_val[j] ? (iv * g.W + w) * (int64_t)g.Cin : 0) + (q & 1) * 4);
+            p_src[j] = (const f32x4 *)(in + (p_val[j] ? act_off(iv / g.H, 0, (int)(iv % g.H), w, g.Cin, g.H, g.W) : 0) + (q & 1) * 4);
         }
         // (macros, not lambdas: captured arrays assigned under a condition end up in scratch memory;
         //  loads past the last chunk are clamped to it instead of being skipped)
-        f32x4 ru[NU], rp[NPL];   // native vectors: HIP's float4 struct is not promoted out of scratch here
-#define WINO_LOAD_U(CH)                                                                             \
+        // two register sets, each loaded two chunk periods before it is written to LDS (HBM latency under
+        // this load is ~2.5 us, longer than one period); native vectors: HIP's float4 struct arrays
+        // are not promoted out of scratch across barriers
+        f32x4 ruA[NU], rpA[NPL], ruB[NU], rpB[NPL];
+#define WINO_LOAD_U(ru, CH)                                                                         \
     {                                                                                               \
         const int64_t cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                   \
         _Pragma("unroll") for (int j = 0; j < NU; ++j) ru[j] = u_src[cc_ * u_chunk_stride + 2 * j * u_pos_stride]; \
     }
-#define WINO_LOAD_P(CH)                                                                             \
+#define WINO_LOAD_P(rp, CH)                                                                         \
     {                                                                                               \
         const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                       \
-        _Pragma("unroll") for (int j = 0; j < NPL; ++j) rp[j] = p_src[j][cc_ * (WK / 4)];            \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) rp[j] = p_src[j][cc_ * plane_f4];            \
     }
-#define WINO_WRITE_U(BOFF)                                                                          \
+#define WINO_WRITE_U(ru, BOFF)                                                                      \
     { _Pragma("unroll") for (int j = 0; j < NU; ++j) *(f32x4 *)(smem + (BOFF) + (ptid + 256 * j) * 4) = ru[j]; }
-#define WINO_WRITE_P(PBUF)                                                                          \
+#define WINO_WRITE_P(rp, PBUF)                                                                      \
     {                                                                                               \
         _Pragma("unroll") for (int j = 0; j < NPL; ++j)                                              \
             if (ptid + 256 * j < npix2)                                                              \
-                *(f32x4 *)((PBUF) + (ptid + 256 * j) * 4) = p_val[j] ? rp[j] : (f32x4)(0.0f);                  \
+                *(f32x4 *)((PBUF) + (ptid + 256 * j) * 4) = p_val[j] ? rp[j] : (f32x4)(0.0f);        \
+    }
+// one producer iteration: write the set loaded two periods ago (U(chunk+1), patch(chunk+2)), refill it
+// with U(chunk+3), patch(chunk+4), then transform patch(chunk+1) -> V(chunk+1)
+#define WINO_PRODUCE(ru, rp)                                                                        \
+    {                                                                                               \
+        const int cur = (chunk & 1) * BUF;                                                           \
+        WINO_T(0)                                                                                    \
+        __syncthreads(); /* X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free */    \
+        WINO_T(1)                                                                                    \
+        if (chunk + 1 < n_chunks) {                                                                  \
+            WINO_WRITE_U(ru, BUF - cur)                                                              \
+            WINO_WRITE_P(rp, patch0 + (chunk & 1) * pfl)                                             \
+            WINO_T(2)                                                                                \
+            WINO_LOAD_U(ru, chunk + 3)                                                               \
+            WINO_LOAD_P(rp, chunk + 4)                                                               \
+            WINO_T(3)                                                                                \
+            transform_store(patch0 + ((chunk + 1) & 1) * pfl, BUF - cur);                            \
+            WINO_T(4)                                                                                \
+        }                                                                                            \
     }
 
         // ---- transform items: thread = (tile, channel quad, row xi of B^T d B), two tiles per thread ----
@@ -403,28 +445,28 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         };
 
         // patch(k) lives in patch buffer k & 1; U(k), V(k) in U/V buffer k & 1.
-        WINO_LOAD_U(0)
-        WINO_LOAD_P(0)
+        WINO_LOAD_U(ruA, 0)
+        WINO_LOAD_P(rpA, 0)
+        WINO_LOAD_P(rpB, 1)
         __syncthreads();                     // B0 (kept for symmetry with the consumers)
-        WINO_WRITE_U(0)
-        WINO_WRITE_P(patch0)
-        WINO_LOAD_P(1)
-        WINO_WRITE_P(patch0 + pfl)
+        WINO_WRITE_U(ruA, 0)
+        WINO_WRITE_P(rpA, patch0)
+        WINO_WRITE_P(rpB, patch0 + pfl)
+        WINO_LOAD_U(ruA, 1)                  // set A: U(1), patch(2) -> written at chunk 0
+        WINO_LOAD_P(rpA, 2)
+        WINO_LOAD_U(ruB, 2)                  // set B: U(2), patch(3) -> written at chunk 1
+        WINO_LOAD_P(rpB, 3)
         __syncthreads();                     // B1: patch(0) visible to every producer wave
         transform_store(patch0, 0);          // V(0)
-        WINO_LOAD_U(1)
-        WINO_LOAD_P(2)
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            const int cur = (chunk & 1) * BUF;
-            __syncthreads();                 // X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free
+        for (int chunk = 0; chunk < n_chunks; chunk += 2) {
+            WINO_PRODUCE(ruA, rpA)
             if (chunk + 1 < n_chunks) {
-                WINO_WRITE_U(BUF - cur)                               // U(chunk+1), loaded in the previous period
-                WINO_WRITE_P(patch0 + (chunk & 1) * pfl)              // patch(chunk+2)
-                WINO_LOAD_U(chunk + 2)
-                WINO_LOAD_P(chunk + 3)
-                transform_store(patch0 + ((chunk + 1) & 1) * pfl, BUF - cur);  // patch(chunk+1) -> V(chunk+1)
+                ++chunk;
+                WINO_PRODUCE(ruB, rpB)
+                --chunk;
             }
         }
+#undef WINO_PRODUCE
 #undef WINO_LOAD_U
 #undef WINO_LOAD_P
 #undef WINO_WRITE_U
@@ -461,7 +503,9 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
     __syncthreads();  // B1 (producers: first patch landed)
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const float *sb = smem + (chunk & 1) * BUF;
+        WINO_T(0)
         __syncthreads();
+        WINO_T(1)
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             float4 av[2], bv[2];
@@ -482,6 +526,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
                 acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pp][1][1], 0, 0, 0);
             }
         }
+        WINO_T(2)
     }
 
     // ---- epilogue: exchange positions through LDS (all 128 KB), one half of the channels per pass:
@@ -530,12 +575,12 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
                 const int64_t s = vtr / g.TR;
                 const int tr = (int)(vtr % g.TR);
                 if (POOL) {
-                    out[((s * g.Ho + tr) * g.Wo + tc) * (int64_t)g.Cout + co] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
+                    out[act_off(s, co, tr, tc, g.Cout, g.Ho, g.Wo)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int hh = 2 * tr + (e >> 1), ww = 2 * tc + (e & 1);
-                        if (hh < g.H && ww < g.W) out[((s * g.H + hh) * g.W + ww) * (int64_t)g.Cout + co] = y[e];
+                        if (hh < g.H && ww < g.W) out[act_off(s, co, hh, ww, g.Cout, g.H, g.W)] = y[e];
                     }
                 }
             }
@@ -546,7 +591,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
 // ------------------------------------------------------------------------------------------------
 // conv_block1.conv1: one input channel (the log-mel image) -> 64 channels.  K = 9: no matrix
 // shape to speak of; direct, output-bandwidth bound (writes S*T*M*64 floats).
-// thread = (pixel slot, 4 output channels); 16 threads cover one pixel's 64 channels = 256 B.
+// thread = (pixel slot, 4 output channels); output in the channel-blocked layout (32 B per pixel per block).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in, const float *__restrict__ w /*[cout][9]*/,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
@@ -563,7 +608,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
         sh[c] = shift[cg * 4 + c];
     }
     const float *ip = in + (int64_t)s * n_pix_per_stream;
-    float *op = out + (int64_t)s * n_pix_per_stream * Cout;
+    float *op = out + (int64_t)s * n_pix_per_stream * Cout + (int64_t)(cg >> 1) * n_pix_per_stream * 8 + (cg & 1) * 4;  // NC8HW8
     for (int64_t p = (int64_t)blockIdx.x * pix_per_iter + ps; p < n_pix_per_stream; p += (int64_t)gridDim.x * pix_per_iter) {
         const int h = (int)(p / W), x = (int)(p % W);
         float v[9];
@@ -582,23 +627,23 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
             r[c] = fmaxf(fmaf(a, sc[c], sh[c]), 0.0f);
         }
         o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
-        *(float4 *)(op + p * Cout + cg * 4) = o;
+        *(float4 *)(op + p * 8) = o;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Pooling head (panns.py:262-266): mean over mel, then max over time + mean over time.
-// x (S, H, W, C) -> feat (S, C)
+// x (S, C/8, H, W, 8) -> feat (S, C)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_head(const float *__restrict__ x, float *__restrict__ feat, int H, int W, int C) {
     const int s = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const float *p = x + (int64_t)s * H * W * C + c;
+    const float *p = x + act_off(s, c, 0, 0, C, H, W);  // NC8HW8: pixel stride 8 within the channel block
     float mx = -INFINITY, sum = 0.0f;
     for (int h = 0; h < H; ++h) {
         float rs = 0.0f;
-        for (int w = 0; w < W; ++w) rs += p[((int64_t)h * W + w) * C];
+        for (int w = 0; w < W; ++w) rs += p[((int64_t)h * W + w) * 8];
         const float m = rs / (float)W;
         mx = fmaxf(mx, m);
         sum += m;
@@ -826,6 +871,8 @@ static int launch_conv_tw(const float *in, const float *wpk, const float *scale,
 }
 
 
+static long long *g_wino_trace = nullptr;  // stito_debug_wino_trace
+
 template <int TTW, bool POOL>
 static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t &blocks) {
     constexpr int TTH = 64 / TTW;
@@ -856,7 +903,8 @@ static int launch_wino(const float *in, const float *upk, const float *scale, co
     int64_t blocks;
     STITO_REQUIRE((wino_geometry<TTW, POOL>(c, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd): %dx%d map does not fit the LDS-resident halo patch", c.H, c.W);
-    auto kern = k_conv_wino<TTW, POOL>;
+    g.trace = g_wino_trace;
+    auto kern = g_wino_trace ? k_conv_wino<TTW, POOL, true> : k_conv_wino<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WINO_THREADS), lds, st, in, upk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
@@ -933,6 +981,11 @@ extern "C" int stito_bn_fold(const float *gamma_dev, const float *beta_dev, cons
 extern "C" int stito_transpose(const float *in_dev, int rows, int cols, float *out_dev, void *stream) {
     hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, in_dev, rows, cols, out_dev);
     STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+extern "C" int stito_debug_wino_trace(long long *buf_dev) {
+    g_wino_trace = buf_dev;
     return STITO_OK;
 }
 

@@ -202,8 +202,14 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
                      + shift.double()[None, :, None, None])
     if pool:
         ref = torch.nn.functional.avg_pool2d(ref, 2)
-    ref = ref.permute(0, 2, 3, 1).contiguous()  # NHWC
-    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    def blocked(t):  # (n, C, H, W) -> channel-blocked (n, C/8, H, W, 8); C == 1 stays (n, H, W)
+        n_, C_, H_, W_ = t.shape
+        if C_ == 1:
+            return t.reshape(n_, H_, W_).contiguous()
+        return t.reshape(n_, C_ // 8, 8, H_, W_).permute(0, 1, 3, 4, 2).contiguous()
+
+    ref = blocked(ref)
+    xd = blocked(x).to(dev)
     wd = w.contiguous().to(dev)
     if not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
         assert algo == 1, "the direct kernel must cover every Cnn14-shaped layer"

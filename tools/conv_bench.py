@@ -30,7 +30,7 @@ def main():
     ref_out = {}
     for li, r in enumerate(rows):
         g = torch.Generator(device="cpu").manual_seed(li)
-        x = torch.randn((a.streams, r["H"], r["W"], r["cin"]), generator=g).to(dev)
+        x = torch.randn((a.streams, r["cin"] // 8, r["H"], r["W"], 8), generator=g).to(dev)
         w = (torch.randn((r["cout"], r["cin"], 3, 3), generator=g) / np.sqrt(9 * r["cin"])).to(dev)
         sc = (0.5 + torch.rand(r["cout"], generator=g)).to(dev)
         sh = (0.1 * torch.randn(r["cout"], generator=g)).to(dev)
@@ -38,7 +38,7 @@ def main():
         for m in modes:
             packed = torch.empty(L.stito_cnn14_packed_conv_floats(r["cout"], r["cin"], m), device=dev)
             _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), r["cout"], r["cin"], m, _hip.ptr(packed), st))
-            out = torch.empty((a.streams, Ho, Wo, r["cout"]), device=dev)
+            out = torch.empty((a.streams, r["cout"] // 8, Ho, Wo, 8), device=dev)
             args = (_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), a.streams, r["H"], r["W"],
                     r["cin"], r["cout"], r["pool"], m, st)
             _hip.check(L.stito_conv3x3_bn_relu(*args))
