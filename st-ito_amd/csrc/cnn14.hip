@@ -42,6 +42,18 @@ struct ConvShape {
     int S, H, W, Cin, Cout;
 };
 
+// Same copy with everything but the per-lane byte offset on the scalar unit: global address =
+// sbase (SGPR pair, wave-uniform) + voff (32-bit per-lane offset), LDS base wave-uniform.  No VALU
+// instruction at all -- on a SIMD whose vector pipe is saturated by f32 MFMAs every VALU/VGPR-port
+// cycle of a co-resident wave is a cycle the MFMAs do not get.
+__device__ __forceinline__ void glds16_s(const float *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_conv3x3: 3x3 conv (pad 1) + per-channel scale/shift + ReLU (+ 2x2 average pool).
 //   * rows are tiled in "virtual row" space (all streams' output rows concatenated), so tiles
@@ -338,16 +350,18 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         // which stretches its ~150 instructions per chunk over more than a chunk period.
         __builtin_amdgcn_s_setprio(3);
         const int ptid = tid - 512;
-        // the row of zeros behind each patch buffer (write_p fills everything else, zeros included)
-        for (int i = ptid; i < 256; i += 256) { patch0[g.pa_i * 256 + i] = 0.0f; patch0[pfl + g.pa_i * 256 + i] = 0.0f; }
 
-        // ---- staging: U slab (16 x 64 x 8 floats per chunk, contiguous per position) and the halo patch
-        // go HBM/L2 -> registers -> LDS.  (LDS-DMA from only four waves per CU sustains too little
-        // bandwidth here: its in-flight window is small; ordinary loads pipeline two orders deeper.)
-        constexpr int NU = 8;   // float4 of U per producer thread per chunk
+        // ---- staging -----------------------------------------------------------------------------
+        // U slab (16 positions x 64 channels x 8 floats per chunk, 2 KB contiguous per position):
+        // LDS-DMA, 32 wave-instructions per chunk, 8 per producer wave, addressed from the scalar unit.
+        // Halo patch: HBM -> registers -> LDS (two register sets, loaded two periods ahead); pixels
+        // outside the map are never written: both patch buffers are zero-filled once.
+        constexpr int NU = 8;   // U wave-copies per producer wave per chunk
         constexpr int NPL = 4;  // float4 of patch per producer thread per chunk (upper bound)
-        const f32x4 *u_src = (const f32x4 *)(upk + (int64_t)n0 * WK) + (ptid >> 7) * ((int64_t)g.Cout * WK / 4) + (ptid & 127);
-        const int64_t u_pos_stride = (int64_t)g.Cout * WK / 4, u_chunk_stride = 16 * u_pos_stride;
+        const int pw = wv - 8;
+        const float *u_base = upk + (int64_t)n0 * WK;                       // wave-uniform
+        const int64_t u_pos_stride = (int64_t)g.Cout * WK, u_chunk_stride = 16 * u_pos_stride;  // floats
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;  // LDS byte address of smem
         const int npix2 = g.PR * PWC * 2;
         const int64_t plane_f4 = (int64_t)g.H * g.W * 2;  // float4 per 8-channel plane of one stream
         const f32x4 *p_src[NPL];
@@ -361,43 +375,42 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             p_val[j] = q < npix2 && iv >= 0 && iv < (int64_t)g.S * g.H && w >= 0 && w < g.W;
             p_src[j] = (const f32x4 *)(in + (p_val[j] ? act_off(iv / g.H, 0, (int)(iv % g.H), w, g.Cin, g.H, g.W) : 0) + (q & 1) * 4);
         }
-        // (macros, not lambdas: captured arrays assigned under a condition end up in scratch memory;
-        //  loads past the last chunk are clamped to it instead of being skipped)
+        for (int i = ptid; i < 2 * pfl; i += 256) patch0[i] = 0.0f;  // patch buffers + their zero rows
         // two register sets, each loaded two chunk periods before it is written to LDS (HBM latency under
         // this load is ~2.5 us, longer than one period); native vectors: HIP's float4 struct arrays
         // are not promoted out of scratch across barriers
-        f32x4 ruA[NU], rpA[NPL], ruB[NU], rpB[NPL];
-#define WINO_LOAD_U(ru, CH)                                                                         \
-    {                                                                                               \
-        const int64_t cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                   \
-        _Pragma("unroll") for (int j = 0; j < NU; ++j) ru[j] = u_src[cc_ * u_chunk_stride + 2 * j * u_pos_stride]; \
+        f32x4 rpA[NPL], rpB[NPL];
+#define WINO_COPY_U(CH, BOFF)                                                                       \
+    if ((CH) < n_chunks) {                                                                           \
+        _Pragma("unroll") for (int k = 0; k < NU; ++k) {                                             \
+            const int ii = pw * NU + k; /* wave-uniform: position ii/2, half ii%2 of its 2 KB */     \
+            glds16_s(u_base + (int64_t)(CH) * u_chunk_stride + (ii >> 1) * u_pos_stride + (ii & 1) * 256, \
+                     (unsigned)lane * 16u, lds0 + (unsigned)((BOFF) + (ii >> 1) * 64 * WK + (ii & 1) * 256) * 4u); \
+        }                                                                                            \
     }
 #define WINO_LOAD_P(rp, CH)                                                                         \
     {                                                                                               \
         const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                       \
         _Pragma("unroll") for (int j = 0; j < NPL; ++j) rp[j] = p_src[j][cc_ * plane_f4];            \
     }
-#define WINO_WRITE_U(ru, BOFF)                                                                      \
-    { _Pragma("unroll") for (int j = 0; j < NU; ++j) *(f32x4 *)(smem + (BOFF) + (ptid + 256 * j) * 4) = ru[j]; }
 #define WINO_WRITE_P(rp, PBUF)                                                                      \
     {                                                                                               \
         _Pragma("unroll") for (int j = 0; j < NPL; ++j)                                              \
-            if (ptid + 256 * j < npix2)                                                              \
-                *(f32x4 *)((PBUF) + (ptid + 256 * j) * 4) = p_val[j] ? rp[j] : (f32x4)(0.0f);        \
+            if (p_val[j]) *(f32x4 *)((PBUF) + (ptid + 256 * j) * 4) = rp[j];                         \
     }
-// one producer iteration: write the set loaded two periods ago (U(chunk+1), patch(chunk+2)), refill it
-// with U(chunk+3), patch(chunk+4), then transform patch(chunk+1) -> V(chunk+1)
-#define WINO_PRODUCE(ru, rp)                                                                        \
+// one producer iteration: start the U(chunk+1) copy, write the patch set loaded two periods ago
+// (patch(chunk+2)), refill it with patch(chunk+4), then transform patch(chunk+1) -> V(chunk+1)
+#define WINO_PRODUCE(rp)                                                                            \
     {                                                                                               \
         const int cur = (chunk & 1) * BUF;                                                           \
         WINO_T(0)                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own U(chunk) copies landed */            \
         __syncthreads(); /* X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free */    \
         WINO_T(1)                                                                                    \
         if (chunk + 1 < n_chunks) {                                                                  \
-            WINO_WRITE_U(ru, BUF - cur)                                                              \
+            WINO_COPY_U(chunk + 1, BUF - cur)                                                        \
             WINO_WRITE_P(rp, patch0 + (chunk & 1) * pfl)                                             \
             WINO_T(2)                                                                                \
-            WINO_LOAD_U(ru, chunk + 3)                                                               \
             WINO_LOAD_P(rp, chunk + 4)                                                               \
             WINO_T(3)                                                                                \
             transform_store(patch0 + ((chunk + 1) & 1) * pfl, BUF - cur);                            \
@@ -426,50 +439,43 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             // write the same nu then hit 4 different 32-B slots instead of one bank group
             vdst[it] = U_FLOATS + (xi * 4) * 64 * WK + ((tile + xi) & 63) * WK + p_quad * 4;
         }
-        auto f4fma = [](float s_, float4 b, float4 a) { return make_float4(fmaf(s_, b.x, a.x), fmaf(s_, b.y, a.y), fmaf(s_, b.z, a.z), fmaf(s_, b.w, a.w)); };
-        auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-        auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
         auto transform_store = [&](const float *pbuf, int v_boff) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                float4 T[4];
+                f32x4 T[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    T[j] = f4fma(sgn, *(const float4 *)(pbuf + rowB[it] + j * 8), *(const float4 *)(pbuf + rowA[it] + j * 8));
+                for (int j = 0; j < 4; ++j)  // native vector arithmetic -> v_pk_fma_f32 / v_pk_add_f32
+                    T[j] = *(const f32x4 *)(pbuf + rowA[it] + j * 8) + sgn * *(const f32x4 *)(pbuf + rowB[it] + j * 8);
                 float *vb = smem + v_boff + vdst[it];
-                *(float4 *)(vb + 0 * 64 * WK) = f4sub(T[0], T[2]);
-                *(float4 *)(vb + 1 * 64 * WK) = f4add(T[1], T[2]);
-                *(float4 *)(vb + 2 * 64 * WK) = f4sub(T[2], T[1]);
-                *(float4 *)(vb + 3 * 64 * WK) = f4sub(T[1], T[3]);
+                *(f32x4 *)(vb + 0 * 64 * WK) = T[0] - T[2];
+                *(f32x4 *)(vb + 1 * 64 * WK) = T[1] + T[2];
+                *(f32x4 *)(vb + 2 * 64 * WK) = T[2] - T[1];
+                *(f32x4 *)(vb + 3 * 64 * WK) = T[1] - T[3];
             }
         };
 
         // patch(k) lives in patch buffer k & 1; U(k), V(k) in U/V buffer k & 1.
-        WINO_LOAD_U(ruA, 0)
         WINO_LOAD_P(rpA, 0)
         WINO_LOAD_P(rpB, 1)
-        __syncthreads();                     // B0 (kept for symmetry with the consumers)
-        WINO_WRITE_U(ruA, 0)
+        __syncthreads();                     // B0: zero fill of the patch buffers complete
+        WINO_COPY_U(0, 0)
         WINO_WRITE_P(rpA, patch0)
         WINO_WRITE_P(rpB, patch0 + pfl)
-        WINO_LOAD_U(ruA, 1)                  // set A: U(1), patch(2) -> written at chunk 0
-        WINO_LOAD_P(rpA, 2)
-        WINO_LOAD_U(ruB, 2)                  // set B: U(2), patch(3) -> written at chunk 1
-        WINO_LOAD_P(rpB, 3)
+        WINO_LOAD_P(rpA, 2)                  // set A: patch(2) -> written at chunk 0
+        WINO_LOAD_P(rpB, 3)                  // set B: patch(3) -> written at chunk 1
         __syncthreads();                     // B1: patch(0) visible to every producer wave
         transform_store(patch0, 0);          // V(0)
         for (int chunk = 0; chunk < n_chunks; chunk += 2) {
-            WINO_PRODUCE(ruA, rpA)
+            WINO_PRODUCE(rpA)
             if (chunk + 1 < n_chunks) {
                 ++chunk;
-                WINO_PRODUCE(ruB, rpB)
+                WINO_PRODUCE(rpB)
                 --chunk;
             }
         }
 #undef WINO_PRODUCE
-#undef WINO_LOAD_U
+#undef WINO_COPY_U
 #undef WINO_LOAD_P
-#undef WINO_WRITE_U
 #undef WINO_WRITE_P
         // keep the barrier count of the consumers' epilogue
 #pragma unroll 1
