@@ -12,12 +12,16 @@ not available offline).  For N > 1 every GPU evaluates its own 256 candidates of
 population (weak scaling, configs[3] shape) and the fitness scalars are all-gathered over RCCL.
 
 The JSON line also carries
-  roofline     : the f32-MFMA conv kernel family (k_conv3x3), algorithmic FLOPs / measured time
-                 (HIP events on the launch stream, per layer) against the 157.3 TFLOP/s peak;
+  roofline     : the f32-MFMA conv kernel family (k_conv_wino / k_conv3x3): algorithmic FLOPs per
+                 launch / average launch duration, measured with HIP events recorded by the library
+                 on its launch stream around every conv launch of the TIMED steps
+                 (stito_conv_timing_enable/read), against the 157.3 TFLOP/s f32-MFMA peak; traffic =
+                 HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/);
   cpu_baseline : the CPU oracle (port of the reference path) timed on this box's host cores on
                  a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -64,9 +68,22 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-def measure_conv_roofline(model, n_streams, T, reps=3):
-    """Time every conv launch of the trunk with HIP events on the launch stream (torch's current
-    stream is the stream the C ABI launches on) and return the roofline object."""
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round1_g_conv_pmc_traffic.json")
+
+
+def pmc_traffic_per_launch(n_streams):
+    """HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the
+    same 11 launches at the same stream count), or None if no committed measurement matches."""
+    try:
+        d = json.load(open(PMC_TRAFFIC_JSON))
+    except OSError:
+        return None
+    return float(d["traffic_bytes_per_launch"]) if d.get("n_streams") == n_streams else None
+
+
+def conv_layer_times(model, n_streams, T, reps=3):
+    """Per-layer table (informational): every conv launch of the trunk timed on its own with HIP
+    events on the launch stream (torch's current stream is the stream the C ABI launches on)."""
     from st_ito import _hip
     L = _hip.lib()
     W, FE, _ = model._ensure()
@@ -99,16 +116,7 @@ def measure_conv_roofline(model, n_streams, T, reps=3):
         if r["cin"] % 8 == 0:
             mfma_flops += fl; mfma_ms += ms
         cur = out
-    achieved = mfma_flops / mfma_ms / 1e9
-    return {
-        "bound": "mfma", "kernel": "k_conv_wino<*> / k_conv3x3<*> (the 11 f32-MFMA 3x3-conv launches of one trunk pass; "
-        "achieved counts the direct-convolution FLOPs 2*9*cin*cout*H*W, so the Winograd F(2x2,3x3) kernel, which issues "
-        "16/36 of those MACs, can exceed 1.0 of the MFMA peak)",
-        "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-        "flops_per_launch_avg": mfma_flops / 11, "avg_launch_ms": round(mfma_ms / 11, 4),
-        "n_streams": n_streams, "layers": layers,
-    }
+    return layers, mfma_flops / mfma_ms / 1e9
 
 
 def cpu_baseline(n_samples, kinds, budget_s=12.0):
@@ -200,11 +208,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    timing = rank == 0 and not args.no_roofline
+    if timing:  # the library records HIP events around every MFMA conv launch of the timed steps
+        _hip.check(_hip.lib().stito_conv_timing_enable(1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    conv_ms, conv_launches = ctypes.c_double(0.0), ctypes.c_int(0)
+    if timing:
+        _hip.check(_hip.lib().stito_conv_timing_enable(0))
+        _hip.check(_hip.lib().stito_conv_timing_read(ctypes.byref(conv_ms), ctypes.byref(conv_launches)))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,11 +238,27 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             T = n // 1024 + 1
-            rl = measure_conv_roofline(model, model.max_streams_per_pass, T)
-            # algorithmic conv FLOPs of one step / measured step time (whole path, incl. DSP + front end)
+            # algorithmic conv FLOPs (direct-convolution count 2*9*cin*cout*H*W) of one step on this rank
             fl_step = sum(r["flops"] for r in conv_layer_table(T) if r["cin"] % 8 == 0) * 2 * args.pop_per_gpu
-            rl["end_to_end_frac"] = round(fl_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
-            out["roofline"] = rl
+            n_l = max(conv_launches.value, 1)
+            achieved = fl_step * args.steps / conv_ms.value / 1e9  # TFLOP/s over the timed region's conv launches
+            streams_per_launch = min(2 * args.pop_per_gpu, model.max_streams_per_pass)
+            layers, _ = conv_layer_times(model, streams_per_launch, T)
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": "k_conv_wino<*> / k_conv3x3<*>: the 11 f32-MFMA 3x3-conv launches of a trunk pass. achieved counts "
+                          "direct-convolution FLOPs (2*9*cin*cout*H*W); the Winograd F(2x2,3x3) kernel issues 16/36 of those "
+                          "MACs, so it can exceed 1.0 of the MFMA peak",
+                "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": pmc_traffic_per_launch(streams_per_launch), "traffic_unit": "HBM bytes per launch (PMC, "
+                "profiles/round1_g_conv_pmc_traffic.json)",
+                "flops_per_launch": fl_step * args.steps / n_l, "avg_launch_ms": round(conv_ms.value / n_l, 4),
+                "launches_timed": conv_launches.value, "n_streams": streams_per_launch,
+                # whole path (DSP + front end + trunk + host) against the same peak
+                "end_to_end_frac": round(fl_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "layers": layers,
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, kinds)
         print(json.dumps(out), flush=True)

@@ -182,6 +182,12 @@ int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, i
  * workgroup 100 records s_memtime stamps of 32 chunks x 12 waves x 8 phases (int64) into buf_dev;
  * NULL (default) restores the plain kernel.  See tools/wino_timeline.py. */
 int stito_debug_wino_trace(long long *buf_dev);
+/* Measurement aid (bench.py "roofline"): while enabled, stito_cnn14_forward brackets every f32-MFMA
+ * conv launch (cin % 8 == 0: 11 of the 12 convs) with hipEventRecord on the launch stream.
+ * stito_conv_timing_read waits for the recorded events, returns their summed elapsed time and the
+ * number of launches, and clears the list.  Not thread-safe (one host thread per GPU). */
+int stito_conv_timing_enable(int on);
+int stito_conv_timing_read(double *total_ms, int *n_launches);
 /* 1 if stito_conv3x3_bn_relu can run this shape with `algo`, else 0. */
 int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,

@@ -12,7 +12,7 @@ fetch_db, write_db, S = sys.argv[1], sys.argv[2], int(sys.argv[3])
 
 def per_dispatch(path, counter):
     cur = sqlite3.connect(path).cursor()
-    return cur.execute("select name, counter_value, duration from pmc_events where counter_name=? and name like '%k_conv3x3%' "
+    return cur.execute("select name, counter_value, duration from pmc_events where counter_name=? and (name like '%k_conv3x3%' or name like '%k_conv_wino%') "
                        "order by dispatch_id", (counter,)).fetchall()
 
 
@@ -28,7 +28,7 @@ for b in range(6):
         cin = (chans[b - 1] if b else 1) if j == 0 else chans[b]
         cout = chans[b]
         pool = j == 1 and b < 5
-        if cin % 4 == 0:
+        if cin % 8 == 0:
             Ho, Wo = (H // 2, W // 2) if pool else (H, W)
             alg = 4.0 * (S * H * W * cin + S * Ho * Wo * cout + 9 * cin * cout)
             layers.append((f"{H}x{W} {cin}->{cout}{' pool' if pool else ''}", alg, 2.0 * 9 * cin * cout * H * W * S))
@@ -39,7 +39,14 @@ tf = tw = ta = 0.0
 for i, (name, alg, fl) in enumerate(layers):
     fe = f[2 * i + 1][1] * 1024 * 2 / 1e9
     wr = w[2 * i + 1][1] * 1024 / 1e9
+    kern = "wino" if "wino" in f[2 * i + 1][0] else "direct"
+    name = f"{name} [{kern}]"
     print(f"{name:26s} {fe:12.3f} {wr:9.3f} {fe + wr:10.3f} {alg / 1e9:14.3f} {(fe + wr) / (alg / 1e9):6.2f} {fl / ((fe + wr) * 1e9):7.0f}")
     tf += fe; tw += wr; ta += alg / 1e9
 print(f"{'total (11 launches)':26s} {tf:12.3f} {tw:9.3f} {tf + tw:10.3f} {ta:14.3f} {(tf + tw) / ta:6.2f}")
 print(f"per launch average: traffic {1e3 * (tf + tw) / 11:.1f} MB, algorithmic {1e3 * ta / 11:.1f} MB  (n_streams = {S})")
+if len(sys.argv) > 4:
+    import json
+    json.dump({"n_streams": S, "launches": 11, "fetch_GB_x2": tf, "write_GB": tw, "traffic_GB": tf + tw, "algorithmic_GB": ta,
+               "traffic_bytes_per_launch": (tf + tw) * 1e9 / 11, "algorithmic_bytes_per_launch": ta * 1e9 / 11},
+              open(sys.argv[4], "w"), indent=1)

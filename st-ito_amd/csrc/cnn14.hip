@@ -22,6 +22,9 @@
 // happen in registers.  Details of the data movement are at k_conv3x3.
 #include "common.h"
 
+#include <utility>
+#include <vector>
+
 namespace stito {
 
 // Activation layout: channel-blocked NC8HW8 -- element (stream s, channel c, row h, column w) of a map
@@ -1048,6 +1051,35 @@ extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int 
     return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + 256;
 }
 
+// ---- optional launch timing for bench.py: HIP events on the launch stream around the MFMA convs ----
+namespace {
+struct ConvTiming {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;  // created on demand, reused
+    size_t used = 0;
+} g_conv_timing;
+}  // namespace
+
+extern "C" int stito_conv_timing_enable(int on) {
+    g_conv_timing.on = on != 0;
+    return STITO_OK;
+}
+
+extern "C" int stito_conv_timing_read(double *total_ms, int *n_launches) {
+    STITO_REQUIRE(total_ms != nullptr && n_launches != nullptr, STITO_E_INVALID, "null output");
+    double tot = 0.0;
+    for (size_t i = 0; i < g_conv_timing.used; ++i) {
+        float ms = 0.f;
+        STITO_HIP_CHECK(hipEventSynchronize(g_conv_timing.pool[i].second));
+        STITO_HIP_CHECK(hipEventElapsedTime(&ms, g_conv_timing.pool[i].first, g_conv_timing.pool[i].second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = (int)g_conv_timing.used;
+    g_conv_timing.used = 0;
+    return STITO_OK;
+}
+
 extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, int n_cand, int channels,
                                    int64_t n_frames, float *mid_dev, float *side_dev, void *workspace_dev,
                                    size_t workspace_bytes, void *stream) {
@@ -1081,10 +1113,21 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
             // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
             const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, STITO_CONV_WINOGRAD);
+            const bool timed = g_conv_timing.on && ci % 8 == 0;
+            if (timed) {
+                if (g_conv_timing.used == g_conv_timing.pool.size()) {
+                    hipEvent_t e0, e1;
+                    STITO_HIP_CHECK(hipEventCreate(&e0));
+                    STITO_HIP_CHECK(hipEventCreate(&e1));
+                    g_conv_timing.pool.emplace_back(e0, e1);
+                }
+                STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
+            }
             const int rc = stito_conv3x3_bn_relu(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
                                                  w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
                                                  wino ? STITO_CONV_WINOGRAD : STITO_CONV_DIRECT, stream);
             if (rc) return rc;
+            if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
         }
         cur = actB;
     }

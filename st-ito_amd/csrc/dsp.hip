@@ -301,27 +301,40 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
 // ------------------------------------------------------------------------------------------------
 // Compressor: juce::dsp::Compressor<float> (peak ballistics + VCA), effects.py:891-897
 // ------------------------------------------------------------------------------------------------
-static constexpr int CE_T = 128;           // samples per tile
-static constexpr int CE_LD = CE_T + 4;     // LDS row stride (16-B aligned rows, conflict-free b128 column walks)
+static constexpr int CE_T = 64;            // samples per tile
+static constexpr int CE_LD = 2 * CE_T + 4; // LDS row stride in floats: CE_T (a, r) pairs (16-B aligned rows,
+                                           // conflict-free b128 column walks)
 static constexpr int CE_THREADS = 256;     // wave 0: recurrence; waves 1-3: global <-> LDS movers
 static constexpr int CE_MOVERS = CE_THREADS - 64;
 static constexpr int CE_SLOTS = 3;         // LDS ring: tile being stored / computed / filled
-static constexpr int CE_NIT = (64 * (CE_T / 4) + CE_MOVERS - 1) / CE_MOVERS;  // float4 items per mover per tile
+static constexpr int CE_COLS = CE_T / 4;   // float4 columns of a tile row
+static constexpr int CE_RSTEP = CE_MOVERS / CE_COLS;             // rows between a mover's items (12)
+static constexpr int CE_NIT = (64 + CE_RSTEP - 1) / CE_RSTEP;    // float4 items per mover per tile (6)
 
-__device__ __forceinline__ float env_step(float x, float &yold, float cat, float crl) {
-    const float v = fabsf(x), d = yold - v;
-    const float ya = fmaf(cat, d, v), yr = fmaf(crl, d, v);
-    yold = (d < 0.0f) ? ya : yr;  // v > yold  <=>  d < 0
-    return yold;
+typedef float ce_f2 __attribute__((ext_vector_type(2)));
+typedef float ce_f4 __attribute__((ext_vector_type(4)));
+
+// One step of the switching one-pole in "max of two affine maps" form.  The reference form is
+//     y' = v + c (y - v),  c = (v > y) ? c_att : c_rel,  v = |x|                       (effects.py:891-897)
+// Both candidates are affine in y and differ by (c_att - c_rel)(y - v), so for c_att <= c_rel the
+// selected one is the larger: y' = max(c_att y + (1-c_att) v, c_rel y + (1-c_rel) v); for
+// c_att > c_rel it is the smaller, which is the same max applied to z = -y.  With
+// (a, r) = s ((1-c_att) v, (1-c_rel) v), s = +-1, precomputed off the critical path the serial wave
+// issues one v_pk_fma_f32 and one v_max_f32 per sample (a single wave issues a VALU instruction
+// every ~7 cycles whether or not it depends on the previous one -- tools/ubench/env_chain.hip --
+// so the instruction count, not the dependency depth, sets the time per sample).  env = |z|.
+__device__ __forceinline__ float env_step(ce_f2 c2, float z, ce_f2 ar) {
+    const ce_f2 t = __builtin_elementwise_fma(c2, (ce_f2){z, z}, ar);
+    return fmaxf(t.x, t.y);
 }
 
-// envelope: env = v + cte*(env_prev - v), cte = v > env_prev ? attack : release.
 // The recurrence is serial in time (a switching one-pole is not associative), so the time axis
 // cannot be split; what can be done is to make the serial wave do nothing but the recurrence and
 // to keep HBM latency off its critical path.  One workgroup = 64 streams: lane l of wave 0 owns
-// stream l and rewrites its row of an LDS tile in place (x -> env, 4 samples per ds_read_b128);
-// waves 1-3 are movers: tile j+3 is in flight HBM -> registers (two register sets), tile j+1 is
-// being written to the ring, tile j-1 is being stored -- one barrier per 128 samples.
+// stream l and walks its row of an LDS tile ((a, r) pairs in, z out over the already-consumed head
+// of the same row, 4 samples per pair of ds_read_b128); waves 1-3 are movers: tile j+3 is in flight
+// HBM -> registers (two register sets), tile j+1 is being expanded to (a, r) pairs in the ring,
+// tile j-1 is being stored as |z| -- one barrier per 64 samples.
 template <bool VEC>
 __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
                                                           int C, int64_t L, int S, const double *__restrict__ coef) {
@@ -329,39 +342,47 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
     float *ring = ce_smem;                                                       // [CE_SLOTS][64][CE_LD]
     const float **row_in = (const float **)(ce_smem + CE_SLOTS * 64 * CE_LD);   // [64]
     float **row_out = (float **)(row_in + 64);                                   // [64]
+    float *row_sa = (float *)(row_out + 64), *row_sr = row_sa + 64;              // [64] each
 
     const int tid = threadIdx.x;
     const int s0 = blockIdx.x * 64;
     const int nrows = min(64, S - s0);
-    float cat = 0.f, crl = 0.f;
+    ce_f2 c2 = {0.f, 0.f};
     if (tid < 64) {
         const int s = s0 + (tid < nrows ? tid : 0);
         const int cand = s / C, ch = s % C;
         row_in[tid] = in_ptr(in, cand, ch);
         row_out[tid] = env + (int64_t)cand * cand_stride + (int64_t)ch * L;
         const double *cf = coef + (int64_t)cand * COEF_STRIDE;
-        cat = (float)cf[3];
-        crl = (float)cf[4];
+        const float cat = (float)cf[3], crl = (float)cf[4];
+        const float sg = cat <= crl ? 1.0f : -1.0f;
+        c2 = (ce_f2){cat, crl};
+        row_sa[tid] = sg * (1.0f - cat);
+        row_sr[tid] = sg * (1.0f - crl);
     }
     __syncthreads();
     const int64_t ntiles = (L + CE_T - 1) / CE_T;
     const int m = tid - 64;  // mover index
-    float yold = 0.0f;
+    float z = 0.0f;
 
-    if (!VEC) {  // unaligned fallback: synchronous scalar tiles (any L / base alignment)
+    if (!VEC) {  // unaligned fallback: synchronous scalar tiles (any L / base alignment), same arithmetic
         for (int64_t k = 0; k < ntiles; ++k) {
             const int64_t t0 = k * CE_T;
             for (int i = tid; i < 64 * CE_T; i += CE_THREADS) {
                 const int r = i / CE_T, j = i % CE_T;
-                ring[r * CE_LD + j] = (r < nrows && t0 + j < L) ? row_in[r][t0 + j] : 0.0f;
+                const float v = (r < nrows && t0 + j < L) ? fabsf(row_in[r][t0 + j]) : 0.0f;
+                *(ce_f2 *)(ring + r * CE_LD + 2 * j) = (ce_f2){row_sa[r] * v, row_sr[r] * v};
             }
             __syncthreads();
             if (tid < 64)
-                for (int j = 0; j < CE_T; ++j) ring[tid * CE_LD + j] = env_step(ring[tid * CE_LD + j], yold, cat, crl);
+                for (int j = 0; j < CE_T; ++j) {
+                    z = env_step(c2, z, *(const ce_f2 *)(ring + tid * CE_LD + 2 * j));
+                    ring[tid * CE_LD + j] = z;  // slot j <= 2j: already consumed
+                }
             __syncthreads();
             for (int i = tid; i < 64 * CE_T; i += CE_THREADS) {
                 const int r = i / CE_T, j = i % CE_T;
-                if (r < nrows && t0 + j < L) row_out[r][t0 + j] = ring[r * CE_LD + j];
+                if (r < nrows && t0 + j < L) row_out[r][t0 + j] = fabsf(ring[r * CE_LD + j]);
             }
             __syncthreads();
         }
@@ -369,23 +390,26 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
     }
 
     // every mover thread serves the same (row, float4 column) items in every tile: column
-    // q = m % 32, rows m / 32 + 6u (CE_MOVERS = 6 * 32).  Pointers are kept in registers as
+    // q = m % 16, rows m / 16 + 12u (CE_MOVERS = 12 * 16).  Pointers are kept in registers as
     // global-address-space pointers (the row tables in LDS hold generic pointers).
-    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef ce_f4 f4;
     typedef const __attribute__((address_space(1))) f4 *gsrc_t;
     typedef __attribute__((address_space(1))) f4 *gdst_t;
     gsrc_t gsrc[CE_NIT];
     gdst_t gdst[CE_NIT];
+    float sa[CE_NIT], sr[CE_NIT];
     bool ok[CE_NIT], inr[CE_NIT];
-    const int mq = 4 * (m & 31), mr0 = m >> 5;
-    const int lbase = mr0 * CE_LD + mq;  // + u * 6 * CE_LD
+    const int mq = 4 * (m & (CE_COLS - 1)), mr0 = m / CE_COLS;
+    const int lbase = mr0 * CE_LD;  // + u * CE_RSTEP * CE_LD; pairs at + 2 mq, results at + mq
 #pragma unroll
     for (int u = 0; u < CE_NIT; ++u) {
-        const int r = mr0 + 6 * u;
+        const int r = mr0 + CE_RSTEP * u;
         inr[u] = tid >= 64 && r < 64;
         ok[u] = inr[u] && r < nrows;
         gsrc[u] = (gsrc_t)(row_in[r & 63]);
         gdst[u] = (gdst_t)(row_out[r & 63]);
+        sa[u] = row_sa[r & 63];
+        sr[u] = row_sr[r & 63];
     }
     f4 setA[CE_NIT], setB[CE_NIT], vst[CE_NIT];
 
@@ -400,31 +424,42 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
     }
 #define CE_LWRITE(SET, K)                                                                     \
     {                                                                                         \
-        float *dst_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase;                       \
+        float *dst_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase + 2 * mq;              \
         const bool in_ = (int64_t)(K) * CE_T + mq + 3 < L; /* masked here, not at load time */ \
-        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            if (inr[u]) *(f4 *)(dst_ + u * 6 * CE_LD) = (ok[u] && in_) ? SET[u] : (f4)(0.0f);  \
+        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u) if (inr[u]) {                       \
+            const f4 x_ = (ok[u] && in_) ? SET[u] : (f4)(0.0f);                                \
+            const f4 v_ = {fabsf(x_.x), fabsf(x_.y), fabsf(x_.z), fabsf(x_.w)};                \
+            float *d_ = dst_ + u * CE_RSTEP * CE_LD;                                           \
+            *(f4 *)d_ = (f4){sa[u] * v_.x, sr[u] * v_.x, sa[u] * v_.y, sr[u] * v_.y};          \
+            *(f4 *)(d_ + 4) = (f4){sa[u] * v_.z, sr[u] * v_.z, sa[u] * v_.w, sr[u] * v_.w};    \
+        }                                                                                     \
     }
 #define CE_GSTORE(K)                                                                          \
     {                                                                                         \
-        const float *src_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase;                 \
+        const float *src_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase + mq;            \
         const int64_t t0_ = (int64_t)(K) * CE_T + mq;                                          \
         _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            vst[u] = *(const f4 *)(src_ + (inr[u] ? u * 6 * CE_LD : 0));                       \
+            vst[u] = *(const f4 *)(src_ + (inr[u] ? u * CE_RSTEP * CE_LD : 0));                \
         _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            if (ok[u] && t0_ + 3 < L) gdst[u][t0_ >> 2] = vst[u];                              \
+            if (ok[u] && t0_ + 3 < L)                                                          \
+                gdst[u][t0_ >> 2] = (f4){fabsf(vst[u].x), fabsf(vst[u].y), fabsf(vst[u].z), fabsf(vst[u].w)}; \
     }
     auto serial_tile = [&](int64_t k) {
         float *row = ring + (int)(k % CE_SLOTS) * 64 * CE_LD + tid * CE_LD;
-#pragma unroll 4
-        for (int j = 0; j < CE_T; j += 4) {
-            const float4 x4 = *(const float4 *)(row + j);
-            float4 e4;
-            e4.x = env_step(x4.x, yold, cat, crl);
-            e4.y = env_step(x4.y, yold, cat, crl);
-            e4.z = env_step(x4.z, yold, cat, crl);
-            e4.w = env_step(x4.w, yold, cat, crl);
-            *(float4 *)(row + j) = e4;
+        f4 n0 = *(const f4 *)row, n1 = *(const f4 *)(row + 4);
+#pragma unroll
+        for (int g = 0; g < CE_T / 4; ++g) {  // the next group's pairs are read under this group's chain
+            const f4 q0 = n0, q1 = n1;
+            if (g + 1 < CE_T / 4) {
+                n0 = *(const f4 *)(row + 8 * (g + 1));
+                n1 = *(const f4 *)(row + 8 * (g + 1) + 4);
+            }
+            f4 e;
+            e.x = z = env_step(c2, z, (ce_f2){q0.x, q0.y});
+            e.y = z = env_step(c2, z, (ce_f2){q0.z, q0.w});
+            e.z = z = env_step(c2, z, (ce_f2){q1.x, q1.y});
+            e.w = z = env_step(c2, z, (ce_f2){q1.z, q1.w});
+            *(f4 *)(row + 4 * g) = e;  // floats [4g, 4g+4) held pairs 2g, 2g+1: consumed (this group or earlier)
         }
     };
 
@@ -859,7 +894,7 @@ extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, con
                 break;
             case STITO_FX_COMPRESSOR:
             {
-                const size_t lds = (size_t)CE_SLOTS * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *);
+                const size_t lds = (size_t)CE_SLOTS * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *) + 128 * sizeof(float);
                 // float4 rows need 16-B aligned stream starts: every stream offset is a multiple of L
                 const bool vec = (L % 4 == 0) && (((uintptr_t)in.base & 15) == 0) && (((uintptr_t)envbuf & 15) == 0);
                 auto kern = vec ? k_comp_env<true> : k_comp_env<false>;

@@ -74,6 +74,8 @@ SIGNATURES = {
     "stito_cnn14_forward": (c_int, [POINTER(Cnn14Weights), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
     "stito_debug_wino_trace": (c_int, [c_void_p]),
+    "stito_conv_timing_enable": (c_int, [c_int]),
+    "stito_conv_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),

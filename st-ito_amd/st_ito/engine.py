@@ -8,6 +8,7 @@ and the cosine loss in run_es.evaluate (st_ito/style_transfer.py:504-573).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -175,6 +176,7 @@ class PopulationEvaluator:
         self.tside = target_embeds["side"].to(self.device, torch.float32).contiguous().view(-1)
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._streams = None
 
     def _input(self, random_crop: bool, rng) -> torch.Tensor:
         """Length policy of style_transfer.py:505-518."""
@@ -187,27 +189,68 @@ class PopulationEvaluator:
             return x
         return torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
 
+    def _groups(self, P: int, c_out: int) -> int:
+        """Number of candidate groups pipelined over two HIP streams (STITO_PIPELINE_GROUPS, default
+        1 = off).  Measured on MI355X at pop 256 x 10 s stereo: 111.1 ms/step with 1 group, 113.4
+        with 2, 117.2 with 3 -- the render of group g+1 does overlap the trunk of group g, but its
+        time-serial kernels (compressor envelope, reverb) do not shrink with the group, their
+        workgroups pin whole CUs away from the MFMA trunk, and the trunk loses efficiency at half the
+        batch.  Kept as an option for populations much larger than one trunk pass."""
+        g = int(os.environ.get("STITO_PIPELINE_GROUPS", "1"))
+        return max(1, min(g, P))
+
     def evaluate(self, W, random_crop: bool = False, rng=np.random, want_audio: bool = False, dropout: float = 0.0):
+        """Fitness of every row of W.  With more than one group (see _groups) the population is
+        software-pipelined over two HIP streams: while group g runs log-mel + Cnn14 + loss on the
+        embed stream, group g+1 runs its effect chain on the render stream.  A candidate's result
+        does not depend on the grouping."""
+        if dropout > 0.0:
+            raise NotImplementedError("embedding dropout inside evaluate is not built (run_optim default is 0.0)")
         Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
         if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
             raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
         x = self._input(random_crop, rng)
         P = Wt.shape[0]
-        step = self.max_cand or P
-        losses, mids, sides, audios = [], [], [], []
-        for p0 in range(0, P, step):
-            Wc = Wt[p0:p0 + step].contiguous()
-            audio, peaks = render_population(self.plugins, x, Wc, self.sample_rate, chain=self.chain)
-            mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
-            if dropout > 0.0:
-                raise NotImplementedError("embedding dropout inside evaluate is not built (run_optim default is 0.0)")
-            loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
-            _hip.check(_hip.lib().stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1],
-                                                   _hip.ptr(self.tmid), _hip.ptr(self.tside), _hip.ptr(loss),
-                                                   _hip.ptr(self.flags), _hip.stream_ptr()))
+        c_out = _hip.lib().stito_chain_out_channels(self.chain[0], len(self.plugins), x.shape[0])
+        G = self._groups(P, c_out)
+        step = (P + G - 1) // G
+        if self.max_cand:
+            step = min(step, self.max_cand)
+        bounds = [(p0, min(P, p0 + step)) for p0 in range(0, P, step)]
+        L = _hip.lib()
+        main = torch.cuda.current_stream(self.device)
+        pipelined = len(bounds) > 1
+        if pipelined:
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            s_render, s_embed = self._streams
+            s_render.wait_stream(main)
+            s_embed.wait_stream(main)
+        else:
+            s_render = s_embed = main
+        losses, mids, sides, audios, keep = [], [], [], [], []
+        for p0, p1 in bounds:
+            with torch.cuda.stream(s_render):
+                Wc = Wt[p0:p1].contiguous()
+                audio, peaks = render_population(self.plugins, x, Wc, self.sample_rate, chain=self.chain)
+                rendered = torch.cuda.Event()
+                rendered.record(s_render)
+            with torch.cuda.stream(s_embed):
+                s_embed.wait_event(rendered)
+                mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
+                loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
+                _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1],
+                                              _hip.ptr(self.tmid), _hip.ptr(self.tside), _hip.ptr(loss),
+                                              _hip.ptr(self.flags), _hip.stream_ptr()))
+                if want_audio:
+                    audios.append(normalize_audio_(audio, peaks))
             losses.append(loss); mids.append(mid); sides.append(side)
-            if want_audio:
-                audios.append(normalize_audio_(audio, peaks))
-        loss = torch.cat(losses)
+            keep.append((Wc, audio, peaks))  # alive until both streams have been joined
+        if pipelined:
+            main.wait_stream(s_render)
+            main.wait_stream(s_embed)
+        loss = torch.cat(losses) if len(losses) > 1 else losses[0]
         embeds = {"mid": torch.cat(mids), "side": torch.cat(sides)}
-        return loss, embeds, (torch.cat(audios) if want_audio else None)
+        audio_out = torch.cat(audios) if want_audio else None
+        del keep  # side-stream buffers: reused only after the next evaluate() has made that stream wait on main
+        return loss, embeds, audio_out

@@ -130,3 +130,29 @@ def test_fitness_independent_of_batch_position_and_size(dev):
     one = np.array([ev.evaluate(W[i:i + 1])[0].item() for i in range(6)], dtype=np.float32)
     np.testing.assert_array_equal(full, rev)
     np.testing.assert_array_equal(full, one)
+
+
+def test_stream_pipelined_groups_give_identical_fitness(dev, monkeypatch):
+    """STITO_PIPELINE_GROUPS > 1 (render of group g+1 overlapped with the trunk of group g on two
+    HIP streams) must return bitwise the fitness, embeddings and audio of the single-group path."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    x = O.synth_audio(31, 2, 90000)[None]
+    tgt = O.synth_audio(32, 2, 90000)[None]
+    pp = E.make_plugins("bench5")
+    te = get_param_embeds(tgt, pm, SR)
+    ev = PopulationEvaluator(x, SR, pp, pm, te)
+    W = np.random.default_rng(1).random((7, 45))
+    monkeypatch.setenv("STITO_PIPELINE_GROUPS", "1")
+    l1, e1, a1 = ev.evaluate(W, want_audio=True)
+    for g in ("2", "3"):
+        monkeypatch.setenv("STITO_PIPELINE_GROUPS", g)
+        for _ in range(2):  # second call re-uses the side streams and their cached buffers
+            lg, eg, ag = ev.evaluate(W, want_audio=True)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(l1.cpu().numpy(), lg.cpu().numpy())
+            np.testing.assert_array_equal(e1["mid"].cpu().numpy(), eg["mid"].cpu().numpy())
+            np.testing.assert_array_equal(e1["side"].cpu().numpy(), eg["side"].cpu().numpy())
+            np.testing.assert_array_equal(a1.cpu().numpy(), ag.cpu().numpy())
