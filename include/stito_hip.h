@@ -91,6 +91,15 @@ int stito_render_population(const stito_fx_desc *chain, int n_fx, const float *x
                             double sample_rate, float *audio_dev, float *peaks_dev, void *workspace_dev,
                             size_t workspace_bytes, void *stream);
 
+/* Multi-pair batch (BASELINE.json configs[2]; an extension: the reference's evaluate assumes one
+ * input, style_transfer.py:520, and eval_pst.py:691-765 walks its examples serially).
+ *   x_dev  (n_inputs, in_channels, n_samples); pop % n_inputs == 0; candidate p reads input
+ *   p / (pop / n_inputs).  Everything else as stito_render_population (= the n_inputs == 1 case). */
+int stito_render_population_multi(const stito_fx_desc *chain, int n_fx, const float *x_dev, int n_inputs,
+                                  int in_channels, int64_t n_samples, const double *w_dev, int pop, int n_dims,
+                                  double sample_rate, float *audio_dev, float *peaks_dev, void *workspace_dev,
+                                  size_t workspace_bytes, void *stream);
+
 /* max|x| per candidate over (channels, n_samples). */
 int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples, float *peaks_dev,
                void *stream);

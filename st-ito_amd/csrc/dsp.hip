@@ -26,13 +26,16 @@ static constexpr int COEF_STRIDE = 32;  // doubles per (effect, candidate)
 
 struct InView {  // where a stage reads its input from
     const float *base;
-    int64_t cand_stride;  // 0: the shared input x
+    int64_t cand_stride;  // 0: an input x shared by a group of candidates
     int64_t ch_stride;
     int in_ch;  // channel c reads channel c % in_ch (mono -> stereo up-mix, style_transfer.py:94-95)
+    int group = 1 << 30;       // candidates per input (multi-pair batches: candidate p reads input p / group)
+    int64_t group_stride = 0;  // floats between consecutive inputs
 };
 
 __device__ __forceinline__ const float *in_ptr(const InView &v, int cand, int ch) {
-    return v.base + (int64_t)cand * v.cand_stride + (int64_t)(ch % v.in_ch) * v.ch_stride;
+    return v.base + (int64_t)cand * v.cand_stride + (int64_t)(cand / v.group) * v.group_stride +
+           (int64_t)(ch % v.in_ch) * v.ch_stride;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,7 +846,17 @@ extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, con
                                        int64_t n_samples, const double *w_dev, int pop, int n_dims,
                                        double sample_rate, float *audio_dev, float *peaks_dev,
                                        void *workspace_dev, size_t workspace_bytes, void *stream) {
+    return stito_render_population_multi(chain, n_fx, x_dev, 1, in_channels, n_samples, w_dev, pop, n_dims, sample_rate,
+                                         audio_dev, peaks_dev, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_fx, const float *x_dev, int n_inputs,
+                                             int in_channels, int64_t n_samples, const double *w_dev, int pop,
+                                             int n_dims, double sample_rate, float *audio_dev, float *peaks_dev,
+                                             void *workspace_dev, size_t workspace_bytes, void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    STITO_REQUIRE(n_inputs >= 1 && pop % n_inputs == 0, STITO_E_INVALID,
+                  "population %d is not a multiple of the number of inputs %d", pop, n_inputs);
     STITO_REQUIRE(n_fx >= 0 && n_fx <= 16, STITO_E_INVALID, "chain length %d not in [0,16]", n_fx);
     STITO_REQUIRE(in_channels == 1 || in_channels == 2, STITO_E_INVALID, "in_channels must be 1 or 2, got %d", in_channels);
     STITO_REQUIRE(pop > 0 && n_samples > 0, STITO_E_INVALID, "empty population or audio");
@@ -875,7 +888,7 @@ extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, con
         STITO_LAUNCH_CHECK();
     }
 
-    InView in{x_dev, 0, L, in_channels};
+    InView in{x_dev, 0, L, in_channels, pop / n_inputs, (int64_t)in_channels * L};
     int C = in_channels;
     bool in_buffer = false;
     for (int i = 0; i < n_fx; ++i) {

@@ -62,6 +62,8 @@ SIGNATURES = {
     "stito_render_workspace_bytes": (c_size_t, [POINTER(FxDesc), c_int, c_int, c_int64, c_int]),
     "stito_render_population": (c_int, [POINTER(FxDesc), c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_int,
                                         c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "stito_render_population_multi": (c_int, [POINTER(FxDesc), c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_int,
+                                              c_int, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "stito_peak": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "stito_normalize_audio": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "stito_num_frames": (c_int64, [c_int64, c_int]),

@@ -90,28 +90,31 @@ _WS = _Workspace()
 
 def render_population(plugins: Dict[str, dict], x: torch.Tensor, W: torch.Tensor, sample_rate: float,
                       chain=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """x (C, L) float32 on the GPU, W (P, D) float64 on the GPU -> (audio (P, C', L) before peak
-    normalisation, peaks (P,))."""
+    """x (C, L) float32 on the GPU -- or (B, C, L): B inputs, candidate p reads input p // (P // B) --
+    W (P, D) float64 on the GPU -> (audio (P, C', L) before peak normalisation, peaks (P,))."""
     _hip.require_gpu()
     L = _hip.lib()
     descs, ndims = chain if chain is not None else compile_chain(plugins)
     n_fx = len(plugins)
-    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 3)
     assert W.is_cuda and W.dtype == torch.float64 and W.dim() == 2
     x = x.contiguous()
     W = W.contiguous()
     if W.shape[1] != ndims:
         raise ValueError(f"parameter vector has {W.shape[1]} dims, chain consumes {ndims}")
-    C, n = x.shape
+    n_inputs = x.shape[0] if x.dim() == 3 else 1
+    C, n = x.shape[-2:]
     P = W.shape[0]
+    if P % n_inputs:
+        raise ValueError(f"population {P} is not a multiple of the number of inputs {n_inputs}")
     c_out = L.stito_chain_out_channels(descs, n_fx, C)
     audio = torch.empty((P, c_out, n), dtype=torch.float32, device=x.device)
     peaks = torch.empty((P,), dtype=torch.float32, device=x.device)
     need = L.stito_render_workspace_bytes(descs, n_fx, C, n, P)
     ws = _WS.get("render", need, x.device)
-    _hip.check(L.stito_render_population(descs, n_fx, _hip.ptr(x), C, n, _hip.ptr(W), P, ndims, float(sample_rate),
-                                         _hip.ptr(audio), _hip.ptr(peaks), _hip.ptr(ws), ws.numel(),
-                                         _hip.stream_ptr()))
+    _hip.check(L.stito_render_population_multi(descs, n_fx, _hip.ptr(x), n_inputs, C, n, _hip.ptr(W), P, ndims,
+                                               float(sample_rate), _hip.ptr(audio), _hip.ptr(peaks), _hip.ptr(ws),
+                                               ws.numel(), _hip.stream_ptr()))
     return audio, peaks
 
 
@@ -159,7 +162,11 @@ class PopulationEvaluator:
 
     One instance per run_es call: holds the (padded) input on the device, the compiled chain
     and the target embeddings.  evaluate(W) returns the fitness list; embeddings and (lazily)
-    normalised audio are available for --savepop."""
+    normalised audio are available for --savepop.
+
+    Multi-pair batches (BASELINE.json configs[2]): x may hold B inputs (B, C, L) with B target
+    embeddings (B, E); evaluate then takes the B populations stacked pair-major, (B * P, D), and
+    scores the candidates of pair b against target b."""
 
     def __init__(self, x: torch.Tensor, sample_rate: int, plugins: Dict[str, dict], model, target_embeds: dict,
                  device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None):
@@ -170,22 +177,25 @@ class PopulationEvaluator:
         self.model = model
         self.chain = compile_chain(plugins)
         self.ndims = self.chain[1]
-        assert x.dim() == 3 and x.shape[0] == 1, "evaluate assumes a batch of one input (style_transfer.py:520)"
-        self.x_full = x[0].to(self.device, torch.float32).contiguous()
-        self.tmid = target_embeds["mid"].to(self.device, torch.float32).contiguous().view(-1)
-        self.tside = target_embeds["side"].to(self.device, torch.float32).contiguous().view(-1)
+        assert x.dim() == 3, "input audio must be (batch, chs, seq_len)"
+        self.n_inputs = x.shape[0]
+        self.x_full = x.to(self.device, torch.float32).contiguous()
+        self.tmid = target_embeds["mid"].to(self.device, torch.float32).contiguous().view(-1, target_embeds["mid"].shape[-1])
+        self.tside = target_embeds["side"].to(self.device, torch.float32).contiguous().view(-1, target_embeds["side"].shape[-1])
+        if self.tmid.shape[0] != self.n_inputs or self.tside.shape[0] != self.n_inputs:
+            raise ValueError(f"{self.n_inputs} inputs but {self.tmid.shape[0]} target embeddings")
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._streams = None
 
     def _input(self, random_crop: bool, rng) -> torch.Tensor:
-        """Length policy of style_transfer.py:505-518."""
+        """Length policy of style_transfer.py:505-518 (one crop position for all inputs of a batch)."""
         x = self.x_full
         n = x.shape[-1]
         if n > CROP_LEN:
             if random_crop and (n - CROP_LEN) > 16384:
                 start = int(rng.randint(16384, n - CROP_LEN))
-                return x[:, start:start + CROP_LEN].contiguous()
+                return x[..., start:start + CROP_LEN].contiguous()
             return x
         return torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
 
@@ -211,15 +221,21 @@ class PopulationEvaluator:
             raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
         x = self._input(random_crop, rng)
         P = Wt.shape[0]
-        c_out = _hip.lib().stito_chain_out_channels(self.chain[0], len(self.plugins), x.shape[0])
+        B = self.n_inputs
+        if P % B:
+            raise ValueError(f"{P} candidates cannot be split over {B} inputs")
+        per = P // B  # candidates per input
+        c_out = _hip.lib().stito_chain_out_channels(self.chain[0], len(self.plugins), x.shape[-2])
         G = self._groups(P, c_out)
         step = (P + G - 1) // G
         if self.max_cand:
             step = min(step, self.max_cand)
+        if B > 1:  # passes hold whole pairs
+            step = max(per, step // per * per)
         bounds = [(p0, min(P, p0 + step)) for p0 in range(0, P, step)]
         L = _hip.lib()
         main = torch.cuda.current_stream(self.device)
-        pipelined = len(bounds) > 1
+        pipelined = len(bounds) > 1 and G > 1
         if pipelined:
             if self._streams is None:
                 self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
@@ -230,18 +246,22 @@ class PopulationEvaluator:
             s_render = s_embed = main
         losses, mids, sides, audios, keep = [], [], [], [], []
         for p0, p1 in bounds:
+            b0, b1 = p0 // per, (p1 + per - 1) // per
             with torch.cuda.stream(s_render):
                 Wc = Wt[p0:p1].contiguous()
-                audio, peaks = render_population(self.plugins, x, Wc, self.sample_rate, chain=self.chain)
+                xin = x[0] if B == 1 else x[b0:b1]
+                audio, peaks = render_population(self.plugins, xin, Wc, self.sample_rate, chain=self.chain)
                 rendered = torch.cuda.Event()
                 rendered.record(s_render)
             with torch.cuda.stream(s_embed):
                 s_embed.wait_event(rendered)
                 mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
                 loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
-                _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1],
-                                              _hip.ptr(self.tmid), _hip.ptr(self.tside), _hip.ptr(loss),
-                                              _hip.ptr(self.flags), _hip.stream_ptr()))
+                spans = [(0, 0, p1 - p0)] if B == 1 else [(b, (b - b0) * per, (b - b0 + 1) * per) for b in range(b0, b1)]
+                for b, q0, q1 in spans:  # candidates of pair b against target b
+                    _hip.check(L.stito_embed_loss(_hip.ptr(mid[q0:q1]), _hip.ptr(side[q0:q1]), q1 - q0, mid.shape[1],
+                                                  _hip.ptr(self.tmid[b]), _hip.ptr(self.tside[b]), _hip.ptr(loss[q0:q1]),
+                                                  _hip.ptr(self.flags), _hip.stream_ptr()))
                 if want_audio:
                     audios.append(normalize_audio_(audio, peaks))
             losses.append(loss); mids.append(mid); sides.append(side)

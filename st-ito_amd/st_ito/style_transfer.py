@@ -3,7 +3,9 @@
 and `run_es` (399-692), with the evaluate-population step on the MI355X.
 
 Only the ES path is built; the baselines of the reference file (run_input, run_random,
-run_rule_based, run_deepafx_st) are outside this build's scope.
+run_rule_based, run_deepafx_st) are outside this build's scope.  `run_es_batch` is an extension
+(BASELINE.json configs[2]): several (input, target) pairs optimised together, every iteration
+evaluating all their populations in one GPU batch.
 """
 from __future__ import annotations
 
@@ -275,3 +277,93 @@ def run_es(
         "wopt_history": wopt_history,
         "num_evals": n_evals,
     }
+
+
+def run_es_batch(
+    input_audios: torch.Tensor,
+    target_audios: torch.Tensor,
+    sample_rate: int,
+    plugins: List[dict],
+    model: torch.nn.Module,
+    embed_func: callable,
+    max_iters: int = 100,
+    sigma0: float = 0.1,
+    popsize: int = 32,
+    random_crop: bool = False,
+    seed: int = None,
+    early_stop: bool = True,
+):
+    """ES over B independent (input, target) pairs at once -- BASELINE.json configs[2].
+
+    The reference optimises its examples one after the other (scripts/eval/eval_pst.py:691-765)
+    and its evaluate closure assumes one input (style_transfer.py:520).  Here every pair keeps its
+    own CMA-ES state (seed + pair index) and each iteration evaluates the B populations, stacked
+    pair-major as (B * popsize, D), in one pass over the GPU; pair b's candidates read input b and
+    are scored against target b.  A pair's trajectory is bitwise the one `run_es(find_w0=False,
+    seed=seed + b)` produces for it alone.  Pairs that stop early (same rule as run_es, lines
+    655-670) keep being evaluated with their last population but are no longer told.
+
+    input_audios / target_audios: (B, chs, seq_len), all pairs the same length and channel count.
+    Under torch.distributed the PAIRS are sharded over the ranks (no collective until
+    the final gather); every rank returns the full list of B result dicts."""
+    if input_audios.dim() != 3 or target_audios.dim() != 3 or input_audios.shape[0] != target_audios.shape[0]:
+        raise ValueError("input_audios and target_audios must be (B, chs, seq_len) with the same B")
+    dist, rank, world = _dist_info()
+    B_all = input_audios.shape[0]
+    lo, hi = shard_bounds(B_all, rank, world)
+    results = [None] * B_all
+    if hi > lo:
+        xs = input_audios[lo:hi].clone()
+        ts = target_audios[lo:hi].clone()
+        B = hi - lo
+        total_num_params = sum([plugin["num_params"] for plugin in plugins.values()])
+        # peak normalise each pair on its own (run_es 452-453)
+        xs /= xs.abs().amax(dim=(1, 2), keepdim=True).clamp(min=1e-8)
+        ts /= ts.abs().amax(dim=(1, 2), keepdim=True).clamp(min=1e-8)
+        target_embed = embed_func(ts, model, sample_rate)
+        evaluator = engine.PopulationEvaluator(xs, sample_rate, plugins, model, target_embed)
+        if evaluator.ndims != total_num_params:
+            raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
+        rng = np.random.RandomState(seed) if seed is not None else np.random
+        states = []
+        for b in range(B):
+            opts = {"bounds": [0, 1], "popsize": popsize}
+            if seed is not None:
+                opts["seed"] = seed + lo + b
+            states.append(dict(es=cma.CMAEvolutionStrategy(np.ones(total_num_params) * 0.5, sigma0, opts), fval_history=[],
+                               wopt_history=[], stale=0, active=True, last_W=None, n_evals=0))
+        for iteration in range(max_iters):
+            if not any(st["active"] for st in states):
+                break
+            Ws = []
+            for st in states:
+                if st["active"]:
+                    st["last_W"] = st["es"].ask()
+                Ws.append(st["last_W"])
+            loss, _, _ = evaluator.evaluate(np.concatenate([np.asarray(W) for W in Ws], 0), random_crop=random_crop, rng=rng)
+            fv = loss.tolist()
+            for b, st in enumerate(states):
+                if not st["active"]:
+                    continue
+                fvals = fv[b * popsize:(b + 1) * popsize]
+                st["n_evals"] += popsize
+                st["wopt_history"].append(st["es"].result[0])
+                st["fval_history"].append(st["es"].result[1])
+                st["es"].tell(st["last_W"], fvals)
+                fval_delta = (min(fvals) - min(st["fval_history"])) if iteration > 0 else -0.02
+                st["stale"] = st["stale"] + 1 if fval_delta > -0.01 else 0
+                if early_stop and st["stale"] > 10:
+                    st["active"] = False
+        for b, st in enumerate(states):
+            wopt, fopt = st["es"].result[0], st["es"].result[1]
+            out = torch.from_numpy(process_audio(xs[b].cpu().numpy(), wopt, sample_rate, plugins))
+            results[lo + b] = {"output_audio": out, "params": parameters_to_dict(wopt, plugins), "fopt": fopt, "wopt": wopt,
+                               "fval_history": st["fval_history"], "wopt_history": st["wopt_history"],
+                               "num_evals": st["n_evals"]}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [(i, r) for i, r in enumerate(results) if r is not None])
+        for part in gathered:
+            for i, r in part:
+                results[i] = r
+    return results

@@ -156,3 +156,36 @@ def test_stream_pipelined_groups_give_identical_fitness(dev, monkeypatch):
             np.testing.assert_array_equal(e1["mid"].cpu().numpy(), eg["mid"].cpu().numpy())
             np.testing.assert_array_equal(e1["side"].cpu().numpy(), eg["side"].cpu().numpy())
             np.testing.assert_array_equal(a1.cpu().numpy(), ag.cpu().numpy())
+
+
+def test_multi_pair_render_and_batch_es_match_single_pair_runs(dev):
+    """configs[2] (multi-pair batch): stito_render_population_multi must give candidate p of pair b
+    exactly what the single-input call gives, and run_es_batch must reproduce, pair by pair and
+    bitwise, the trajectory of run_es(find_w0=False, seed=seed+b) on that pair alone."""
+    from st_ito import effects as E, engine
+    from st_ito.style_transfer import run_es, run_es_batch
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    B, P, n = 3, 4, 80000
+    xs = torch.stack([O.synth_audio(40 + b, 2, n) for b in range(B)])
+    ts = torch.stack([O.synth_audio(50 + b, 2, n) * (0.3 + 0.2 * b) for b in range(B)])
+    pp = E.make_plugins("bench5")
+    # render: multi-input vs per-input
+    W = torch.from_numpy(np.random.default_rng(3).random((B * P, 45))).to(dev)
+    multi, mpeaks = engine.render_population(pp, xs.to(dev), W, SR)
+    for b in range(B):
+        single, speaks = engine.render_population(pp, xs[b].to(dev), W[b * P:(b + 1) * P], SR)
+        assert torch.equal(multi[b * P:(b + 1) * P], single) and torch.equal(mpeaks[b * P:(b + 1) * P], speaks)
+    with pytest.raises(ValueError):
+        engine.render_population(pp, xs.to(dev), W[:B * P - 1], SR)
+    # ES: batch vs one pair at a time
+    res = run_es_batch(xs.clone(), ts.clone(), SR, E.make_plugins("bench5"), pm, get_param_embeds, max_iters=3, sigma0=0.33,
+                       popsize=P, seed=11, early_stop=False)
+    assert len(res) == B
+    for b in range(B):
+        one = run_es(xs[b:b + 1].clone(), ts[b:b + 1].clone(), SR, E.make_plugins("bench5"), pm, get_param_embeds, max_iters=3,
+                     popsize=P, find_w0=False, sigma0=0.33, seed=11 + b, early_stop=False)
+        np.testing.assert_array_equal(res[b]["wopt"], one["wopt"])
+        assert res[b]["fopt"] == one["fopt"] and res[b]["fval_history"] == one["fval_history"]
+        assert torch.equal(res[b]["output_audio"], one["output_audio"])
+        assert res[b]["num_evals"] == 3 * P

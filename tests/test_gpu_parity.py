@@ -90,6 +90,31 @@ def test_single_effect_vs_oracle(dev, kind, chs, tol):
         assert err < tol, f"{kind} cand {p}: max err {err:.3e}"
 
 
+def test_compressor_ballistics_corners(dev):
+    """Heavy compression (threshold -40 dB, ratio 20) at the corners of the attack/release range,
+    including attack slower than release (c_att > c_rel: the GPU envelope runs on z = -y there) and
+    an odd length (scalar fallback of k_comp_env).  The GPU evaluates the switching one-pole as
+    max(c_a y + (1-c_a) v, c_r y + (1-c_r) v); the oracle as v + c (y - v): the same real-number map
+    with different float32 rounding (measured here: <= 3e-7 of peak; bound 2e-5 like the other
+    compressor test)."""
+    op, pp = _plugins_pair(["Compressor"])
+    raw = lambda v, lo, hi: (v - lo) / (hi - lo)
+    rows = []
+    for att in (0.1, 1.0, 100.0):
+        for rel in (10.0, 1000.0):
+            rows.append([raw(-40.0, -80.0, 0.0), raw(20.0, 1.0, 20.0), raw(att, 0.1, 100.0), raw(rel, 10.0, 1000.0)])
+    W = np.array(rows)
+    for n in (48000, 30011):
+        x = O.synth_audio(9, 2, n).numpy()
+        got, _ = _render_gpu(pp, x, W, dev, normalize=False)
+        for p in range(len(W)):
+            ref = _oracle_chain_raw(op, x, W[p])
+            assert np.abs(ref).max() < 0.5 * np.abs(x).max()  # it really compresses
+            err = np.abs(got[p] - ref).max() / max(1.0, np.abs(ref).max())
+            print(f"compressor att/rel corner {p} n={n}: err {err:.3e}")
+            assert err < 2e-5
+
+
 def test_eq_golden_reference_vectors(dev, golden_dir):
     """HIP EQ against outputs of the reference's own parametric_eq (tests/golden/eq_parametric.npz)."""
     from st_ito import effects as E

@@ -190,6 +190,55 @@ def test_population_sharding_world_size_2_gloo(tmp_path):
     np.testing.assert_array_equal(o0[:6], es.result[0])
 
 
+_PAIR_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r} + "/st-ito_amd")
+import numpy as np, torch, torch.distributed as dist
+from st_ito import style_transfer as ST
+rank = int(sys.argv[1]); world = int(sys.argv[2])
+if world > 1:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+class FakeEvaluator:                      # stands in for the GPU evaluator: pair b's optimum is its target value
+    def __init__(self, x, sr, plugins, model, target_embeds):
+        self.ndims = 4; self.t = target_embeds["mid"][:, 0].double().numpy(); self.B = x.shape[0]
+    def evaluate(self, W, random_crop=False, rng=None):
+        W = np.asarray(W); per = len(W) // self.B
+        f = [float(np.sum((w - self.t[i // per]) ** 2)) for i, w in enumerate(W)]
+        return torch.tensor(f, dtype=torch.float32), None, None
+ST.engine.PopulationEvaluator = FakeEvaluator
+ST.process_audio = lambda x, w, sr, plugins: x
+ST.parameters_to_dict = lambda w, plugins: dict(w=list(w))
+embed = lambda t, model, sr: dict(mid=t[:, :1, 1], side=t[:, :1, 1])   # target "embedding" = second sample
+B = 5
+x = torch.ones(B, 1, 8); tgt = torch.linspace(0.2, 0.8, B).view(B, 1, 1).repeat(1, 1, 8); tgt[:, :, 0] = 1.0  # peak 1
+plugins = dict(fx=dict(num_params=4))
+res = ST.run_es_batch(x, tgt, 48000, plugins, None, embed, max_iters=12, sigma0=0.3, popsize=6, seed=7, early_stop=False)
+assert len(res) == B and all(r is not None for r in res)
+np.save(sys.argv[4] + f".{{rank}}.npy", np.stack([np.concatenate([r["wopt"], [r["fopt"], r["num_evals"]]]) for r in res]))
+if world > 1:
+    dist.destroy_process_group()
+"""
+
+
+def test_pair_sharding_world_size_2_gloo(tmp_path):
+    """run_es_batch (configs[2]): pairs are sharded over the ranks (5 pairs -> 3 + 2), no collective
+    until the final gather; every rank ends with all results, identical to the single-process run."""
+    script = tmp_path / "pair_worker.py"
+    script.write_text(_PAIR_WORKER.format(root=ROOT))
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(tmp_path / "p")]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    assert subprocess.call([sys.executable, str(script), "0", "1", port, str(tmp_path / "s")]) == 0
+    p0, p1, s0 = np.load(tmp_path / "p.0.npy"), np.load(tmp_path / "p.1.npy"), np.load(tmp_path / "s.0.npy")
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(p0, s0)
+    assert p0.shape == (5, 6) and np.all(p0[:, 5] == 12 * 6)
+    assert np.all(np.abs(p0[:, :4] - np.linspace(0.2, 0.8, 5)[:, None]) < 0.15)   # each pair heads for ITS optimum
+
+
 def test_cli_parser_keeps_reference_flags():
     sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
     import importlib
