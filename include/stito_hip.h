@@ -48,10 +48,13 @@ enum {
     STITO_FX_DELAY = 3,         /* effects.py:919-934,  3 params, 2-channel in run_optim.py:395 */
     STITO_FX_REVERB = 4,        /* effects.py:937-959,  4 params, 2-channel */
     STITO_FX_GAIN = 5,          /* effects.py:532-542,  1 param  (BASELINE "gain" stage) */
-    STITO_FX_NUM_KINDS = 6
+    STITO_FX_NOISE_REVERB = 6,  /* effects.py:558-620 (apply_reverb -> dasp noise_shaped_reverberation), 25 params
+                                   (12 band gains, 12 band decays, mix; raw values used as they are), 2-channel;
+                                   convolution reverb of BASELINE.json configs[4].  Needs aux_dev / aux_len. */
+    STITO_FX_NUM_KINDS = 7
 };
 
-#define STITO_MAX_FX_PARAMS 18
+#define STITO_MAX_FX_PARAMS 32
 
 /* One plugin of the chain == one entry of the reference's `plugins` dict
  * (run_optim.py:376-437, style_transfer.py:17-42). */
@@ -64,6 +67,9 @@ typedef struct {
                              (style_transfer.py:79-84) */
     uint32_t reserved;
     double fixed_raw[STITO_MAX_FX_PARAMS]; /* raw [0,1] value = (v - min) / (max - min) */
+    const float *aux_dev; /* STITO_FX_NOISE_REVERB: band-filtered noise bank (2, 12, aux_len) float32 on the device
+                             (the library draws it afresh per call; here it is an input); NULL otherwise */
+    int64_t aux_len;      /* STITO_FX_NOISE_REVERB: impulse-response length in taps (dasp default 65 536) */
 } stito_fx_desc;
 
 const char *stito_last_error(void);

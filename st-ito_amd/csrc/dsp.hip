@@ -19,24 +19,10 @@
 //   delay          : feedback delay of D samples = D independent geometric recurrences.
 //   distortion/gain: element-wise.
 #include "common.h"
+#include "dsp_view.h"
 
 namespace stito {
 
-static constexpr int COEF_STRIDE = 32;  // doubles per (effect, candidate)
-
-struct InView {  // where a stage reads its input from
-    const float *base;
-    int64_t cand_stride;  // 0: an input x shared by a group of candidates
-    int64_t ch_stride;
-    int in_ch;  // channel c reads channel c % in_ch (mono -> stereo up-mix, style_transfer.py:94-95)
-    int group = 1 << 30;       // candidates per input (multi-pair batches: candidate p reads input p / group)
-    int64_t group_stride = 0;  // floats between consecutive inputs
-};
-
-__device__ __forceinline__ const float *in_ptr(const InView &v, int cand, int ch) {
-    return v.base + (int64_t)cand * v.cand_stride + (int64_t)(cand / v.group) * v.group_stride +
-           (int64_t)(ch % v.in_ch) * v.ch_stride;
-}
 
 // ------------------------------------------------------------------------------------------------
 // parameter tables: (min, max) of every Parameter, reference order
@@ -49,15 +35,17 @@ __constant__ double c_pmin[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
     {-48, -24},
     {0.01, 0.05, 0.0},
     {0, 0, 0, 0},
-    {-48}};
+    {-48},
+    {0}};
 __constant__ double c_pmax[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
     {24, 4000, 4, 24, 10000, 4, 24, 10000, 4, 24, 10000, 4, 24, 10000, 4, 24, 18000, 4},
     {0, 20, 100, 1000},
     {48, 24},
     {1.0, 1.0, 1.0},
     {1, 1, 1, 1},
-    {48}};
-static const int h_nparams[STITO_FX_NUM_KINDS] = {18, 4, 2, 3, 4, 1};
+    {48},
+    {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
+static const int h_nparams[STITO_FX_NUM_KINDS] = {18, 4, 2, 3, 4, 1, 25};
 
 struct ChainArgs {
     int n_fx;
@@ -112,7 +100,7 @@ __global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, 
     const stito_fx_desc &fx = chain.fx[f];
     const int kind = fx.kind;
     double v[STITO_MAX_FX_PARAMS];
-    const int np = kind == 0 ? 18 : kind == 1 ? 4 : kind == 2 ? 2 : kind == 3 ? 3 : kind == 4 ? 4 : 1;
+    const int np = kind == 0 ? 18 : kind == 1 ? 4 : kind == 2 ? 2 : kind == 3 ? 3 : kind == 4 ? 4 : kind == 5 ? 1 : 25;
     for (int p = 0; p < np; ++p) {
         const double raw = ((fx.fixed_mask >> p) & 1u) ? fx.fixed_raw[p]
                                                        : w[(int64_t)cand * D + fx.w_offset + fx.has_bypass + p];
@@ -147,6 +135,12 @@ __global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, 
         o[2] = 0.5f * wet * (1.0f + width);
         o[3] = 0.5f * wet * (1.0f - width);
         o[4] = dryl * 2.0f;
+    } else if (kind == STITO_FX_NOISE_REVERB) {  // dasp noise_shaped_reverberation: gains, 10 decay + 1, mix (float32)
+        for (int b = 0; b < 12; ++b) {
+            o[b] = (float)v[b];
+            o[12 + b] = (float)v[12 + b] * 10.0f + 1.0f;
+        }
+        o[24] = (float)v[24];
     } else {
         o[0] = powf(10.0f, (float)v[0] / 20.0f);
     }
@@ -812,7 +806,13 @@ extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
     size_t env = has_comp ? align_up((size_t)pop * cout * n_samples * sizeof(float), 256) : 0;
-    return coef + env + 256;
+    size_t cr = 0;  // convolution reverb: spectra of the input blocks and of every candidate's IR partitions
+    for (int i = 0; i < n_fx; ++i)
+        if (chain[i].kind == STITO_FX_NOISE_REVERB) {
+            const size_t need = conv_reverb_workspace_bytes(pop * 2, n_samples, chain[i].aux_len > 0 ? chain[i].aux_len : 1);
+            cr = need > cr ? need : cr;
+        }
+    return coef + env + cr + 256;
 }
 
 extern "C" int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples, float *peaks_dev,
@@ -872,6 +872,9 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
     char *ws = (char *)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
     double *coef = (double *)ws;
     float *envbuf = (float *)(ws + align_up((size_t)(n_fx > 0 ? n_fx : 1) * pop * COEF_STRIDE * sizeof(double), 256));
+    bool has_comp = false;
+    for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
+    char *crbuf = (char *)envbuf + (has_comp ? align_up((size_t)pop * C_out * n_samples * sizeof(float), 256) : 0);
 
     if (n_fx > 0) {
         ChainArgs args;
@@ -940,6 +943,12 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                               "Reverb: sample rate %.0f needs delay lines outside the LDS-resident design", sample_rate);
                 STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(k_reverb, dim3(pop), dim3(RV_THREADS), lds, st, in, audio_dev, cand_stride, L, cf, g);
+                break;
+            }
+            case STITO_FX_NOISE_REVERB: {
+                STITO_REQUIRE(Cn == 2, STITO_E_INVALID, "NoiseShapedReverb must be declared with num_channels=2");
+                const int rc = conv_reverb_stage(in, audio_dev, cand_stride, pop, L, cf, fx.aux_dev, fx.aux_len, crbuf, st);
+                if (rc) return rc;
                 break;
             }
             default:

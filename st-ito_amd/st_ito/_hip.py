@@ -14,10 +14,10 @@ import torch  # noqa: F401  (must be imported first: brings in the process' liba
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libstito_hip.so")
 
-FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN = range(6)
+FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB = range(7)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
 CONV_DIRECT, CONV_WINOGRAD = 0, 1
-MAX_FX_PARAMS = 18
+MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 
 
@@ -25,6 +25,7 @@ class FxDesc(Structure):
     _fields_ = [
         ("kind", c_int32), ("num_channels", c_int32), ("w_offset", c_int32), ("has_bypass", c_int32),
         ("fixed_mask", c_uint32), ("reserved", c_uint32), ("fixed_raw", c_double * MAX_FX_PARAMS),
+        ("aux_dev", c_void_p), ("aux_len", c_int64),
     ]
 
 

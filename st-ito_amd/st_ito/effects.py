@@ -147,6 +147,64 @@ class BasicGain(_BasicEffect):
         self.parameters = OrderedDict([("gain_db", Parameter(gain_db, -48.0, 48.0))])
 
 
+def octave_band_filterbank(num_taps: int, sample_rate: float):
+    """12 FIR filters (low-pass < 12 Hz... octave bands 31.25 Hz - 16 kHz ... high-pass > 18 kHz), the
+    bank dasp_pytorch.noise_shaped_reverberation shapes its noise with: scipy.signal.firwin designs,
+    time-reversed, float32, (12, 1, num_taps)."""
+    import scipy.signal
+    import torch
+
+    filts = [scipy.signal.firwin(num_taps, 12, fs=sample_rate)]
+    for fc in [31.25, 62.5, 125, 250, 500, 1000, 2000, 4000, 8000, 16000]:
+        f_min, f_max = fc / np.sqrt(2), fc * np.sqrt(2)
+        f_max = np.clip(f_max, a_min=0, a_max=(sample_rate / 2) * 0.999)
+        filts.append(scipy.signal.firwin(num_taps, [f_min, f_max], fs=sample_rate, pass_zero=False))
+    filts.append(scipy.signal.firwin(num_taps, 18000, fs=sample_rate, pass_zero=False))
+    return torch.stack([torch.flip(torch.from_numpy(f.astype("float32")), dims=[0]) for f in filts], 0).unsqueeze(1)
+
+
+def make_noise_bank(num_samples: int = 65536, num_bandpass_taps: int = 1023, sample_rate: float = 48000, seed: int = 0):
+    """Band-filtered white noise (2, 12, num_samples) float32: what noise_shaped_reverberation draws
+    afresh (unseeded) on every call, drawn once from a seeded generator so that the impulse
+    responses -- and with them the optimisation -- are reproducible."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    wn = torch.randn(2, 12, num_samples + num_bandpass_taps - 1, generator=g)
+    return torch.nn.functional.conv1d(wn, octave_band_filterbank(num_bandpass_taps, sample_rate), groups=12).contiguous()
+
+
+class NoiseShapedReverb(_BasicEffect):
+    """Convolution reverb of the reference's apply_reverb (effects.py:558-620 ->
+    dasp_pytorch.noise_shaped_reverberation): 12 band gains, 12 band decays, mix -- all used raw in
+    [0, 1] -- shape a noise impulse response of `num_samples` taps (65 536 in the library, 96 000
+    = 2 s in BASELINE.json configs[4]) that is convolved with the audio.  Always stereo (mono is
+    duplicated).  Not in run_optim.py's ES chains (the reference calls it from the autodiff path
+    only); here it is a chain stage like any other."""
+
+    KIND = _hip.FX_NOISE_REVERB
+    NUM_CHANNELS = 2
+    ALWAYS_STEREO = True
+
+    def __init__(self, num_samples: int = 65536, num_bandpass_taps: int = 1023, sample_rate: float = 48000,
+                 seed: int = 0, noise_bank=None):
+        names = [f"band{b}_gain" for b in range(12)] + [f"band{b}_decay" for b in range(12)] + ["mix"]
+        self.parameters = OrderedDict((n, Parameter(0.5, 0.0, 1.0)) for n in names)
+        self.noise_bank = noise_bank if noise_bank is not None else make_noise_bank(num_samples, num_bandpass_taps,
+                                                                                      sample_rate, seed)
+        if self.noise_bank.dim() != 3 or tuple(self.noise_bank.shape[:2]) != (2, 12):
+            raise ValueError("noise_bank must be (2, 12, num_samples)")
+        self.num_samples = int(self.noise_bank.shape[-1])
+        self._bank_dev = None
+
+    def noise_bank_device(self, device):
+        import torch
+
+        if self._bank_dev is None or self._bank_dev.device != device:
+            self._bank_dev = self.noise_bank.to(device, torch.float32).contiguous()
+        return self._bank_dev
+
+
 class BasicChorus(_BasicEffect):
     """reference effects.py:962-985 -- not on the ES path of run_optim.py; not built here."""
 
@@ -164,6 +222,10 @@ BASIC_CHAINS = {
     "bench5": [("ParametricEQ", BasicParametricEQ, 1), ("Compressor", BasicCompressor, 1),
                ("Reverb", BasicReverb, 2), ("ParametricEQ2", BasicParametricEQ, 1), ("Gain", BasicGain, 1)],
     "eq": [("ParametricEQ", BasicParametricEQ, 1)],
+    # BASELINE.json configs[4] shape: convolution reverb in the chain (class_path may be a
+    # functools.partial(NoiseShapedReverb, num_samples=96000) for the 2 s impulse response)
+    "eq-convreverb-gain": [("ParametricEQ", BasicParametricEQ, 1), ("ConvReverb", NoiseShapedReverb, 2),
+                           ("Gain", BasicGain, 1)],
 }
 
 

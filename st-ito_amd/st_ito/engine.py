@@ -42,6 +42,7 @@ def compile_chain(plugins: Dict[str, dict]) -> Tuple[ctypes.Array, int]:
     names listed in plugin["fixed_parameters"] take the fixed value (via Parameter.set_value)
     but still consume their slot."""
     descs = (_hip.FxDesc * max(1, len(plugins)))()
+    descs._keep = []  # device buffers the descriptor points into
     off = 0
     for i, (plugin_name, plugin) in enumerate(plugins.items()):
         if "vst_filepath" in plugin and "class_path" not in plugin:
@@ -67,6 +68,11 @@ def compile_chain(plugins: Dict[str, dict]) -> Tuple[ctypes.Array, int]:
                 d.fixed_raw[p] = prm.raw_value
                 mask |= 1 << p
         d.fixed_mask = mask
+        if kind == _hip.FX_NOISE_REVERB:  # the band-filtered noise bank is an input of the stage
+            _hip.require_gpu()
+            bank = inst.noise_bank_device(torch.device("cuda", torch.cuda.current_device()))
+            descs._keep.append(bank)
+            d.aux_dev, d.aux_len = bank.data_ptr(), bank.shape[-1]
         off += len(names)
     return descs, off
 
@@ -133,7 +139,7 @@ def render_single(instance, x: np.ndarray, sample_rate: float) -> np.ndarray:
         raise ValueError("process expects a (chs, n) array")
     # .process() is called with exactly the channels the effect should see; a stereo effect
     # called with mono audio is fed the mono signal as in pedalboard (no up-mix here).
-    nch = 2 if (x.shape[0] == 2 and instance.NUM_CHANNELS == 2) else 1
+    nch = 2 if ((x.shape[0] == 2 and instance.NUM_CHANNELS == 2) or getattr(instance, "ALWAYS_STEREO", False)) else 1
     plugins = {"fx": {"class_path": type(instance), "instance": instance, "num_channels": nch,
                       "fixed_parameters": {}, "parameter_names": list(instance.parameters.keys()),
                       "num_params": len(instance.parameters)}}

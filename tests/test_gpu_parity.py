@@ -115,6 +115,71 @@ def test_compressor_ballistics_corners(dev):
             assert err < 2e-5
 
 
+def _noise_reverb_pair(n_taps, taps=255):
+    """Oracle and product NoiseShapedReverb plugin dicts sharing one seeded noise bank."""
+    from st_ito import effects as E
+    bank = O.make_noise_bank(n_taps, taps, SR, seed=3)
+    assert torch.equal(bank, E.make_noise_bank(n_taps, taps, SR, seed=3))  # the two restatements agree bitwise
+    oi, pi = O.OracleNoiseShapedReverb(noise_bank=bank), E.NoiseShapedReverb(noise_bank=bank)
+    names = list(oi.parameters.keys())
+    assert names == list(pi.parameters.keys()) and len(names) == 25
+    mk = lambda inst: {"ConvReverb": {"class_path": type(inst), "num_params": 25, "num_channels": 2, "fixed_parameters": {},
+                                       "instance": inst, "parameter_names": list(names)}}
+    return mk(oi), mk(pi)
+
+
+@pytest.mark.parametrize("n_taps,n,chs", [(5000, 30011, 2), (5000, 9000, 1), (65536, 20000, 2), (4096, 4096, 2)])
+def test_noise_shaped_conv_reverb_vs_oracle(dev, n_taps, n, chs):
+    """SURVEY 8(a) a9 / configs[4]: partitioned overlap-save FFT convolution on the GPU against the
+    oracle's restatement of dasp noise_shaped_reverberation (direct conv1d for short IRs, float64 FFT
+    for long ones).  float32 FFT round-off: bound 1e-5 of the output peak."""
+    op, pp = _noise_reverb_pair(n_taps)
+    rng = np.random.default_rng(n_taps + n)
+    x = O.synth_audio(17, chs, n).numpy()
+    W = rng.random((4, 25))
+    W[0, 24] = 1.0   # fully wet
+    W[1, :12] = 0.0  # all band gains zero: wet = 0 -> y = (1 - mix) x
+    got, _ = _render_gpu(pp, x, W, dev, normalize=False)
+    assert got.shape == (4, 2, n)  # always stereo
+    for p in range(4):
+        ref = _oracle_chain_raw(op, x, W[p])
+        err = np.abs(got[p] - ref).max() / max(1e-3, np.abs(ref).max())
+        print(f"conv reverb taps={n_taps} n={n} cand {p}: rel-to-peak err {err:.3e}")
+        assert err < 1e-5
+    xs = np.concatenate((x, x), 0) if chs == 1 else x
+    np.testing.assert_allclose(got[1], (1.0 - np.float32(W[1, 24])) * xs, rtol=0, atol=1e-7)
+
+
+def test_conv_reverb_in_chain_and_multi_pair(dev):
+    """The stage after an in-place effect (per-candidate input blocks) and as first effect of a
+    multi-pair batch (input spectra shared by each pair's candidates)."""
+    from st_ito import effects as E, engine
+    bank = O.make_noise_bank(6000, 255, SR, seed=5)
+    def chain(mod, eq, rv, gn):
+        pl = {}
+        for name, inst, nch in (("ParametricEQ", eq(), 1), ("ConvReverb", rv(noise_bank=bank), 2), ("Gain", gn(), 1)):
+            names = list(inst.parameters.keys())
+            pl[name] = {"class_path": type(inst), "num_params": len(names), "num_channels": nch, "fixed_parameters": {},
+                        "instance": inst, "parameter_names": names}
+        return pl
+    op = chain(O, O.OracleParametricEQ, O.OracleNoiseShapedReverb, O.OracleGain)
+    pp = chain(E, E.BasicParametricEQ, E.NoiseShapedReverb, E.BasicGain)
+    x = O.synth_audio(23, 1, 25000).numpy()  # mono: EQ runs mono, the reverb up-mixes
+    W = np.random.default_rng(8).random((3, 18 + 25 + 1))
+    got, _ = _render_gpu(pp, x, W, dev, normalize=False)
+    for p in range(3):
+        ref = _oracle_chain_raw(op, x, W[p])
+        assert np.abs(got[p] - ref).max() / max(1e-3, np.abs(ref).max()) < 2e-5
+    # reverb first, two pairs x two candidates
+    _, rp = _noise_reverb_pair(5000)
+    xs = torch.stack([O.synth_audio(60 + b, 2, 20000) for b in range(2)]).to(dev)
+    Wm = torch.from_numpy(np.random.default_rng(9).random((4, 25))).to(dev)
+    multi, _ = engine.render_population(rp, xs, Wm, SR)
+    for b in range(2):
+        single, _ = engine.render_population(rp, xs[b], Wm[2 * b:2 * b + 2], SR)
+        assert torch.equal(multi[2 * b:2 * b + 2], single)
+
+
 def test_eq_golden_reference_vectors(dev, golden_dir):
     """HIP EQ against outputs of the reference's own parametric_eq (tests/golden/eq_parametric.npz)."""
     from st_ito import effects as E
