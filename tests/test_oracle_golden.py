@@ -247,3 +247,39 @@ def test_cosine_of_identical_audio_is_minus_one():
     te = O.get_param_embeds(xl.clone(), m, SR)
     f, _, _ = O.evaluate([w], x, SR, plugins, te, m)
     assert abs(f[0] + 1.0) < 1e-5
+
+
+def test_noise_shaped_reverb_known_answers():
+    """dasp noise_shaped_reverberation restatement (parity unpinned: no reference test or vector
+    exists, and the library's IR is random per call) -- known-answer checks instead."""
+    bank = O.make_noise_bank(3000, 127, SR, seed=1)
+    assert bank.shape == (2, 12, 3000) and bank.dtype == torch.float32
+    fb = O.octave_band_filterbank(127, SR)
+    assert fb.shape == (12, 1, 127)
+    assert abs(float(fb[0].sum()) - 1.0) < 1e-3          # low-pass: unit DC gain
+    assert abs(float(fb[8].sum())) < 1e-2 and abs(float(fb[11].sum())) < 1e-2  # 4 kHz band / high-pass: no DC
+    fb_full = O.octave_band_filterbank(1023, SR)                                # the library's default length
+    assert all(abs(float(fb_full[b].sum())) < 1e-2 for b in range(3, 12))       # 125 Hz and up resolved at 1023 taps
+    r = O.OracleNoiseShapedReverb(noise_bank=bank)
+    x = O.synth_audio(2, 2, 5000).numpy()
+    r.parameters["mix"].raw_value = 0.0
+    np.testing.assert_array_equal(r.process(x, SR), x)     # dry only
+    assert r.process(x[:1], SR).shape == (2, 5000)          # mono is copied to stereo
+    r.parameters["mix"].raw_value = 1.0
+    for b in range(12):
+        r.parameters[f"band{b}_gain"].raw_value = 1.0
+        r.parameters[f"band{b}_decay"].raw_value = 0.0      # envelope exp(-t)
+    ir = r.impulse_response()
+    np.testing.assert_allclose(ir[:, 0].numpy(), (bank * torch.exp(-torch.linspace(0, 1, 3000))).mean(1).numpy(), atol=1e-7)
+    imp = np.zeros((2, 5000), np.float32); imp[:, 0] = 1.0
+    np.testing.assert_allclose(r.process(imp, SR)[:, :3000], ir[:, 0].numpy(), atol=1e-7)  # impulse in -> IR out (causal)
+    assert np.abs(r.process(imp, SR)[:, 3000:]).max() < 1e-7
+    y1, y2 = r.process(x, SR), r.process(2 * x, SR)
+    np.testing.assert_allclose(y2, 2 * y1, rtol=1e-5, atol=1e-6)                           # linear
+    for b in range(12):
+        r.parameters[f"band{b}_decay"].raw_value = 1.0      # exp(-11 t): the tail is 60+ dB down
+    ir_fast = r.impulse_response()
+    assert ir_fast[:, 0, -300:].abs().max() < 1e-3 * ir_fast[:, 0, :300].abs().max()
+    # the product's host-side bank builder is the same restatement
+    from st_ito import effects as E
+    assert torch.equal(E.make_noise_bank(3000, 127, SR, seed=1), bank)
