@@ -55,6 +55,9 @@ enum {
 };
 
 #define STITO_MAX_FX_PARAMS 32
+/* stito_fx_desc.reserved bit 0: joint peak normalisation of every candidate after this stage --
+ * process_audio(normalize_stages=True), style_transfer.py:106-107. */
+#define STITO_FX_FLAG_NORMALIZE_AFTER 1u
 
 /* One plugin of the chain == one entry of the reference's `plugins` dict
  * (run_optim.py:376-437, style_transfer.py:17-42). */
@@ -65,7 +68,7 @@ typedef struct {
     int32_t has_bypass;   /* 1: slot 0 is the dead "our_bypass" dimension (style_transfer.py:28, 89-92) */
     uint32_t fixed_mask;  /* bit p set: parameter p comes from fixed_raw[p], but still consumes a w slot
                              (style_transfer.py:79-84) */
-    uint32_t reserved;
+    uint32_t reserved;    /* flags: STITO_FX_FLAG_* (the field keeps its first-round name) */
     double fixed_raw[STITO_MAX_FX_PARAMS]; /* raw [0,1] value = (v - min) / (max - min) */
     const float *aux_dev; /* STITO_FX_NOISE_REVERB: band-filtered noise bank (2, 12, aux_len) float32 on the device
                              (the library draws it afresh per call; here it is an input); NULL otherwise */

@@ -698,10 +698,13 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
 // ------------------------------------------------------------------------------------------------
 // peak / normalise (style_transfer.py:113)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_peak(const float *__restrict__ a, int64_t per_cand, float *__restrict__ peaks) {
+// per_cand = floats scanned per candidate, stride = floats between candidates (>= per_cand: a mono
+// stage of a chain that ends stereo only fills the first channel of each candidate's slot)
+__global__ __launch_bounds__(256) void k_peak(const float *__restrict__ a, int64_t per_cand, int64_t stride,
+                                               float *__restrict__ peaks) {
     __shared__ float red[4];
     const int cand = blockIdx.y;
-    const float4 *p4 = (const float4 *)(a + (int64_t)cand * per_cand);
+    const float4 *p4 = (const float4 *)(a + (int64_t)cand * stride);
     const int64_t n4 = per_cand / 4;
     float m = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -718,10 +721,11 @@ __global__ __launch_bounds__(256) void k_peak(const float *__restrict__ a, int64
     }
 }
 
-__global__ __launch_bounds__(256) void k_peak_scalar(const float *__restrict__ a, int64_t per_cand, float *__restrict__ peaks) {
+__global__ __launch_bounds__(256) void k_peak_scalar(const float *__restrict__ a, int64_t per_cand, int64_t stride,
+                                                      float *__restrict__ peaks) {
     __shared__ float red[4];
     const int cand = blockIdx.y;
-    const float *p = a + (int64_t)cand * per_cand;
+    const float *p = a + (int64_t)cand * stride;
     float m = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_cand; i += (int64_t)gridDim.x * blockDim.x)
         m = fmaxf(m, fabsf(p[i]));
@@ -735,10 +739,11 @@ __global__ __launch_bounds__(256) void k_peak_scalar(const float *__restrict__ a
     }
 }
 
-__global__ __launch_bounds__(256) void k_normalize(float *__restrict__ a, int64_t per_cand, const float *__restrict__ peaks) {
+__global__ __launch_bounds__(256) void k_normalize(float *__restrict__ a, int64_t per_cand, int64_t stride,
+                                                    const float *__restrict__ peaks) {
     const int cand = blockIdx.y;
     const float d = fmaxf(peaks[cand], 1e-8f);
-    float *p = a + (int64_t)cand * per_cand;
+    float *p = a + (int64_t)cand * stride;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_cand; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = p[i] / d;
 }
@@ -812,34 +817,40 @@ extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n
             const size_t need = conv_reverb_workspace_bytes(pop * 2, n_samples, chain[i].aux_len > 0 ? chain[i].aux_len : 1);
             cr = need > cr ? need : cr;
         }
-    return coef + env + cr + 256;
+    return coef + env + cr + align_up((size_t)pop * sizeof(float), 256) + 256;
 }
 
-extern "C" int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples, float *peaks_dev,
-                          void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    STITO_REQUIRE(pop > 0 && channels > 0 && n_samples > 0, STITO_E_INVALID, "stito_peak: empty input");
+static int peak_strided(const float *audio_dev, int pop, int64_t per, int64_t stride, float *peaks_dev, hipStream_t st) {
     STITO_HIP_CHECK(hipMemsetAsync(peaks_dev, 0, sizeof(float) * pop, st));
-    const int64_t per = (int64_t)channels * n_samples;
-    if (((uintptr_t)audio_dev & 15) == 0 && per % 4 == 0) {
+    if (((uintptr_t)audio_dev & 15) == 0 && per % 4 == 0 && stride % 4 == 0) {
         dim3 grid(grid_x_for(per / 4, pop), pop);
-        hipLaunchKernelGGL(k_peak, grid, dim3(256), 0, st, audio_dev, per, peaks_dev);
+        hipLaunchKernelGGL(k_peak, grid, dim3(256), 0, st, audio_dev, per, stride, peaks_dev);
     } else {
         dim3 grid(grid_x_for(per, pop), pop);
-        hipLaunchKernelGGL(k_peak_scalar, grid, dim3(256), 0, st, audio_dev, per, peaks_dev);
+        hipLaunchKernelGGL(k_peak_scalar, grid, dim3(256), 0, st, audio_dev, per, stride, peaks_dev);
     }
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
 
-extern "C" int stito_normalize_audio(float *audio_dev, int pop, int channels, int64_t n_samples,
-                                     const float *peaks_dev, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t per = (int64_t)channels * n_samples;
+static int normalize_strided(float *audio_dev, int pop, int64_t per, int64_t stride, const float *peaks_dev, hipStream_t st) {
     dim3 grid(grid_x_for(per, pop), pop);
-    hipLaunchKernelGGL(k_normalize, grid, dim3(256), 0, st, audio_dev, per, peaks_dev);
+    hipLaunchKernelGGL(k_normalize, grid, dim3(256), 0, st, audio_dev, per, stride, peaks_dev);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
+}
+
+extern "C" int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples, float *peaks_dev,
+                          void *stream) {
+    STITO_REQUIRE(pop > 0 && channels > 0 && n_samples > 0, STITO_E_INVALID, "stito_peak: empty input");
+    const int64_t per = (int64_t)channels * n_samples;
+    return peak_strided(audio_dev, pop, per, per, peaks_dev, (hipStream_t)stream);
+}
+
+extern "C" int stito_normalize_audio(float *audio_dev, int pop, int channels, int64_t n_samples,
+                                     const float *peaks_dev, void *stream) {
+    const int64_t per = (int64_t)channels * n_samples;
+    return normalize_strided(audio_dev, pop, per, per, peaks_dev, (hipStream_t)stream);
 }
 
 extern "C" int stito_render_population(const stito_fx_desc *chain, int n_fx, const float *x_dev, int in_channels,
@@ -875,6 +886,8 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
     char *crbuf = (char *)envbuf + (has_comp ? align_up((size_t)pop * C_out * n_samples * sizeof(float), 256) : 0);
+    // per-stage peaks (normalize_stages) live in the last pop floats of the workspace
+    float *stage_peaks = (float *)(ws + (need - 256 - align_up((size_t)pop * sizeof(float), 256)));
 
     if (n_fx > 0) {
         ChainArgs args;
@@ -958,6 +971,12 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
         C = Cn;
         in = InView{audio_dev, cand_stride, L, C};
         in_buffer = true;
+        if (fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER) {  // normalize_stages (style_transfer.py:106-107)
+            int rc = peak_strided(audio_dev, pop, (int64_t)C * L, cand_stride, stage_peaks, st);
+            if (rc) return rc;
+            rc = normalize_strided(audio_dev, pop, (int64_t)C * L, cand_stride, stage_peaks, st);
+            if (rc) return rc;
+        }
     }
     if (!in_buffer) {  // empty chain: broadcast x
         const int S = pop * C_out;

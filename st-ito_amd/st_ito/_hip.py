@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libstito_hip.so")
 
 FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB = range(7)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
+FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.reserved bit 0
 CONV_DIRECT, CONV_WINOGRAD = 0, 1
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4

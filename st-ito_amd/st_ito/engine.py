@@ -34,7 +34,7 @@ def _instance_of(plugin: dict):
     return plugin["instance"]
 
 
-def compile_chain(plugins: Dict[str, dict]) -> Tuple[ctypes.Array, int]:
+def compile_chain(plugins: Dict[str, dict], normalize_stages: bool = False) -> Tuple[ctypes.Array, int]:
     """Compile the reference's `plugins` dict into the C chain descriptor.
 
     Mirrors how process_audio walks the dict (style_transfer.py:65-92): every name in
@@ -68,6 +68,7 @@ def compile_chain(plugins: Dict[str, dict]) -> Tuple[ctypes.Array, int]:
                 d.fixed_raw[p] = prm.raw_value
                 mask |= 1 << p
         d.fixed_mask = mask
+        d.reserved = _hip.FX_FLAG_NORMALIZE_AFTER if normalize_stages else 0  # style_transfer.py:106-107
         if kind == _hip.FX_NOISE_REVERB:  # the band-filtered noise bank is an input of the stage
             _hip.require_gpu()
             bank = inst.noise_bank_device(torch.device("cuda", torch.cuda.current_device()))
@@ -149,13 +150,14 @@ def render_single(instance, x: np.ndarray, sample_rate: float) -> np.ndarray:
     return audio[0].cpu().numpy()
 
 
-def process_audio_gpu(x: np.ndarray, w: np.ndarray, sr: int, plugins: Dict[str, dict]) -> np.ndarray:
+def process_audio_gpu(x: np.ndarray, w: np.ndarray, sr: int, plugins: Dict[str, dict],
+                      normalize_stages: bool = False) -> np.ndarray:
     """process_audio for one parameter vector (style_transfer.py:45-115)."""
     _hip.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
     wt = torch.as_tensor(np.asarray(w, dtype=np.float64)[None, :]).to(dev)
-    audio, peaks = render_population(plugins, xt, wt, sr)
+    audio, peaks = render_population(plugins, xt, wt, sr, chain=compile_chain(plugins, normalize_stages))
     normalize_audio_(audio, peaks)
     return audio[0].cpu().numpy()
 
@@ -220,8 +222,6 @@ class PopulationEvaluator:
         software-pipelined over two HIP streams: while group g runs log-mel + Cnn14 + loss on the
         embed stream, group g+1 runs its effect chain on the render stream.  A candidate's result
         does not depend on the grouping."""
-        if dropout > 0.0:
-            raise NotImplementedError("embedding dropout inside evaluate is not built (run_optim default is 0.0)")
         Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
         if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
             raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
@@ -263,10 +263,20 @@ class PopulationEvaluator:
                 s_embed.wait_event(rendered)
                 mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
                 loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
+                # dropout (style_transfer.py:549-551) hits the embeddings only inside the distance; the cosine is
+                # scale-invariant, so dropping the raw vectors and normalising afterwards is the same quantity.
+                # The returned embeddings stay undropped, like the reference's output_embeds.
+                md, sd = mid, side
+                if dropout > 0.0:
+                    md = torch.nn.functional.dropout(mid, p=dropout, training=True).contiguous()
+                    sd = torch.nn.functional.dropout(side, p=dropout, training=True).contiguous()
                 spans = [(0, 0, p1 - p0)] if B == 1 else [(b, (b - b0) * per, (b - b0 + 1) * per) for b in range(b0, b1)]
                 for b, q0, q1 in spans:  # candidates of pair b against target b
-                    _hip.check(L.stito_embed_loss(_hip.ptr(mid[q0:q1]), _hip.ptr(side[q0:q1]), q1 - q0, mid.shape[1],
+                    _hip.check(L.stito_embed_loss(_hip.ptr(md[q0:q1]), _hip.ptr(sd[q0:q1]), q1 - q0, mid.shape[1],
                                                   _hip.ptr(self.tmid[b]), _hip.ptr(self.tside[b]), _hip.ptr(loss[q0:q1]),
+                                                  _hip.ptr(self.flags), _hip.stream_ptr()))
+                if dropout > 0.0:  # NaN scrub + L2 norm of the embeddings handed back
+                    _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1], None, None, None,
                                                   _hip.ptr(self.flags), _hip.stream_ptr()))
                 if want_audio:
                     audios.append(normalize_audio_(audio, peaks))

@@ -49,15 +49,13 @@ def load_plugins(plugins: dict):
 def process_audio(x: np.ndarray, w: np.ndarray, sr: int, plugins: List[dict], normalize_stages: bool = False):
     """Process audio with plugins and provided parameters on [0, 1] (reference
     style_transfer.py:45-115).  x: (chs, num_samples) float32, w: (num_params,).  Rendered on the
-    GPU by stito_render_population + stito_normalize_audio."""
-    if normalize_stages:
-        raise NotImplementedError("normalize_stages=True is not built (run_es never forwards it, "
-                                  "style_transfer.py:419-420)")
+    GPU by stito_render_population + stito_normalize_audio; normalize_stages (106-107) adds a joint
+    peak normalisation after every plugin (STITO_FX_FLAG_NORMALIZE_AFTER)."""
     if isinstance(x, torch.Tensor):
         x = x.detach().cpu().numpy()
     if isinstance(w, torch.Tensor):
         w = w.detach().cpu().numpy()
-    return engine.process_audio_gpu(x, w, sr, plugins)
+    return engine.process_audio_gpu(x, w, sr, plugins, normalize_stages=normalize_stages)
 
 
 def parameters_to_dict(w: np.ndarray, plugins: List[dict]):

@@ -189,3 +189,27 @@ def test_multi_pair_render_and_batch_es_match_single_pair_runs(dev):
         assert res[b]["fopt"] == one["fopt"] and res[b]["fval_history"] == one["fval_history"]
         assert torch.equal(res[b]["output_audio"], one["output_audio"])
         assert res[b]["num_evals"] == 3 * P
+
+
+def test_evaluate_dropout(dev):
+    """evaluate(dropout=p), style_transfer.py:549-551: dropout acts on the embeddings inside the
+    distance only; the embeddings handed back are the undropped ones; torch's RNG drives the mask."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    x = O.synth_audio(71, 2, 70000)[None]
+    tgt = O.synth_audio(72, 2, 70000)[None]
+    ev = PopulationEvaluator(x, SR, E.make_plugins("eq-comp"), pm, get_param_embeds(tgt, pm, SR))
+    W = np.random.default_rng(4).random((5, 22))
+    l0, e0, _ = ev.evaluate(W)
+    torch.manual_seed(123)
+    l1, e1, _ = ev.evaluate(W, dropout=0.5)
+    torch.manual_seed(123)
+    l2, e2, _ = ev.evaluate(W, dropout=0.5)
+    assert torch.equal(l1, l2)                                   # same seed, same mask
+    assert torch.equal(e0["mid"], e1["mid"]) and torch.equal(e0["side"], e1["side"])
+    assert not torch.equal(l0, l1) and bool(((l1 >= -1.0001) & (l1 <= 1.0001)).all())
+    # expectation: cos(mask * e, t) ~ sqrt(1 - p) cos(e, t) for a random mask over 512 dims
+    ls = torch.stack([ev.evaluate(W, dropout=0.5)[0] for _ in range(24)]).mean(0)
+    np.testing.assert_allclose(ls.cpu().numpy(), np.sqrt(0.5) * l0.cpu().numpy(), atol=0.06)

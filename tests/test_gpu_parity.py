@@ -390,3 +390,21 @@ def test_full_chain_losses_vs_oracle(dev):
     for k in ("mid", "side"):
         rel = (embeds[k].cpu() - e_ref[k]).abs().max() / e_ref[k].abs().max()
         assert rel < 1e-4, f"{k} embeddings: {rel:.3e}"
+
+
+def test_process_audio_normalize_stages_vs_oracle(dev):
+    """process_audio(normalize_stages=True), style_transfer.py:106-107: joint peak normalisation after
+    every plugin.  Mono input through the run_optim 'basic' chain: the first three stages are mono
+    inside a stereo result buffer (strided peak scan), then the delay up-mixes."""
+    from st_ito.style_transfer import process_audio
+    op, pp = _plugins_pair(["ParametricEQ", "Compressor", "Distortion", "Delay", "Reverb"])
+    rng = np.random.default_rng(12)
+    for chs, n in ((1, 30000), (2, 24001)):
+        x = O.synth_audio(30 + chs, chs, n).numpy()
+        w = rng.random(31)
+        ref = O.process_audio(x.copy(), w, SR, op, normalize_stages=True)
+        got = process_audio(x.copy(), w, SR, pp, normalize_stages=True)
+        plain = process_audio(x.copy(), w, SR, pp)
+        assert got.shape == ref.shape == (2, n)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        assert np.abs(got - plain).max() > 1e-3  # the compressor / distortion see a different level: it is not a no-op
