@@ -1003,7 +1003,7 @@ extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, i
     if (pool && (H < 2 || W < 2)) return 0;
     if (algo == STITO_CONV_WINOGRAD) return wino_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (cin == 1) return (!pool && 256 % (cout / 4) == 0) ? 1 : 0;
-    return (cin % CK == 0 && cout % 64 == 0) ? 1 : 0;
+    return (cin % 8 == 0 && cout % 64 == 0) ? 1 : 0;  // channel-blocked activations: 8 channels per block
 }
 
 extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
@@ -1011,7 +1011,7 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
                                      int pool, int algo, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
-    if (cin % CK != 0) {
+    if (cin % 8 != 0) {
         STITO_REQUIRE(cin == 1 && !pool, STITO_E_UNSUPPORTED, "conv: cin=%d (only 1 or a multiple of 8)", cin);
         return conv_first(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cout, st);
     }
