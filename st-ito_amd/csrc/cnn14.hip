@@ -334,17 +334,17 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
     const int m_blk = blockIdx.x / n_tiles;
     const int n0 = (blockIdx.x % n_tiles) * 64;
     const int cb = m_blk % g.n_col_blocks;
-    const int64_t rb = m_blk / g.n_col_blocks;
-    const int64_t vtr0 = rb * TTH;
+    const int rb = m_blk / g.n_col_blocks;
+    const int vtr0 = rb * TTH;  // virtual tile row; S*TR and S*H fit 31 bits (host check): 32-bit divisions only
     const int tc0 = cb * TTW;
     const int n_chunks = g.Cin / WK;
 
     // LDS map (floats): [0, 2*BUF) U/V double buffer | patch[2] (raw halo patch, LDS-DMA) | zero row
     constexpr int PWC = 2 * TTW + 2;                 // patch columns
-    const int pfl = g.pa_i * 256 + 256;              // floats per patch buffer: pixels + a row of zeros
+    const int pfl = g.pa_i * 256 + 512;              // floats per patch buffer: pixels + a row of zeros + trash row
     float *patch0 = smem + 2 * BUF;                  // (the zero row is what out-of-stream rows read)
     // input virtual row (s*H + h) of patch row 0: one above the first tile row's centre rows
-    const int64_t iv_lo = (vtr0 / g.TR) * g.H + 2 * (vtr0 % g.TR) - 1;
+    const int iv_lo = (vtr0 / g.TR) * g.H + 2 * (vtr0 % g.TR) - 1;
 
     if (wv >= 8) {
         // =============================== producer waves ===============================
@@ -369,16 +369,17 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         const int64_t plane_f4 = (int64_t)g.H * g.W * 2;  // float4 per 8-channel plane of one stream
         const f32x4 *p_src[NPL];
         bool p_val[NPL];
+        int p_dst[NPL];  // float offset in a patch buffer; lanes without a pixel write the trash row
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int q = ptid + 256 * j, pix = q >> 1;
             const int pr = pix / PWC, pc = pix % PWC;
-            const int64_t iv = iv_lo + pr;
+            const int iv = iv_lo + pr;
             const int w = 2 * tc0 - 1 + pc;
-            p_val[j] = q < npix2 && iv >= 0 && iv < (int64_t)g.S * g.H && w >= 0 && w < g.W;
+            p_val[j] = q < npix2 && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
             p_src[j] = (const f32x4 *)(in + (p_val[j] ? act_off(iv / g.H, 0, (int)(iv % g.H), w, g.Cin, g.H, g.W) : 0) + (q & 1) * 4);
+            p_dst[j] = p_val[j] ? q * 4 : g.pa_i * 256 + 256 + lane * 4;
         }
-        for (int i = ptid; i < 2 * pfl; i += 256) patch0[i] = 0.0f;  // patch buffers + their zero rows
         // two register sets, each loaded two chunk periods before it is written to LDS (HBM latency under
         // this load is ~2.5 us, longer than one period); native vectors: HIP's float4 struct arrays
         // are not promoted out of scratch across barriers
@@ -398,21 +399,28 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
     }
 #define WINO_WRITE_P(rp, PBUF)                                                                      \
     {                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < NPL; ++j)                                              \
-            if (p_val[j]) *(f32x4 *)((PBUF) + (ptid + 256 * j) * 4) = rp[j];                         \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) *(f32x4 *)((PBUF) + p_dst[j]) = rp[j];       \
     }
-// one producer iteration: start the U(chunk+1) copy, write the patch set loaded two periods ago
-// (patch(chunk+2)), refill it with patch(chunk+4), then transform patch(chunk+1) -> V(chunk+1)
+// one producer iteration: write the patch set loaded two periods ago (patch(chunk+2)), start the
+// U(chunk+1) copy, refill the set with patch(chunk+4), then transform patch(chunk+1) -> V(chunk+1).
+// The LDS-DMA copies are inline asm the compiler does not count, so any vmcnt(n) it inserts after
+// them is too small by their number and drains them (a full L2 round trip in the middle of every
+// chunk).  It inserts such waits before a ds_write of loaded registers and before reloading
+// registers whose previous load it has not seen waited for -- which is why the patch writes are
+// unconditional (lanes without a pixel write a trash slot): every load is consumed before the copies
+// are issued, nothing after them waits, and at the top of the next iteration the NPL patch loads
+// issued after the copies may stay in flight: vmcnt(NPL).
 #define WINO_PRODUCE(rp)                                                                            \
     {                                                                                               \
         const int cur = (chunk & 1) * BUF;                                                           \
         WINO_T(0)                                                                                    \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own U(chunk) copies landed */            \
+        if (chunk == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* U(0) landed (2 sets younger) */ \
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            /* U(chunk) landed */       \
         __syncthreads(); /* X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free */    \
         WINO_T(1)                                                                                    \
         if (chunk + 1 < n_chunks) {                                                                  \
-            WINO_COPY_U(chunk + 1, BUF - cur)                                                        \
             WINO_WRITE_P(rp, patch0 + (chunk & 1) * pfl)                                             \
+            WINO_COPY_U(chunk + 1, BUF - cur)                                                        \
             WINO_T(2)                                                                                \
             WINO_LOAD_P(rp, chunk + 4)                                                               \
             WINO_T(3)                                                                                \
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             WINO_T(4)                                                                                \
         }                                                                                            \
     }
+    static_assert(NPL == 4, "the vmcnt immediates of WINO_PRODUCE assume 4 patch loads per set");
 
         // ---- transform items: thread = (tile, channel quad, row xi of B^T d B), two tiles per thread ----
         const int xi = ptid & 3, p_quad = (ptid >> 2) & 1;
@@ -429,11 +438,11 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int tile = (ptid >> 3) + 32 * it;
-            const int64_t vtr = vtr0 + tile / TTW;
+            const int vtr = vtr0 + tile / TTW;
             const int tcl = tile % TTW;
-            const int64_t s_ = vtr / g.TR;
-            const int tr = (int)(vtr % g.TR);
-            const int pc0 = (int)(s_ * g.H + 2 * tr - 1 - iv_lo);  // patch row of this tile's row rr = 0
+            const int s_ = vtr / g.TR;
+            const int tr = vtr % g.TR;
+            const int pc0 = s_ * g.H + 2 * tr - 1 - iv_lo;  // patch row of this tile's row rr = 0
             const int ha = 2 * tr - 1 + ra, hb = 2 * tr - 1 + rb;
             const int zoff = g.pa_i * 256;
             rowA[it] = ((vtr < g.VTR && ha >= 0 && ha < g.H) ? ((pc0 + ra) * PWC + 2 * tcl) * 8 : zoff) + p_quad * 4;
@@ -458,10 +467,11 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         };
 
         // patch(k) lives in patch buffer k & 1; U(k), V(k) in U/V buffer k & 1.
+        WINO_COPY_U(0, 0)                    // oldest in the queue: the waits below cover it without over-waiting
         WINO_LOAD_P(rpA, 0)
         WINO_LOAD_P(rpB, 1)
+        for (int i = ptid; i < 2 * pfl; i += 256) patch0[i] = 0.0f;  // patch buffers + their zero rows, under the loads
         __syncthreads();                     // B0: zero fill of the patch buffers complete
-        WINO_COPY_U(0, 0)
         WINO_WRITE_P(rpA, patch0)
         WINO_WRITE_P(rpB, patch0 + pfl)
         WINO_LOAD_P(rpA, 2)                  // set A: patch(2) -> written at chunk 0
@@ -578,11 +588,11 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             y[3] = (t1[1] - t1[2]) - t1[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(y[e], sc, sh), 0.0f);
-            const int64_t vtr = vtr0 + tl / TTW;
+            const int vtr = vtr0 + tl / TTW;
             const int tc = tc0 + tl % TTW;
             if (vtr < g.VTR && tc < g.TC) {
-                const int64_t s = vtr / g.TR;
-                const int tr = (int)(vtr % g.TR);
+                const int s = vtr / g.TR;
+                const int tr = vtr % g.TR;
                 if (POOL) {
                     out[act_off(s, co, tr, tc, g.Cout, g.Ho, g.Wo)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
                 } else {
@@ -896,11 +906,12 @@ static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t 
     const int64_t nrb = (g.VTR + TTH - 1) / TTH;
     blocks = nrb * g.n_col_blocks * (g.Cout / 64);
     if (nrb * g.n_col_blocks >= (1 << 30) || blocks >= (1ll << 31)) return false;
+    if ((int64_t)g.S * g.H >= (1ll << 31) - 64 || g.VTR >= (1ll << 31) - 64) return false;  // the kernel's row arithmetic is 32-bit
     g.n_m_blocks = (int)(nrb * g.n_col_blocks);
     // patch rows: 2 per tile row + 2 halo, plus the rows skipped at every stream boundary a block can straddle
     g.PR = 2 * TTH + 2 + ((TTH - 1) / g.TR + 1) * (g.H - 2 * g.TR > 0 ? g.H - 2 * g.TR : 0);
     g.pa_i = (g.PR * (2 * TTW + 2) * 2 + 63) / 64;
-    lds = ((size_t)2 * (16 * 64 * WK * 2) + 2 * (g.pa_i * 256 + 256)) * sizeof(float);
+    lds = ((size_t)2 * (16 * 64 * WK * 2) + 2 * (g.pa_i * 256 + 512)) * sizeof(float);
     return g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
 }
 
