@@ -20,6 +20,7 @@
 //   distortion/gain: element-wise.
 #include "common.h"
 #include "dsp_view.h"
+#include "comp_env_serial.inc"
 
 namespace stito {
 
@@ -298,15 +299,16 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
 // ------------------------------------------------------------------------------------------------
 // Compressor: juce::dsp::Compressor<float> (peak ballistics + VCA), effects.py:891-897
 // ------------------------------------------------------------------------------------------------
-static constexpr int CE_T = 64;            // samples per tile
+static constexpr int CE_T = 64;            // samples per tile (comp_env_serial.inc is generated for 64)
 static constexpr int CE_LD = 2 * CE_T + 4; // LDS row stride in floats: CE_T (a, r) pairs (16-B aligned rows,
                                            // conflict-free b128 column walks)
-static constexpr int CE_THREADS = 256;     // wave 0: recurrence; waves 1-3: global <-> LDS movers
+static constexpr int CE_THREADS = 768;     // wave 0: recurrence; waves 1-11: global <-> LDS movers (3 mover waves
+                                           // could not keep up with the 3-instruction-per-sample serial wave)
 static constexpr int CE_MOVERS = CE_THREADS - 64;
 static constexpr int CE_SLOTS = 3;         // LDS ring: tile being stored / computed / filled
 static constexpr int CE_COLS = CE_T / 4;   // float4 columns of a tile row
-static constexpr int CE_RSTEP = CE_MOVERS / CE_COLS;             // rows between a mover's items (12)
-static constexpr int CE_NIT = (64 + CE_RSTEP - 1) / CE_RSTEP;    // float4 items per mover per tile (6)
+static constexpr int CE_RSTEP = CE_MOVERS / CE_COLS;             // rows between a mover's items (44)
+static constexpr int CE_NIT = (64 + CE_RSTEP - 1) / CE_RSTEP;    // float4 items per mover per tile (2)
 
 typedef float ce_f2 __attribute__((ext_vector_type(2)));
 typedef float ce_f4 __attribute__((ext_vector_type(4)));
@@ -331,7 +333,9 @@ __device__ __forceinline__ float env_step(ce_f2 c2, float z, ce_f2 ar) {
 // stream l and walks its row of an LDS tile ((a, r) pairs in, z out over the already-consumed head
 // of the same row, 4 samples per pair of ds_read_b128); waves 1-3 are movers: tile j+3 is in flight
 // HBM -> registers (two register sets), tile j+1 is being expanded to (a, r) pairs in the ring,
-// tile j-1 is being stored as |z| -- one barrier per 64 samples.
+// tile j-1 is being stored as |z| -- one barrier per 64 samples.  (Applying the VCA in the movers
+// as well was measured: 8.0 ms fused against 6.5 + 1.1 ms separate -- the gain computer is
+// throughput work for 256 CUs, this kernel only occupies S / 64 of them.)
 template <bool VEC>
 __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
                                                           int C, int64_t L, int S, const double *__restrict__ coef) {
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
     }
 
     // every mover thread serves the same (row, float4 column) items in every tile: column
-    // q = m % 16, rows m / 16 + 12u (CE_MOVERS = 12 * 16).  Pointers are kept in registers as
+    // q = m % 16, rows m / 16 + CE_RSTEP u (CE_MOVERS = CE_RSTEP * 16).  Pointers are kept in registers as
     // global-address-space pointers (the row tables in LDS hold generic pointers).
     typedef ce_f4 f4;
     typedef const __attribute__((address_space(1))) f4 *gsrc_t;
@@ -441,23 +445,12 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
             if (ok[u] && t0_ + 3 < L)                                                          \
                 gdst[u][t0_ >> 2] = (f4){fabsf(vst[u].x), fabsf(vst[u].y), fabsf(vst[u].z), fabsf(vst[u].w)}; \
     }
+    // the serial wave's tile: generated inline asm (tools/gen/gen_env_asm.py), 3.1 instructions per
+    // sample instead of the 4.25 hipcc needs for the same arithmetic (see comp_env_serial.inc)
     auto serial_tile = [&](int64_t k) {
         float *row = ring + (int)(k % CE_SLOTS) * 64 * CE_LD + tid * CE_LD;
-        f4 n0 = *(const f4 *)row, n1 = *(const f4 *)(row + 4);
-#pragma unroll
-        for (int g = 0; g < CE_T / 4; ++g) {  // the next group's pairs are read under this group's chain
-            const f4 q0 = n0, q1 = n1;
-            if (g + 1 < CE_T / 4) {
-                n0 = *(const f4 *)(row + 8 * (g + 1));
-                n1 = *(const f4 *)(row + 8 * (g + 1) + 4);
-            }
-            f4 e;
-            e.x = z = env_step(c2, z, (ce_f2){q0.x, q0.y});
-            e.y = z = env_step(c2, z, (ce_f2){q0.z, q0.w});
-            e.z = z = env_step(c2, z, (ce_f2){q1.x, q1.y});
-            e.w = z = env_step(c2, z, (ce_f2){q1.z, q1.w});
-            *(f4 *)(row + 4 * g) = e;  // floats [4g, 4g+4) held pairs 2g, 2g+1: consumed (this group or earlier)
-        }
+        const unsigned row_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)row;
+        STITO_COMP_ENV_SERIAL_TILE(z, c2, row_addr);
     };
 
     if (tid >= 64) {  // prologue: tiles 0, 1 -> registers; tile 0 -> ring; tile 2 -> registers
