@@ -213,3 +213,26 @@ def test_evaluate_dropout(dev):
     # expectation: cos(mask * e, t) ~ sqrt(1 - p) cos(e, t) for a random mask over 512 dims
     ls = torch.stack([ev.evaluate(W, dropout=0.5)[0] for _ in range(24)]).mean(0)
     np.testing.assert_allclose(ls.cpu().numpy(), np.sqrt(0.5) * l0.cpu().numpy(), atol=0.06)
+
+
+def test_eval_pst_harness_synthetic(dev, tmp_path):
+    """The ES arm of the PST benchmark harness (scripts/eval/eval_pst.py) on synthetic pairs: sequential
+    and batched (configs[2]) runs give the same numbers; outputs are written at -22 LUFS."""
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import eval_pst
+    from st_ito.audio_io import load_wav
+    from st_ito.loudness import integrated_loudness
+    from st_ito.utils import make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    pairs = eval_pst.synthetic_pairs(2, 2.0, eval_pst.get_plugins("mastering-pb"))
+    kw = dict(max_iters=3, popsize=6, random_crop=False, seed=5, tag="mastering-pb")
+    r_seq = eval_pst.run_pst_benchmark(pairs, eval_pst.get_plugins("mastering-pb"), pm, str(tmp_path / "seq"), **kw)
+    r_bat = eval_pst.run_pst_benchmark(pairs, eval_pst.get_plugins("mastering-pb"), pm, str(tmp_path / "bat"), batched=True, **kw)
+    es = "style-es (param-panns)"
+    assert r_seq[es]["style_features"] == r_bat[es]["style_features"] and len(r_seq[es]["style_features"]) == 2
+    assert r_seq["input"]["style_features"] == r_bat["input"]["style_features"]
+    assert all(-1.0 <= v <= 1.0 for v in r_seq[es]["style_features"])
+    for f in ("00_style-es_mastering-pb.wav", "01_input_mastering-pb.wav", "00_target_mastering-pb.wav"):
+        y, sr = load_wav(str(tmp_path / "seq" / f))
+        assert sr == SR and y.shape[0] == 2 and abs(integrated_loudness(y.numpy().T, sr) - (-22.0)) < 0.1
+    assert (tmp_path / "seq" / "00_style-es_mastering-pb.json").exists()

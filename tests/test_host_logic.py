@@ -265,3 +265,38 @@ def test_audio_io_roundtrip(tmp_path):
     assert sr == 48000 and torch.equal(x, y)
     z = resample(torch.sin(torch.arange(4410) * 0.05)[None], 44100, 48000)
     assert z.shape == (1, 4800)
+
+
+def test_bs1770_loudness_known_answers():
+    """st_ito.loudness (pyloudnorm restatement used by the eval_pst harness): BS.1770 reference points."""
+    from st_ito.loudness import integrated_loudness, normalize_loudness
+    sr = 48000
+    t = np.arange(5 * sr) / sr
+    s = np.sin(2 * np.pi * 997 * t)
+    assert abs(integrated_loudness(s, sr) - (-3.01)) < 0.1              # 0 dBFS 997 Hz sine, one channel
+    assert abs(integrated_loudness(np.stack([s, s], 1), sr) - 0.0) < 0.1  # the same in both front channels: +3.01 LU
+    assert abs(integrated_loudness(0.1 * s, sr) - (-23.01)) < 0.1       # -20 dB
+    assert integrated_loudness(np.zeros(sr), sr) == -np.inf
+    # gating: 4 s of signal + 6 s of near silence measures like the signal alone
+    gated = np.concatenate([0.1 * s[: 4 * sr], 1e-5 * s[: 4 * sr], np.zeros(2 * sr)])
+    assert abs(integrated_loudness(gated, sr) - integrated_loudness(0.1 * s[: 4 * sr], sr)) < 0.3
+    y, lufs = normalize_loudness(torch.from_numpy(np.stack([0.1 * s, 0.1 * s]).astype(np.float32)), sr, -22.0)
+    assert abs(integrated_loudness(y.numpy().T, sr) - (-22.0)) < 0.05 and abs(lufs - (-20.0)) < 0.1
+    with pytest.raises(ValueError):
+        integrated_loudness(np.zeros(100), sr)
+
+
+def test_eval_pst_chain_catalogue():
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import importlib
+    ep = importlib.import_module("eval_pst")
+    from st_ito.style_transfer import load_plugins
+    want = {"general-pb": (["Distortion", "ParametricEQ", "Compressor", "Delay", "Reverb"], 31 + 5),
+            "mastering-pb": (["ParametricEQ", "Compressor", "Reverb"], 26 + 3),
+            "vocals-pb": (["ParametricEQ", "Compressor", "Distortion", "Delay", "Reverb"], 31 + 5),
+            "guitar-pb": (["Compressor", "ParametricEQ", "Distortion", "Reverb"], 28 + 4)}
+    for chain, (names, ndim) in want.items():
+        pl, n, init = load_plugins(ep.get_plugins(chain))
+        assert list(pl) == names and n == ndim == len(init)
+    with pytest.raises(ValueError):
+        ep.get_plugins("general-vst")
