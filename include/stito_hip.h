@@ -212,6 +212,25 @@ int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const 
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
 
+/* ---- hand-crafted features: st_ito/features.py (alternative metrics of the evaluation harness) ---- */
+/* compute_rms_energy (features.py:235-245) and compute_crest_factor (248-264) of (n_items, channels, n) audio
+ * -> rms_dev, crest_dev (n_items, channels). */
+int stito_rms_crest(const float *audio_dev, int n_items, int channels, int64_t n_samples, float *rms_dev,
+                    float *crest_dev, void *stream);
+/* compute_barkspectrum (features.py:166-232).  mode 0 mono / 1 stereo / 2 mid-side; fft_size a power of two
+ * <= 32768 (hop fft_size/4, rectangular window, centred, reflect pad); twiddle_dev: fft_size/2 complex
+ * exp(-2 pi i k / fft_size); fb_dev (n_bands, fft_size/2 + 1): barkscale_fbanks transposed;
+ * out_dev (n_items, n_signals * n_bands), L2-normalised rows. */
+int stito_barkspectrum(const float *audio_dev, int n_items, int channels, int64_t n_samples, int mode, int fft_size,
+                       const float *twiddle_dev, const float *fb_dev, int n_bands, float *out_dev, void *stream);
+/* compute_spectral_centroid (features.py:302-333): Hann 2048 / hop 1024 magnitude STFT, centroid per frame,
+ * nan_to_num, adaptive average pooling to 10, / Nyquist -> out_dev (n_items, channels * 10).
+ * window_dev: 2048 floats; twiddle_dev: 1024 complex exp(-2 pi i k / 2048). */
+size_t stito_spectral_centroid_workspace_bytes(int n_items, int channels, int64_t n_samples);
+int stito_spectral_centroid(const float *audio_dev, int n_items, int channels, int64_t n_samples, double sample_rate,
+                            const float *window_dev, const float *twiddle_dev, float *out_dev, void *workspace_dev,
+                            size_t workspace_bytes, void *stream);
+
 /* ---- embeddings -> fitness ----------------------------------------------------------------- */
 /* In place: NaN scrub (utils.py:491-497), L2-normalise mid/side (n_cand, E).  If target_mid_dev
  * is not NULL also writes loss_dev (n_cand) = mean(-cos(mid, target_mid), -cos(side, target_side))

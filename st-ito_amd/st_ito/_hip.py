@@ -83,6 +83,11 @@ SIGNATURES = {
     "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),
+    "stito_rms_crest": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "stito_barkspectrum": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "stito_spectral_centroid_workspace_bytes": (c_size_t, [c_int, c_int, c_int64]),
+    "stito_spectral_centroid": (c_int, [c_void_p, c_int, c_int, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
     "stito_embed_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -126,3 +126,29 @@ def make_synthetic_param_model(seed: int = 0, input_norm: str = "minmax", embed_
     if torch.cuda.is_available():
         model.cuda()
     return model
+
+
+# ------------------- MIR feature extractor (reference utils.py:65-98) ---------------- #
+def load_mir_feature_extractor(use_gpu: bool = False):
+    class Model:
+        def __init__(self) -> None:
+            self.embed_dim = 49
+
+    return Model()
+
+
+def get_mir_feature_embeds(x: torch.Tensor, model, sample_rate: float, **kwargs):
+    """Dictionary of hand-crafted features computed on the GPU (st_ito.features).  The reference
+    (utils.py:76-98) calls compute_barkspectrum(x, sample_rate, mode="mono"), which binds the sample
+    rate to `fft_size` (a 48 000-point FFT at the default 44.1 kHz filterbank); here the arguments
+    are bound as its evaluation wrappers bind them (eval_pst.py:61-69): fft_size 32768 at `sample_rate`."""
+    from . import features as F
+
+    return {
+        "lufs": F.compute_lufs(x, sample_rate),
+        "rms": F.compute_rms_energy(x),
+        "crest": F.compute_crest_factor(x),
+        "barkspectrum": F.compute_barkspectrum(x, sample_rate=sample_rate, mode="mono"),
+        "spectral_centroid": F.compute_spectral_centroid(x, sample_rate),
+    }
+

@@ -19,6 +19,8 @@ orchestration, not the front-end ("parity unpinned" ther
   G5 param_embeds_toy.npz utils.py:444-508 with a deterministic toy model
   G6 cnn14_trunk_*.npz    panns.py:209-281 conv stack (+ this repo's front-end)
   G7 evaluate_*.npz       style_transfer.py:399-692 run_es -> evaluate losses (fake `cma`)
+  G8 features.npz         features.py:166-264 bark spectrum (3 modes, 2 FFT sizes), RMS, crest factor
+                          on O.synth_audio(seed, 2, n) inputs (the fixture stores the recipe, not the audio)
 """
 import os
 import sys
@@ -249,8 +251,22 @@ def g7():
              fopt=np.array(res["fopt"]), output_audio=res["output_audio"].numpy(), seed=np.array(0))
 
 
+def g8():
+    import st_ito.features as RF  # reference (torchaudio / pyloudnorm are stand-ins: centroid and LUFS are not pinned)
+    seeds, n = [201, 202, 203], 70000
+    x = torch.stack([O.synth_audio(sd, 2, n) * (0.3 + 0.3 * i) for i, sd in enumerate(seeds)])
+    out = dict(seeds=np.array(seeds), n=np.array(n), scales=np.array([0.3 + 0.3 * i for i in range(3)]))
+    for fft in (32768, 4096):
+        for mode in ("mono", "stereo", "mid-side"):
+            out[f"bark_{fft}_{mode.replace('-', '')}"] = RF.compute_barkspectrum(x, fft_size=fft, sample_rate=SR, mode=mode).numpy()
+    out["bark_fb_32768"] = RF.barkscale_fbanks(32768 // 2 + 1, 20.0, 20000.0, 24, SR).numpy().astype(np.float32)[::64]  # every 64th row
+    out["rms"] = RF.compute_rms_energy(x).numpy()
+    out["crest"] = RF.compute_crest_factor(x).numpy()
+    save("features.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8"]
     for name in which:
-        {"g1": g1, "g2": g2, "g3": g3_g4, "g5": g5, "g6": g6, "g7": g7}[name]()
+        {"g1": g1, "g2": g2, "g3": g3_g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8}[name]()

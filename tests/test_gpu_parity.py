@@ -408,3 +408,35 @@ def test_process_audio_normalize_stages_vs_oracle(dev):
         assert got.shape == ref.shape == (2, n)
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
         assert np.abs(got - plain).max() > 1e-3  # the compressor / distortion see a different level: it is not a no-op
+
+
+def test_features_vs_reference_golden_and_oracle(dev, golden_dir):
+    """st_ito/features.py on the GPU against the vectors produced by the reference's own code (G8:
+    bark spectrum in three modes and two FFT sizes, RMS, crest factor) and against the oracle
+    (spectral centroid: torchaudio restatement, unpinned; LUFS: host)."""
+    from st_ito import features as PF
+    g = np.load(os.path.join(golden_dir, "features.npz"))
+    x = torch.stack([O.synth_audio(int(sd), 2, int(g["n"])) * float(sc) for sd, sc in zip(g["seeds"], g["scales"])])
+    for fft in (32768, 4096):
+        for mode in ("mono", "stereo", "mid-side"):
+            got = PF.compute_barkspectrum(x, fft_size=fft, sample_rate=SR, mode=mode)
+            assert got.device == x.device and got.shape == (3, 24 if mode == "mono" else 48)
+            np.testing.assert_allclose(got.numpy(), g[f"bark_{fft}_{mode.replace('-', '')}"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(PF.compute_rms_energy(x).numpy(), g["rms"], rtol=2e-6)
+    np.testing.assert_allclose(PF.compute_crest_factor(x).numpy(), g["crest"], rtol=0, atol=2e-5)
+    xm = x[:, :1]
+    np.testing.assert_allclose(PF.compute_barkspectrum(xm, sample_rate=SR, mode="mono").numpy(),
+                               O.compute_barkspectrum(xm, sample_rate=SR, mode="mono").numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(PF.compute_rms_energy(xm).numpy(), O.compute_rms_energy(xm).numpy(), rtol=2e-6)
+    np.testing.assert_allclose(PF.compute_crest_factor(xm).numpy(), O.compute_crest_factor(xm).numpy(), rtol=0, atol=2e-5)
+    for xx in (x, xm, torch.cat([x[:1], torch.zeros(1, 2, x.shape[-1])])):  # the last one has an all-silent item (NaN frames)
+        np.testing.assert_allclose(PF.compute_spectral_centroid(xx, SR).numpy(), O.compute_spectral_centroid(xx, SR).numpy(),
+                                   rtol=0, atol=2e-5)
+    lufs = PF.compute_lufs(x, SR)
+    assert lufs.shape == (3, 1) and bool(((lufs > -30) & (lufs < 5)).all())
+    with pytest.raises(NotImplementedError):
+        PF.compute_barkspectrum(x, 48000, mode="mono")   # the reference's positional-argument slip (utils.py:88)
+    from st_ito.utils import get_mir_feature_embeds, load_mir_feature_extractor
+    feats = get_mir_feature_embeds(x, load_mir_feature_extractor(), SR)
+    assert {k: tuple(v.shape) for k, v in feats.items()} == {"lufs": (3, 1), "rms": (3, 2), "crest": (3, 2),
+                                                             "barkspectrum": (3, 24), "spectral_centroid": (3, 20)}

@@ -283,3 +283,22 @@ def test_noise_shaped_reverb_known_answers():
     # the product's host-side bank builder is the same restatement
     from st_ito import effects as E
     assert torch.equal(E.make_noise_bank(3000, 127, SR, seed=1), bank)
+
+
+def test_features_oracle_vs_reference_golden(golden_dir):
+    """features.py restatement against vectors produced by the reference's own code (G8)."""
+    g = np.load(os.path.join(golden_dir, "features.npz"))
+    x = torch.stack([O.synth_audio(int(sd), 2, int(g["n"])) * float(sc) for sd, sc in zip(g["seeds"], g["scales"])])
+    for fft in (32768, 4096):
+        for mode in ("mono", "stereo", "mid-side"):
+            got = O.compute_barkspectrum(x, fft_size=fft, sample_rate=SR, mode=mode).numpy()
+            np.testing.assert_allclose(got, g[f"bark_{fft}_{mode.replace('-', '')}"], rtol=0, atol=2e-6)
+    fb = O.barkscale_fbanks(32768 // 2 + 1, 20.0, 20000.0, 24, SR).numpy()
+    np.testing.assert_array_equal(fb[::64], g["bark_fb_32768"])
+    np.testing.assert_array_equal(O.compute_rms_energy(x).numpy(), g["rms"])
+    np.testing.assert_array_equal(O.compute_crest_factor(x).numpy(), g["crest"])
+    # spectral centroid (torchaudio restatement, unpinned): known answer -- a pure tone sits at its frequency
+    t = torch.arange(48000) / 48000.0
+    tone = torch.sin(2 * np.pi * 3000.0 * t)[None, None].repeat(1, 2, 1)
+    sc = O.compute_spectral_centroid(tone, 48000)
+    assert sc.shape == (1, 20) and np.allclose(sc.numpy()[0, 2:8] * 24000, 3000.0, rtol=2e-2)
