@@ -440,3 +440,29 @@ def test_features_vs_reference_golden_and_oracle(dev, golden_dir):
     feats = get_mir_feature_embeds(x, load_mir_feature_extractor(), SR)
     assert {k: tuple(v.shape) for k, v in feats.items()} == {"lufs": (3, 1), "rms": (3, 2), "crest": (3, 2),
                                                              "barkspectrum": (3, 24), "spectral_centroid": (3, 20)}
+
+
+def test_dsp_module_random_effects(dev):
+    """st_ito/dsp.py mirror: random-parameter distortion and noise reverb on the GPU, loudness on the host."""
+    from st_ito import dsp as PD
+    from st_ito.loudness import integrated_loudness
+    x = O.synth_audio(81, 2, 60000)
+    np.random.seed(3)
+    y, drive = PD.apply_random_simple_distortion(x, SR)
+    assert 0 <= drive <= 32 and y.shape == x.shape
+    np.testing.assert_allclose(y.numpy(), np.tanh(x.numpy() * np.float32(10 ** (np.float32(drive) / 20))), rtol=0, atol=2e-6)
+    np.random.seed(4)
+    y, mix = PD.apply_random_reverb(x, SR)
+    rv = O.OracleNoiseShapedReverb(sample_rate=SR, seed=0)
+    for b, d in enumerate([0.6, 0.4, 0.4, 0.5, 0.2, 0.3, 0.3, 0.2, 0.1, 0.1, 0.2, 0.1]):
+        rv.parameters[f"band{b}_decay"].set_value(float(np.float32(d)))
+        rv.parameters[f"band{b}_gain"].set_value(1.0)
+    rv.parameters["mix"].set_value(float(np.float32(mix)))
+    ref = rv.process(x.numpy(), SR)
+    assert np.abs(y.numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    yb, _ = PD.apply_random_reverb(x[None], SR)
+    assert yb.shape == (1, 2, 60000)
+    z = PD.normalize_loudness(x, SR, -23.0)
+    assert abs(integrated_loudness(z.numpy().T, SR) - (-23.0)) < 0.05
+    with pytest.raises(NotImplementedError):
+        PD.apply_random_compressor(x, SR)
