@@ -287,16 +287,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
 // comparable to the direct form (all transform coefficients are 0, +-1, +-1/2).
 //
 // Workgroup = 64 tiles x 64 output channels x 16 positions, 12 waves with two roles:
-//   * 8 consumer waves: wave w owns positions {2w, 2w+1} for the WHOLE 64 x 64 tile (2 x 2 x 2 MFMA
-//     32x32 blocks = 128 accumulator VGPRs); per 8-channel chunk it issues 8 ds_read_b128 and 32
-//     MFMAs and nothing else, so the matrix pipes never wait for VALU work;
+//   * 8 consumer waves: wave w owns one ROW of the 4 x 4 Winograd domain (positions 4 xi + nu, xi = w / 2)
+//     for all 64 tiles and half (w % 2) of the 64 channels (4 x 2 MFMA 32x32 blocks = 128 accumulator
+//     VGPRs); per 8-channel chunk it issues 12 ds_read_b128 and 32 MFMAs and nothing else, so the
+//     matrix pipes never wait for VALU work;
 //   * 4 producer waves: copy U (pre-transformed weights, [cin/8][16][cout][8]) by LDS-DMA, load
 //     each tile's 4x4 patch straight from the NHWC activations (bounds-checked = zero padding,
 //     stream boundaries included), form B^T d B and write V for the NEXT chunk (double buffered).
 //   One barrier per chunk; 3 waves per SIMD (2 consumers + 1 producer), 128 KB LDS.
-// The 16 positions of one output meet only in the epilogue: accumulators are exchanged through LDS
-// (the whole 128 KB, half of the output channels at a time), then A^T M A, BN, ReLU and the 2x2
-// average pool (one Winograd tile == one pooling window) are applied per (tile, channel).
+// The 16 positions of one output meet only in the epilogue: a wave reduces its row over nu in registers
+// (column half of A^T M A), the 4 x 2 partial results per (tile, channel) are exchanged through LDS
+// in one pass, then the row half, BN, ReLU and the 2x2 average pool (one Winograd tile == one pooling
+// window) are applied per (tile, channel).
 // ------------------------------------------------------------------------------------------------
 struct WinoGeom {
     int S, H, W, Cin, Cout;
@@ -491,32 +493,33 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
 #undef WINO_LOAD_P
 #undef WINO_WRITE_P
         // keep the barrier count of the consumers' epilogue
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) __syncthreads();
+        __syncthreads();
+        __syncthreads();
         return;
     }
 
     // =============================== consumer waves ===============================
+    // wave w owns one ROW of the Winograd domain, positions p = 4 xi + nu (xi = w / 2, nu = 0..3), for
+    // all 64 tiles and one half (w % 2) of the 64 output channels: 4 x 2 MFMA 32x32 blocks = 128
+    // accumulator VGPRs.  Holding a complete row lets the wave apply the column half of A^T M A in
+    // registers, so only 2 instead of 4 values per (row, tile, channel) go through the LDS exchange.
     const int half = lane >> 5, l31 = lane & 31;
-    int a_off[2][2], b_off[2][2];  // [pp][mb / nb]
+    const int xi = wv >> 1, nh = wv & 1;
+    int a_off[4][2], b_off[4];  // [nu][mb], [nu]
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int p = 2 * wv + pp;
+    for (int nu = 0; nu < 4; ++nu) {
+        const int p = 4 * xi + nu;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            a_off[pp][q] = U_FLOATS + p * 64 * WK + ((q * 32 + l31 + (p >> 2)) & 63) * WK + half * 4;
-            b_off[pp][q] = p * 64 * WK + (q * 32 + l31) * WK + half * 4;
-        }
+        for (int q = 0; q < 2; ++q) a_off[nu][q] = U_FLOATS + p * 64 * WK + ((q * 32 + l31 + xi) & 63) * WK + half * 4;
+        b_off[nu] = p * 64 * WK + (nh * 32 + l31) * WK + half * 4;
     }
-    f32x16 acc[2][2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+    for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[pp][mb][nb][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.0f;
 
     __syncthreads();  // B0 (producers: zero fill)
     __syncthreads();  // B1 (producers: first patch landed)
@@ -526,81 +529,73 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         __syncthreads();
         WINO_T(1)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            float4 av[2], bv[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                av[q] = *(const float4 *)(sb + a_off[pp][q]);
-                bv[q] = *(const float4 *)(sb + b_off[pp][q]);
-            }
+        for (int nu = 0; nu < 4; ++nu) {
+            const float4 av0 = *(const float4 *)(sb + a_off[nu][0]);
+            const float4 av1 = *(const float4 *)(sb + a_off[nu][1]);
+            const float4 bv = *(const float4 *)(sb + b_off[nu]);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const float a0 = kk == 0 ? av[0].x : kk == 1 ? av[0].y : kk == 2 ? av[0].z : av[0].w;
-                const float a1 = kk == 0 ? av[1].x : kk == 1 ? av[1].y : kk == 2 ? av[1].z : av[1].w;
-                const float b0 = kk == 0 ? bv[0].x : kk == 1 ? bv[0].y : kk == 2 ? bv[0].z : bv[0].w;
-                const float b1 = kk == 0 ? bv[1].x : kk == 1 ? bv[1].y : kk == 2 ? bv[1].z : bv[1].w;
-                acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[pp][0][0], 0, 0, 0);
-                acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[pp][0][1], 0, 0, 0);
-                acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[pp][1][0], 0, 0, 0);
-                acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pp][1][1], 0, 0, 0);
+                const float a0 = kk == 0 ? av0.x : kk == 1 ? av0.y : kk == 2 ? av0.z : av0.w;
+                const float a1 = kk == 0 ? av1.x : kk == 1 ? av1.y : kk == 2 ? av1.z : av1.w;
+                const float b0 = kk == 0 ? bv.x : kk == 1 ? bv.y : kk == 2 ? bv.z : bv.w;
+                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[nu][0], 0, 0, 0);
+                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[nu][1], 0, 0, 0);
             }
         }
         WINO_T(2)
     }
 
-    // ---- epilogue: exchange positions through LDS (all 128 KB), one half of the channels per pass:
-    // xch[pos][tile 0..63][channel 0..31]; then A^T M A, BN + ReLU (+ pool) per (tile, channel)
+    // ---- epilogue: Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1].  Column half in registers:
+    // c0 = m0 + m1 + m2, c1 = m1 - m2 - m3 over nu; exchange xch[2 xi + j][tile 0..63][channel 0..63]
+    // (8 planes over the U/V double buffer and the first 16 KB of the patch buffers, all idle now);
+    // row half, BN + ReLU (+ pool) per (tile, channel).  Tile stride XT = 72 floats: the two half-waves of
+    // an accumulator register sit 4 tiles apart, 4 * 72 = 32 mod 64 banks -> conflict-free writes.
+    constexpr int XT = 72, XP = 64 * XT;
     float *xch = smem;
-    const int e_co = tid & 31, e_t0 = tid >> 5;  // thread -> channel, tiles e_t0 + 16*k
+    __syncthreads();  // main loop done with the LDS
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        __syncthreads();  // main loop / previous pass done with the LDS
+    for (int mb = 0; mb < 2; ++mb) {
+        float *xp = xch + (2 * xi) * XP + mb * 32 * XT + nh * 32 + l31;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float m0 = acc[0][mb][r], m1 = acc[1][mb][r], m2 = acc[2][mb][r], m3 = acc[3][mb][r];
+            xp[row * XT] = (m0 + m1) + m2;
+            xp[XP + row * XT] = (m1 - m2) - m3;
+        }
+    }
+    __syncthreads();
+    const int e_co = tid & 63, e_t0 = tid >> 6;  // thread -> channel, tiles e_t0 + 8*k
+    const int co = n0 + e_co;
+    const float sc = scale[co], sh = shift[co];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                float *xp = xch + (2 * wv + pp) * 64 * 32 + mb * 32 * 32 + l31;
+    for (int it = 0; it < 8; ++it) {
+        const int tl = e_t0 + 8 * it;  // tile within the block
+        float c0[4], c1[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    xp[row * 32] = acc[pp][mb][nb][r];
-                }
-            }
-        __syncthreads();
-        const int co = n0 + nb * 32 + e_co;
-        const float sc = scale[co], sh = shift[co];
+        for (int x = 0; x < 4; ++x) {
+            c0[x] = xch[(2 * x) * XP + tl * XT + e_co];
+            c1[x] = xch[(2 * x + 1) * XP + tl * XT + e_co];
+        }
+        float y[4];
+        y[0] = (c0[0] + c0[1]) + c0[2];
+        y[1] = (c1[0] + c1[1]) + c1[2];
+        y[2] = (c0[1] - c0[2]) - c0[3];
+        y[3] = (c1[1] - c1[2]) - c1[3];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int tl = e_t0 + 16 * it;  // tile within the block
-            float m[16];
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(y[e], sc, sh), 0.0f);
+        const int vtr = vtr0 + tl / TTW;
+        const int tc = tc0 + tl % TTW;
+        if (vtr < g.VTR && tc < g.TC) {
+            const int s = vtr / g.TR;
+            const int tr = vtr % g.TR;
+            if (POOL) {
+                out[act_off(s, co, tr, tc, g.Cout, g.Ho, g.Wo)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
+            } else {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = xch[p * 64 * 32 + tl * 32 + e_co];
-            float t0[4], t1[4];
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                t0[nu] = (m[nu] + m[4 + nu]) + m[8 + nu];
-                t1[nu] = (m[4 + nu] - m[8 + nu]) - m[12 + nu];
-            }
-            float y[4];
-            y[0] = (t0[0] + t0[1]) + t0[2];
-            y[1] = (t0[1] - t0[2]) - t0[3];
-            y[2] = (t1[0] + t1[1]) + t1[2];
-            y[3] = (t1[1] - t1[2]) - t1[3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(y[e], sc, sh), 0.0f);
-            const int vtr = vtr0 + tl / TTW;
-            const int tc = tc0 + tl % TTW;
-            if (vtr < g.VTR && tc < g.TC) {
-                const int s = vtr / g.TR;
-                const int tr = vtr % g.TR;
-                if (POOL) {
-                    out[act_off(s, co, tr, tc, g.Cout, g.Ho, g.Wo)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int hh = 2 * tr + (e >> 1), ww = 2 * tc + (e & 1);
-                        if (hh < g.H && ww < g.W) out[act_off(s, co, hh, ww, g.Cout, g.H, g.W)] = y[e];
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const int hh = 2 * tr + (e >> 1), ww = 2 * tc + (e & 1);
+                    if (hh < g.H && ww < g.W) out[act_off(s, co, hh, ww, g.Cout, g.H, g.W)] = y[e];
                 }
             }
         }
@@ -912,7 +907,8 @@ static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t 
     g.PR = 2 * TTH + 2 + ((TTH - 1) / g.TR + 1) * (g.H - 2 * g.TR > 0 ? g.H - 2 * g.TR : 0);
     g.pa_i = (g.PR * (2 * TTW + 2) * 2 + 63) / 64;
     lds = ((size_t)2 * (16 * 64 * WK * 2) + 2 * (g.pa_i * 256 + 512)) * sizeof(float);
-    return g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
+    // pa_i >= 8: the epilogue's exchange (8 planes x 64 tiles x 72 floats) spills 16 KB into the patch buffers
+    return g.pa_i >= 8 && g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
 }
 
 template <int TTW, bool POOL>
