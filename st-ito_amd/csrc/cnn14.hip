@@ -309,10 +309,20 @@ struct WinoGeom {
     int PR, pa_i;      // halo patch rows; patch LDS-DMA wave-instructions per chunk
     long long *trace;  // TRACE instantiation only: s_memtime stamps of workgroup 100 (tools/wino_timeline.py)
 };
-// phase stamp: [chunk - 8][wave][slot] for chunks 8..39 of workgroup 100
+// phase stamp: [chunk - 8][wave][slot] for chunks 8..23 of workgroup 100.  Stamps go to a spare 6 KB of
+// LDS and are copied out at the end (a global store per stamp queues behind the LDS-DMA copies).
+// What the trace shows (tools/wino_timeline.py, 58x16 512->512): the consumers finish issuing MFMAs at
+// ~4600 cycles and reach the barrier at ~4850; a producer wave issues its copies by ~600, but the first
+// instruction after them that needs a memory counter completes ~4100 cycles later -- LDS-DMA copies sit
+// in the issuing wave's queue like LDS instructions, so its transform cannot start before they land --
+// and the transform then takes ~950 cycles in the MFMA-free tail: arrival ~5850.  Variants measured and
+// rejected: a dedicated copy wave + 3 transform waves (copies land by ~2600, but the transform, now
+// concurrent with the MFMA stream, gets about one issue slot per MFMA: 4900 cycles for 3 items; 87.2 ms
+// against 83.3); transform before the patch loads (no change); n-tile persistent workgroups with the
+// prologue hidden behind the previous epilogue (epilogue in half the LDS: 90.8 ms).
 #define WINO_T(slot)                                                                       \
-    if (TRACE && blockIdx.x == 100 && chunk >= 8 && chunk < 40 && lane == 0)               \
-        g.trace[((chunk - 8) * 12 + wv) * 8 + (slot)] = __builtin_readcyclecounter();
+    if (TRACE && blockIdx.x == 100 && chunk >= 8 && chunk < 24 && lane == 0)               \
+        tr_lds[((chunk - 8) * 12 + wv) * 8 + (slot)] = (unsigned)__builtin_readcyclecounter();
 
 static constexpr int WK = 8;           // input channels per chunk
 static constexpr int WINO_THREADS = 768;
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
     constexpr int PWC = 2 * TTW + 2;                 // patch columns
     const int pfl = g.pa_i * 256 + 512;              // floats per patch buffer: pixels + a row of zeros + trash row
     float *patch0 = smem + 2 * BUF;                  // (the zero row is what out-of-stream rows read)
+    unsigned *tr_lds = (unsigned *)(patch0 + 2 * pfl);  // TRACE only: 16 chunks x 12 waves x 8 slots
     // input virtual row (s*H + h) of patch row 0: one above the first tile row's centre rows
     const int iv_lo = (vtr0 / g.TR) * g.H + 2 * (vtr0 % g.TR) - 1;
 
@@ -600,6 +611,8 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             }
         }
     }
+    if (TRACE && blockIdx.x == 100)
+        for (int i = tid; i < 16 * 12 * 8; i += 512) g.trace[i] = tr_lds[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -920,6 +933,10 @@ static int launch_wino(const float *in, const float *upk, const float *scale, co
     STITO_REQUIRE((wino_geometry<TTW, POOL>(c, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd): %dx%d map does not fit the LDS-resident halo patch", c.H, c.W);
     g.trace = g_wino_trace;
+    if (g_wino_trace) {
+        lds += 16 * 12 * 8 * sizeof(unsigned);
+        STITO_REQUIRE(lds <= 160 * 1024, STITO_E_UNSUPPORTED, "wino trace: no spare LDS for the stamps at this shape");
+    }
     auto kern = g_wino_trace ? k_conv_wino<TTW, POOL, true> : k_conv_wino<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WINO_THREADS), lds, st, in, upk, scale, shift, out, g);
