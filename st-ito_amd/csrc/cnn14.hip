@@ -315,7 +315,11 @@ struct WinoGeom {
 // ~4600 cycles and reach the barrier at ~4850; a producer wave issues its copies by ~600, but the first
 // instruction after them that needs a memory counter completes ~4100 cycles later -- LDS-DMA copies sit
 // in the issuing wave's queue like LDS instructions, so its transform cannot start before they land --
-// and the transform then takes ~950 cycles in the MFMA-free tail: arrival ~5850.  Variants measured and
+// and the transform then takes ~950 cycles in the MFMA-free tail: arrival ~5850.  Neither fewer patch
+// loads nor fewer transform instructions (packed subtractions: 89 -> 77 vector instructions per
+// iteration) move these numbers: the producers' vector instructions only get issued once the two
+// consumer waves of their SIMD have stopped issuing MFMAs (~4600), whatever their priority, so a chunk
+// costs the MFMA phase plus a serial producer tail.  Variants measured and
 // rejected: a dedicated copy wave + 3 transform waves (copies land by ~2600, but the transform, now
 // concurrent with the MFMA stream, gets about one issue slot per MFMA: 4900 cycles for 3 items; 87.2 ms
 // against 83.3); transform before the patch loads (no change); n-tile persistent workgroups with the
@@ -373,7 +377,9 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         // Halo patch: HBM -> registers -> LDS (two register sets, loaded two periods ahead); pixels
         // outside the map are never written: both patch buffers are zero-filled once.
         constexpr int NU = 8;   // U wave-copies per producer wave per chunk
-        constexpr int NPL = 4;  // float4 of patch per producer thread per chunk (upper bound)
+        // float4 of patch per producer thread per chunk: 2 * PR * PWC float4 over 256 threads; PR <= 2 TTH + 4
+        // (geometry check): TTW 8: 2*20*18 = 720, TTW 4: 2*36*10 = 720, TTW 2: 2*68*6 = 816
+        constexpr int NPL = TTW == 2 ? 4 : 3;
         const int pw = wv - 8;
         const float *u_base = upk + (int64_t)n0 * WK;                       // wave-uniform
         const int64_t u_pos_stride = (int64_t)g.Cout * WK, u_chunk_stride = 16 * u_pos_stride;  // floats
@@ -427,8 +433,13 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
     {                                                                                               \
         const int cur = (chunk & 1) * BUF;                                                           \
         WINO_T(0)                                                                                    \
-        if (chunk == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* U(0) landed (2 sets younger) */ \
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            /* U(chunk) landed */       \
+        if (NPL == 4) {                                                                              \
+            if (chunk == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* U(0) landed (2 sets younger) */ \
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            /* U(chunk) landed */   \
+        } else {                                                                                     \
+            if (chunk == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                    \
+        }                                                                                            \
         __syncthreads(); /* X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free */    \
         WINO_T(1)                                                                                    \
         if (chunk + 1 < n_chunks) {                                                                  \
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             WINO_T(4)                                                                                \
         }                                                                                            \
     }
-    static_assert(NPL == 4, "the vmcnt immediates of WINO_PRODUCE assume 4 patch loads per set");
+    static_assert(NPL == 3 || NPL == 4, "the vmcnt immediates of WINO_PRODUCE are written for 3 or 4 patch loads per set");
 
         // ---- transform items: thread = (tile, channel quad, row xi of B^T d B), two tiles per thread ----
         const int xi = ptid & 3, p_quad = (ptid >> 2) & 1;
@@ -472,10 +483,13 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
                 for (int j = 0; j < 4; ++j)  // native vector arithmetic -> v_pk_fma_f32 / v_pk_add_f32
                     T[j] = *(const f32x4 *)(pbuf + rowA[it] + j * 8) + sgn * *(const f32x4 *)(pbuf + rowB[it] + j * 8);
                 float *vb = smem + v_boff + vdst[it];
-                *(f32x4 *)(vb + 0 * 64 * WK) = T[0] - T[2];
+                // differences as fma(b, -1, a): hipcc has no packed subtract and would split a - b into four
+                // v_sub_f32; a * 1 + (-b) is exact, so the results are bit-identical
+                const f32x4 m1 = (f32x4)(-1.0f);
+                *(f32x4 *)(vb + 0 * 64 * WK) = __builtin_elementwise_fma(T[2], m1, T[0]);
                 *(f32x4 *)(vb + 1 * 64 * WK) = T[1] + T[2];
-                *(f32x4 *)(vb + 2 * 64 * WK) = T[2] - T[1];
-                *(f32x4 *)(vb + 3 * 64 * WK) = T[1] - T[3];
+                *(f32x4 *)(vb + 2 * 64 * WK) = __builtin_elementwise_fma(T[1], m1, T[2]);
+                *(f32x4 *)(vb + 3 * 64 * WK) = __builtin_elementwise_fma(T[3], m1, T[1]);
             }
         };
 
@@ -921,6 +935,7 @@ static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t 
     g.pa_i = (g.PR * (2 * TTW + 2) * 2 + 63) / 64;
     lds = ((size_t)2 * (16 * 64 * WK * 2) + 2 * (g.pa_i * 256 + 512)) * sizeof(float);
     // pa_i >= 8: the epilogue's exchange (8 planes x 64 tiles x 72 floats) spills 16 KB into the patch buffers
+    if (g.PR * (2 * TTW + 2) * 2 > (TTW == 2 ? 4 : 3) * 256) return false;  // NPL patch float4 per producer thread
     return g.pa_i >= 8 && g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
 }
 
