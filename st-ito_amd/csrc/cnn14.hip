@@ -319,7 +319,11 @@ struct WinoGeom {
 // loads nor fewer transform instructions (packed subtractions: 89 -> 77 vector instructions per
 // iteration) move these numbers: the producers' vector instructions only get issued once the two
 // consumer waves of their SIMD have stopped issuing MFMAs (~4600), whatever their priority, so a chunk
-// costs the MFMA phase plus a serial producer tail.  Variants measured and
+// costs the MFMA phase plus a serial producer tail.  Pacing the consumers (s_nop / s_sleep after every
+// MFMA) does unblock the producers -- patch loads issue at ~750 instead of ~4650, and with 256 idle
+// cycles per MFMA a producer is completely done at ~2000 -- but every pacing that leaves the matrix pipe
+// fed (s_nop 3 ... 15) stretches the MFMA phase by more than the tail it removes (88.6-89.8 ms against
+// 83.2).  Variants measured and
 // rejected: a dedicated copy wave + 3 transform waves (copies land by ~2600, but the transform, now
 // concurrent with the MFMA stream, gets about one issue slot per MFMA: 4900 cycles for 3 items; 87.2 ms
 // against 83.3); transform before the patch loads (no change); n-tile persistent workgroups with the
