@@ -323,7 +323,9 @@ struct WinoGeom {
 // MFMA) does unblock the producers -- patch loads issue at ~750 instead of ~4650, and with 256 idle
 // cycles per MFMA a producer is completely done at ~2000 -- but every pacing that leaves the matrix pipe
 // fed (s_nop 3 ... 15) stretches the MFMA phase by more than the tail it removes (88.6-89.8 ms against
-// 83.2).  Variants measured and
+// 83.2).  Issuing the transform's 16 ds_read_b128 right after the barrier shortens the tail (1000 -> 640
+// cycles) but the reads collide with the consumers' operand reads and the MFMA phase grows by as much
+// (84.6 ms).  Variants measured and
 // rejected: a dedicated copy wave + 3 transform waves (copies land by ~2600, but the transform, now
 // concurrent with the MFMA stream, gets about one issue slot per MFMA: 4900 cycles for 3 items; 87.2 ms
 // against 83.3); transform before the patch loads (no change); n-tile persistent workgroups with the
