@@ -68,7 +68,7 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round1_g_conv_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round1_p_conv_pmc_traffic.json")
 
 
 def pmc_traffic_per_launch(n_streams):
@@ -252,7 +252,7 @@ def main():
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic_per_launch(streams_per_launch), "traffic_unit": "HBM bytes per launch (PMC, "
-                "profiles/round1_g_conv_pmc_traffic.json)",
+                "profiles/round1_p_conv_pmc_traffic.json)",
                 "flops_per_launch": fl_step * args.steps / n_l, "avg_launch_ms": round(conv_ms.value / n_l, 4),
                 "launches_timed": conv_launches.value, "n_streams": streams_per_launch,
                 # whole path (DSP + front end + trunk + host) against the same peak
