@@ -656,8 +656,9 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
     }
     const float *ip = in + (int64_t)s * n_pix_per_stream;
     float *op = out + (int64_t)s * n_pix_per_stream * Cout + (int64_t)(cg >> 1) * n_pix_per_stream * 8 + (cg & 1) * 4;  // NC8HW8
-    for (int64_t p = (int64_t)blockIdx.x * pix_per_iter + ps; p < n_pix_per_stream; p += (int64_t)gridDim.x * pix_per_iter) {
-        const int h = (int)(p / W), x = (int)(p % W);
+    const int npix = (int)n_pix_per_stream;  // H * W of one stream: 32-bit (a 64-bit p / W costs more than the conv)
+    for (int p = blockIdx.x * pix_per_iter + ps; p < npix; p += gridDim.x * pix_per_iter) {
+        const int h = p / W, x = p - h * W;
         float v[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
             r[c] = fmaxf(fmaf(a, sc[c], sh[c]), 0.0f);
         }
         o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
-        *(float4 *)(op + p * 8) = o;
+        *(float4 *)(op + (int64_t)p * 8) = o;
     }
 }
 
@@ -993,6 +994,7 @@ static int conv_first(const float *in, const float *w, const float *scale, const
                       int W, int Cout, hipStream_t st) {
     STITO_REQUIRE(Cout % 4 == 0 && 256 % (Cout / 4) == 0, STITO_E_UNSUPPORTED, "first conv: cout %d", Cout);
     const int64_t npix = (int64_t)H * W;
+    STITO_REQUIRE(npix < (1ll << 30), STITO_E_UNSUPPORTED, "first conv: %dx%d map too large", H, W);
     const int ppi = 256 / (Cout / 4);
     int64_t gx = (npix + ppi - 1) / ppi;
     const int64_t cap = (256 * 32 + S - 1) / S;

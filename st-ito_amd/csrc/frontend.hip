@@ -59,6 +59,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
         d1 = fmaxf(pk, 1e-8f);
         if (norm_passes > 1) d2 = fmaxf(pk / d1, 1e-8f);  // == 1 unless the candidate is (near) silent
     }
+    const bool second = norm_passes > 1 && d2 != 1.0f;    // x / 1.0f == x: skip the (IEEE, ~10 instruction) divisions
     const float *xl = audio + (int64_t)cand * C * L;
     const float *xr = xl + L;
     const int64_t base = t * fe.hop - N2;  // center=True: frame t covers [t*hop - n_fft/2, t*hop + n_fft/2)
@@ -68,10 +69,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
         const int64_t i0 = reflect_idx(base + 2 * m, L), i1 = reflect_idx(base + 2 * m + 1, L);
         const float w0 = fe.window[2 * m], w1 = fe.window[2 * m + 1];
         float a0 = xl[i0] / d1, a1 = xl[i1] / d1;
-        if (norm_passes > 1) { a0 = a0 / d2; a1 = a1 / d2; }
+        if (second) { a0 = a0 / d2; a1 = a1 / d2; }
         if (C == 2) {
             float b0 = xr[i0] / d1, b1 = xr[i1] / d1;
-            if (norm_passes > 1) { b0 = b0 / d2; b1 = b1 / d2; }
+            if (second) { b0 = b0 / d2; b1 = b1 / d2; }
             const float m0 = (a0 + b0) / 2, m1 = (a1 + b1) / 2, s0 = (a0 - b0) / 2, s1 = (a1 - b1) / 2;
             bufA[m] = make_float2(m0 * w0, m1 * w1);
             bufA[N2 + m] = make_float2(s0 * w0, s1 * w1);
