@@ -15,7 +15,8 @@
 //   Freeverb       : one workgroup per candidate, all delay lines resident in LDS (~112 KB);
 //                    time advances in tiles shorter than the shortest delay line, so comb /
 //                    all-pass updates inside a tile are independent; the comb damping one-pole
-//                    is a wave-level affine scan.
+//                    is a wave-level affine scan on the DPP network; one barrier per tile with
+//                    the combs of tile k and the all-passes of tile k-1 in flight.
 //   delay          : feedback delay of D samples = D independent geometric recurrences.
 //   distortion/gain: element-wise.
 #include "common.h"
@@ -489,7 +490,14 @@ __global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__res
 #undef CE_GSTORE
 }
 
-// VCA: gain = env < thr ? 1 : pow(env/thr, 1/ratio - 1); y = gain * x.
+// VCA: gain = env < thr ? 1 : pow(env/thr, 1/ratio - 1); y = gain * x.  The power goes through
+// v_log_f32 / v_exp_f32 (1 ulp each; base >= 1, |exponent| < 1: relative error < 2e-6 against powf, inside
+// the 2e-5 parity bound of the effect): the kernel is then bound by its 12 bytes per sample of HBM traffic.
+__device__ __forceinline__ float vca_gain(float e, float thr, float thr_inv, float p) {
+    return e < thr ? 1.0f : __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(e * thr_inv));
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_comp_gain(InView in, float *__restrict__ out, const float *__restrict__ env,
                                                     int64_t cand_stride, int C, int64_t L,
                                                     const double *__restrict__ coef) {
@@ -499,10 +507,21 @@ __global__ __launch_bounds__(256) void k_comp_gain(InView in, float *__restrict_
     const int64_t off = (int64_t)cand * cand_stride + (int64_t)ch * L;
     const double *cf = coef + (int64_t)cand * COEF_STRIDE;
     const float thr = (float)cf[0], thr_inv = (float)cf[1], p = (float)cf[2];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
-        const float e = env[off + i];
-        const float g = (e < thr) ? 1.0f : powf(e * thr_inv, p);
-        out[off + i] = g * x[i];
+    if (VEC) {
+        const float4 *x4 = (const float4 *)x, *e4 = (const float4 *)(env + off);
+        float4 *o4 = (float4 *)(out + off);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L / 4; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 e = e4[i], v = x4[i];
+            float4 o;
+            o.x = vca_gain(e.x, thr, thr_inv, p) * v.x;
+            o.y = vca_gain(e.y, thr, thr_inv, p) * v.y;
+            o.z = vca_gain(e.z, thr, thr_inv, p) * v.z;
+            o.w = vca_gain(e.w, thr, thr_inv, p) * v.w;
+            o4[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x)
+            out[off + i] = vca_gain(env[off + i], thr, thr_inv, p) * x[i];
     }
 }
 
@@ -574,14 +593,20 @@ struct ReverbGeom {
     int state_floats;
 };
 
+// DPP move: lane i reads `v` of the lane selected by CTRL; rows outside ROW_MASK and lanes whose source is out of
+// range read 0
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float rv_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
 __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restrict__ out, int64_t cand_stride,
                                                         int64_t L, const double *__restrict__ coef, ReverbGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *state = smem;                          // comb + all-pass delay lines
-    float *s_in = smem + g.state_floats;          // [RV_TT] (L+R)*gain
-    float *s_x = s_in + RV_TT;                    // [2][RV_TT] dry input
-    float *s_comb = s_x + 2 * RV_TT;              // [16][RV_TT] comb outputs
-    float *s_wet = s_comb + 16 * RV_TT;           // [2][RV_TT]
+    float *s_in = smem + g.state_floats;          // [2 buffers][RV_TT] (L+R)*gain
+    float *s_x = s_in + 2 * RV_TT;                // [3 buffers][2][RV_TT] dry input
+    float *s_comb = s_x + 6 * RV_TT;              // [2 buffers][16][RV_TT] comb outputs
 
     const int cand = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -606,25 +631,63 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
         for (int k = 0; k < 6; ++k) { apow[k] = a; a *= a; }
     }
     const float dlane = powf(d3, (float)lane);  // damp^(3*lane)
-    // all-pass positions (thread (c,t) role in phase 2)
+    const float m15 = powf(d3, (float)((lane & 15) + 1));            // from lane 15 of the previous row
+    const float m31 = lane >= 32 ? powf(d3, (float)(lane - 31)) : 0.0f;  // from lane 31
+    // all-pass role: thread u < 2 RV_TT = (channel u & 1, sample u >> 1): the two channels of a sample sit in
+    // adjacent lanes, so the width mix and the (L+R) input sum are one __shfl_xor away -- no exchange through LDS
     int appos[4] = {0, 0, 0, 0};
-    const int c2 = tid / RV_TT, t2 = tid % RV_TT;
+    const int c2 = tid & 1, t2 = tid >> 1;
+    const float *xc_g = c2 == 0 ? xl : xr;
+    float *yc_g = c2 == 0 ? yl : yr;
+    const bool ap = tid < 2 * RV_TT;
 
-    // input tile for the next iteration is fetched one tile ahead (registers) so that its HBM
-    // latency overlaps the comb / all-pass phases
-    float pa = (tid < RV_TT && tid < L) ? xl[tid] : 0.0f, pb = (tid < RV_TT && tid < L) ? xr[tid] : 0.0f;
-    for (int64_t t0 = 0; t0 < L; t0 += RV_TT) {
-        const int nv = (int)min((int64_t)RV_TT, L - t0);
-        __syncthreads();
-        if (tid < RV_TT) {
-            s_x[tid] = pa; s_x[RV_TT + tid] = pb;
-            s_in[tid] = (pa + pb) * 0.015f;
-            const int64_t tn = t0 + RV_TT + tid;
-            pa = tn < L ? xl[tn] : 0.0f;
-            pb = tn < L ? xr[tn] : 0.0f;
+    // ONE barrier per tile, two tiles in flight: in step k the 16 waves run the combs of tile k while the first
+    // 2 RV_TT threads also run comb sums + all-passes + wet/dry mix + store of tile k-1 (comb outputs double-
+    // buffered) and stage the input of tile k+1 (s_in double-, s_x triple-buffered).  Both are chains of LDS round
+    // trips; in one instruction stream their latencies overlap.  The input of tile k+2 is already on its way from
+    // HBM into registers.
+    float px = (ap && t2 < L) ? xc_g[t2] : 0.0f;
+    if (ap) {  // stage tile 0, fetch tile 1
+        const float po = __shfl_xor(px, 1);
+        s_x[c2 * RV_TT + t2] = px;
+        if (c2 == 0) s_in[t2] = (px + po) * 0.015f;
+        const int64_t tn = (int64_t)RV_TT + t2;
+        px = tn < L ? xc_g[tn] : 0.0f;
+    }
+    const int64_t ntiles = (L + RV_TT - 1) / RV_TT;
+    for (int64_t k = 0; k <= ntiles; ++k) {
+        __syncthreads();  // combs of tile k-1, all-passes of tile k-2 and the staging of tile k are complete
+        if (ap && k >= 1) {  // ---- tile k-1: comb sum + 4 series all-passes, mix, store ----
+            const int64_t t0 = (k - 1) * RV_TT;
+            const float *cmb = s_comb + ((k - 1) & 1) * 16 * RV_TT;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += cmb[(c2 * 8 + j) * RV_TT + t2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sz = g.ap_size[c2 * 4 + j];
+                float *ab = state + g.ap_off[c2 * 4 + j];
+                int p = appos[j] + t2;
+                p = p >= sz ? p - sz : p;
+                const float bv = ab[p];
+                ab[p] = acc + (bv * 0.5f);
+                acc = bv - acc;
+                appos[j] += RV_TT;
+                appos[j] = appos[j] >= sz ? appos[j] - sz : appos[j];
+            }
+            const float other = rv_dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the other channel of this sample
+            if (t0 + t2 < L) yc_g[t0 + t2] = acc * wet1 + other * wet2 + s_x[(int)((k - 1) % 3) * 2 * RV_TT + c2 * RV_TT + t2] * dry;
         }
-        __syncthreads();
-        {   // ---- phase 1: 16 comb filters, one per wave ----
+        if (ap && k + 1 < ntiles) {  // ---- stage tile k+1, fetch tile k+2 ----
+            const float po = __shfl_xor(px, 1);
+            s_x[(int)((k + 1) % 3) * 2 * RV_TT + c2 * RV_TT + t2] = px;
+            if (c2 == 0) s_in[((k + 1) & 1) * RV_TT + t2] = (px + po) * 0.015f;
+            const int64_t tn = (k + 2) * RV_TT + t2;
+            px = tn < L ? xc_g[tn] : 0.0f;
+        }
+        if (k < ntiles) {   // ---- tile k: 16 comb filters, one per wave ----
+            const float *in_c = s_in + (k & 1) * RV_TT;
+            float *cmb = s_comb + (k & 1) * 16 * RV_TT;
             float o[3], w[3];
             int idx[3];
 #pragma unroll
@@ -638,52 +701,31 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
             float b = o[0] * omd;
             b = o[1] * omd + b * damp;
             b = o[2] * omd + b * damp;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {  // inclusive wave scan of the affine maps
-                const float up = __shfl_up(b, 1 << k);
-                if (lane >= (1 << k)) b = fmaf(apow[k], up, b);
-            }
-            float carry = __shfl_up(b, 1);
-            carry = (lane > 0 ? carry : 0.0f) + dlane * last_in;
+            // inclusive wave scan of the affine maps on the DPP network (a ds_bpermute shuffle costs an LDS round
+            // trip per step): shifts 1, 2, 4, 8 inside the 16-lane rows (lanes shifted in from outside read 0),
+            // then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3, each with the power of
+            // d3 that belongs to the lane's distance
+            b = fmaf(apow[0], rv_dpp<0x111>(b), b);
+            b = fmaf(apow[1], rv_dpp<0x112>(b), b);
+            b = fmaf(apow[2], rv_dpp<0x114>(b), b);
+            b = fmaf(apow[3], rv_dpp<0x118>(b), b);
+            b = fmaf(m15, rv_dpp<0x142, 0xA>(b), b);
+            b = fmaf(m31, rv_dpp<0x143, 0xC>(b), b);
+            const float carry = rv_dpp<0x138>(b) + dlane * last_in;  // wave_shr:1, lane 0 reads 0
             float last = carry;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 last = (o[i] * omd) + (last * damp);
-                w[i] = s_in[3 * lane + i] + (last * fbk);
+                w[i] = in_c[3 * lane + i] + (last * fbk);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 cbuf[idx[i]] = w[i];
-                s_comb[wv * RV_TT + 3 * lane + i] = o[i];
+                cmb[wv * RV_TT + 3 * lane + i] = o[i];
             }
-            last_in = __shfl(last, 63);
+            last_in = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(last), 63));
             cpos += RV_TT;
             cpos = cpos >= csz ? cpos - csz : cpos;
-        }
-        __syncthreads();
-        if (tid < 2 * RV_TT) {  // ---- phase 2: comb sum + 4 series all-passes, thread = (channel, t) ----
-            float acc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc += s_comb[(c2 * 8 + j) * RV_TT + t2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sz = g.ap_size[c2 * 4 + j];
-                float *ab = state + g.ap_off[c2 * 4 + j];
-                int p = appos[j] + t2;
-                p = p >= sz ? p - sz : p;
-                const float bv = ab[p];
-                ab[p] = acc + (bv * 0.5f);
-                acc = bv - acc;
-                appos[j] += RV_TT;
-                appos[j] = appos[j] >= sz ? appos[j] - sz : appos[j];
-            }
-            s_wet[c2 * RV_TT + t2] = acc;
-        }
-        __syncthreads();
-        if (tid < 2 * RV_TT && t2 < nv) {  // ---- phase 3: wet/dry mix ----
-            const float me = s_wet[c2 * RV_TT + t2], other = s_wet[(1 - c2) * RV_TT + t2];
-            const float v = me * wet1 + other * wet2 + s_x[c2 * RV_TT + t2] * dry;
-            (c2 == 0 ? yl : yr)[t0 + t2] = v;
         }
     }
 }
@@ -924,7 +966,10 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                 hipLaunchKernelGGL(kern, dim3((S + 63) / 64), dim3(CE_THREADS), lds, st, in, envbuf, cand_stride, Cn, L, S, cf);
                 STITO_LAUNCH_CHECK();
             }
-                hipLaunchKernelGGL(k_comp_gain, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
+                if ((L % 4 == 0) && (((uintptr_t)in.base | (uintptr_t)envbuf | (uintptr_t)audio_dev) & 15) == 0)
+                    hipLaunchKernelGGL(k_comp_gain<true>, dim3(grid_x_for(L / 4, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
+                else
+                    hipLaunchKernelGGL(k_comp_gain<false>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
                 break;
             case STITO_FX_DISTORTION:
                 hipLaunchKernelGGL(k_pointwise<STITO_FX_DISTORTION>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
@@ -944,7 +989,7 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                 reverb_geometry(sample_rate, g);
                 int mins = g.ap_size[0];
                 for (int k = 0; k < 8; ++k) mins = g.ap_size[k] < mins ? g.ap_size[k] : mins;
-                const size_t lds = (size_t)(g.state_floats + RV_TT * (1 + 2 + 16 + 2)) * sizeof(float);
+                const size_t lds = (size_t)(g.state_floats + RV_TT * (2 + 6 + 32)) * sizeof(float);
                 STITO_REQUIRE(mins >= RV_TT && lds <= 160 * 1024, STITO_E_UNSUPPORTED,
                               "Reverb: sample rate %.0f needs delay lines outside the LDS-resident design", sample_rate);
                 STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
