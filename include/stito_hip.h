@@ -132,10 +132,16 @@ typedef struct {
     const float *mel_w_dev;       /* packed non-zero runs of melW[:, m] */
     const float *bn0_scale_dev;   /* (n_mels) gamma/sqrt(var+eps)        (BATCHNORM only) */
     const float *bn0_shift_dev;   /* (n_mels) beta - mean*scale          (BATCHNORM only) */
+    int32_t no_center;    /* 0: frames centred with reflect padding (torchlibrosa, panns.py:147-155);
+                             1: frame t starts at t*hop, no padding (torchaudio MelSpectrogram(center=False),
+                             utils.py:104-113) */
+    int32_t reserved;
 } stito_frontend;
 
 /* T = n_samples / hop + 1 frames (center=True, reflect padding). */
 int64_t stito_num_frames(int64_t n_samples, int hop);
+/* T = (n_samples - n_fft) / hop + 1 frames for no_center front ends. */
+int64_t stito_num_frames_nocenter(int64_t n_samples, int n_fft, int hop);
 
 /* audio_dev (pop, channels, n_samples) + peaks_dev (pop) = max|audio[p]|; norm_passes = how many
  * `x /= clip(max|x|, 1e-8)` the reference applies before the model: 2 for rendered candidates
@@ -230,6 +236,14 @@ size_t stito_spectral_centroid_workspace_bytes(int n_items, int channels, int64_
 int stito_spectral_centroid(const float *audio_dev, int n_items, int channels, int64_t n_samples, double sample_rate,
                             const float *window_dev, const float *twiddle_dev, float *out_dev, void *workspace_dev,
                             size_t workspace_bytes, void *stream);
+
+/* MFCC statistics of get_mfcc_feature_embeds (utils.py:116-159) on top of stito_logmel's 10 log10(mel power):
+ * logmel_dev (n_items * channels, T, n_mels); per item: clamp to (max over the item's channels, bands and
+ * frames) - top_db (torchaudio amplitude_to_DB); per frame: DCT with dct_dev (n_mels, n_mfcc); over frames:
+ * mean, unbiased std, max per coefficient -> out_dev (n_items, channels * 3 * n_mfcc) = per channel
+ * [mean | std | max], rows L2-normalised.  n_mfcc <= 32, T * n_mfcc floats must fit 128 KB of LDS. */
+int stito_mfcc_stats(const float *logmel_dev, int n_items, int channels, int64_t n_frames, int n_mels,
+                     const float *dct_dev, int n_mfcc, float top_db, float *out_dev, void *stream);
 
 /* ---- embeddings -> fitness ----------------------------------------------------------------- */
 /* In place: NaN scrub (utils.py:491-497), L2-normalise mid/side (n_cand, E).  If target_mid_dev

@@ -208,9 +208,67 @@ __global__ __launch_bounds__(256) void k_rms_crest(const float *__restrict__ aud
     }
 }
 
+// ---- MFCC statistics (utils.py:116-159 on torchaudio.transforms.MFCC, restated: parity unpinned) ----
+// one workgroup per (item, channel): clamp, DCT per frame into LDS, then mean / unbiased std / max over frames
+__global__ __launch_bounds__(256) void k_mfcc_stats(const float *__restrict__ lm, int channels, int64_t T, int M,
+                                                    const float *__restrict__ dct /*(M, K)*/, int K, float top_db,
+                                                    float *__restrict__ out) {
+    extern __shared__ float mf[];  // [T][K]
+    __shared__ float red[4];
+    const int stream = blockIdx.x, item = stream / channels, ch = stream % channels, tid = threadIdx.x;
+    // top_db floor: max of the item's dB mel spectrogram over its channels, frames and bands
+    float mxv = -INFINITY;
+    {
+        const float *pi = lm + (int64_t)item * channels * T * M;
+        for (int64_t i = tid; i < (int64_t)channels * T * M; i += 256) mxv = fmaxf(mxv, pi[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+        if ((tid & 63) == 0) red[tid >> 6] = mxv;
+        __syncthreads();
+        mxv = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    const float floor_db = mxv - top_db;
+    const float *p = lm + (int64_t)stream * T * M;
+    for (int64_t q = tid; q < T * K; q += 256) {
+        const int64_t t = q / K;
+        const int k = (int)(q % K);
+        float acc = 0.0f;
+        for (int m = 0; m < M; ++m) acc = fmaf(fmaxf(p[t * M + m], floor_db), dct[m * K + k], acc);
+        mf[q] = acc;
+    }
+    __syncthreads();
+    if (tid < K) {
+        float s = 0.0f, mx = -INFINITY;
+        for (int64_t t = 0; t < T; ++t) { const float v = mf[t * K + tid]; s += v; mx = fmaxf(mx, v); }
+        const float mean = s / (float)T;
+        float ss = 0.0f;
+        for (int64_t t = 0; t < T; ++t) { const float d = mf[t * K + tid] - mean; ss = fmaf(d, d, ss); }
+        float *o = out + ((int64_t)item * channels + ch) * 3 * K;
+        o[tid] = mean;
+        o[K + tid] = sqrtf(ss / (float)(T - 1));
+        o[2 * K + tid] = mx;
+    }
+}
+
 }  // namespace stito
 
 using namespace stito;
+
+extern "C" int stito_mfcc_stats(const float *logmel_dev, int n_items, int channels, int64_t n_frames, int n_mels,
+                                const float *dct_dev, int n_mfcc, float top_db, float *out_dev, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    STITO_REQUIRE(n_items > 0 && channels > 0 && n_frames > 1 && n_mels > 0, STITO_E_INVALID, "stito_mfcc_stats: empty input");
+    STITO_REQUIRE(n_mfcc > 0 && n_mfcc <= 32, STITO_E_UNSUPPORTED, "n_mfcc %d not in [1, 32]", n_mfcc);
+    const size_t lds = (size_t)n_frames * n_mfcc * sizeof(float);
+    STITO_REQUIRE(lds <= 128 * 1024, STITO_E_UNSUPPORTED, "MFCC statistics: %lld frames do not fit the LDS", (long long)n_frames);
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_mfcc_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mfcc_stats, dim3(n_items * channels), dim3(256), lds, st, logmel_dev, channels, n_frames, n_mels, dct_dev,
+                       n_mfcc, top_db, out_dev);
+    STITO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_l2norm_rows, dim3((n_items + 63) / 64), dim3(64), 0, st, out_dev, n_items, channels * 3 * n_mfcc);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
 
 static int feat_log2(int n) {
     int l = 0;

@@ -19,7 +19,7 @@
 namespace stito {
 
 struct FrontendDev {
-    int n_fft, hop, n_mels, norm_mode, log2_n2;
+    int n_fft, hop, n_mels, norm_mode, log2_n2, no_center;
     const float *window;
     const float2 *twiddle;  // exp(-2 pi i k / n_fft), k < n_fft/2
     const int *mel_start, *mel_len, *mel_off;
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     const bool second = norm_passes > 1 && d2 != 1.0f;    // x / 1.0f == x: skip the (IEEE, ~10 instruction) divisions
     const float *xl = audio + (int64_t)cand * C * L;
     const float *xr = xl + L;
-    const int64_t base = t * fe.hop - N2;  // center=True: frame t covers [t*hop - n_fft/2, t*hop + n_fft/2)
+    // center=True: frame t covers [t*hop - n_fft/2, t*hop + n_fft/2) with reflection at the ends;
+    // no_center: [t*hop, t*hop + n_fft), always inside the signal
+    const int64_t base = fe.no_center ? t * fe.hop : t * fe.hop - N2;
 
     // ---- load, normalise, mid/side, window, pack even/odd samples as complex ------------------
     for (int m = tid; m < N2; m += FE_THREADS) {
@@ -146,6 +148,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
 using namespace stito;
 
 extern "C" int64_t stito_num_frames(int64_t n_samples, int hop) { return n_samples / hop + 1; }
+extern "C" int64_t stito_num_frames_nocenter(int64_t n_samples, int n_fft, int hop) {
+    return n_samples >= n_fft ? (n_samples - n_fft) / hop + 1 : 0;
+}
 
 extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, const float *peaks_dev, int norm_passes,
                             int pop, int channels, int64_t n_samples, float *logmel_dev, void *stream) {
@@ -155,10 +160,11 @@ extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, co
     const int N = fe->n_fft;
     STITO_REQUIRE(N >= 64 && N <= 4096 && (N & (N - 1)) == 0, STITO_E_UNSUPPORTED, "n_fft %d must be a power of two in [64, 4096]", N);
     STITO_REQUIRE(fe->hop > 0 && fe->n_mels > 0, STITO_E_INVALID, "bad hop / n_mels");
-    STITO_REQUIRE(n_samples > N / 2, STITO_E_INVALID, "reflect padding needs n_samples > n_fft/2 (got %lld)", (long long)n_samples);
+    STITO_REQUIRE(fe->no_center ? n_samples >= N : n_samples > N / 2, STITO_E_INVALID,
+                  "audio too short for the STFT (n_samples %lld, n_fft %d)", (long long)n_samples, N);
     STITO_REQUIRE(pop > 0, STITO_E_INVALID, "empty batch");
     FrontendDev d;
-    d.n_fft = N; d.hop = fe->hop; d.n_mels = fe->n_mels; d.norm_mode = fe->norm_mode;
+    d.n_fft = N; d.hop = fe->hop; d.n_mels = fe->n_mels; d.norm_mode = fe->norm_mode; d.no_center = fe->no_center;
     int l2 = 0;
     while ((1 << l2) < N / 2) ++l2;
     d.log2_n2 = l2;
@@ -166,7 +172,7 @@ extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, co
     d.mel_start = fe->mel_start_dev; d.mel_len = fe->mel_len_dev; d.mel_off = fe->mel_off_dev; d.mel_w = fe->mel_w_dev;
     d.bn_scale = fe->bn0_scale_dev; d.bn_shift = fe->bn0_shift_dev;
     STITO_REQUIRE(fe->norm_mode != STITO_NORM_BATCHNORM || (d.bn_scale && d.bn_shift), STITO_E_INVALID, "batchnorm input norm needs bn0 scale/shift");
-    const int64_t T = stito_num_frames(n_samples, fe->hop);
+    const int64_t T = fe->no_center ? stito_num_frames_nocenter(n_samples, N, fe->hop) : stito_num_frames(n_samples, fe->hop);
     const size_t lds = (size_t)channels * (N / 2) * sizeof(float2) * 2 + (size_t)channels * (N / 2 + 1) * sizeof(float);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_logmel, dim3((unsigned)T, pop), dim3(FE_THREADS), lds, st, d, audio_dev, peaks_dev, norm_passes,

@@ -36,6 +36,7 @@ class Frontend(Structure):
         ("window_dev", c_void_p), ("twiddle_dev", c_void_p), ("mel_start_dev", c_void_p),
         ("mel_len_dev", c_void_p), ("mel_off_dev", c_void_p), ("mel_w_dev", c_void_p),
         ("bn0_scale_dev", c_void_p), ("bn0_shift_dev", c_void_p),
+        ("no_center", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -83,6 +84,8 @@ SIGNATURES = {
     "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),
+    "stito_num_frames_nocenter": (c_int64, [c_int64, c_int, c_int]),
+    "stito_mfcc_stats": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int, ctypes.c_float, c_void_p, c_void_p]),
     "stito_rms_crest": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "stito_barkspectrum": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "stito_spectral_centroid_workspace_bytes": (c_size_t, [c_int, c_int, c_int64]),

@@ -53,6 +53,13 @@ def _bark_to_hz(barks: torch.Tensor, bark_scale: str = "traunmuller") -> torch.T
     return 1960 * ((barks + 0.53) / (26.28 - barks))
 
 
+def _create_triangular_filterbank_from(all_freqs: torch.Tensor, f_pts: torch.Tensor) -> torch.Tensor:
+    """Triangles between consecutive points of f_pts, (n_freqs, len(f_pts) - 2) -- reference features.py:10-36."""
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    return torch.max(torch.zeros(1), torch.min((-1.0 * slopes[:, :-2]) / f_diff[:-1], slopes[:, 2:] / f_diff[1:]))
+
+
 def barkscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_barks: int, sample_rate: int,
                      bark_scale: str = "traunmuller") -> torch.Tensor:
     """Triangular bark filterbank (n_freqs, n_barks) -- reference features.py:10-36, 109-163."""

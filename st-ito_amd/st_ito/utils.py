@@ -4,9 +4,11 @@ The other metrics of the reference's utils.py (CLAP, BEATs, wav2vec2, ...) are o
 build's scope."""
 from __future__ import annotations
 
+import math
 import os
 from importlib import import_module
 
+import numpy as np
 import torch
 import yaml
 
@@ -151,4 +153,81 @@ def get_mir_feature_embeds(x: torch.Tensor, model, sample_rate: float, **kwargs)
         "barkspectrum": F.compute_barkspectrum(x, sample_rate=sample_rate, mode="mono"),
         "spectral_centroid": F.compute_spectral_centroid(x, sample_rate),
     }
+
+
+# ------------------- audio feature (MFCC) extractor (reference utils.py:101-159) ---------------- #
+class MFCCExtractor:
+    """Device tables of torchaudio.transforms.MFCC(sample_rate=48000, n_mfcc=25, melkwargs={n_fft 2048,
+    hop_length 1024, n_mels 128, center False}) -- restated from the library's published definition
+    (un-vendored dependency, parity unpinned): Hann-window power STFT without padding, HTK mel filterbank
+    (f_min 0, f_max sr/2, no normalisation), 10 log10(clamp(., 1e-10)) with an 80 dB floor below the item's
+    maximum, orthonormal DCT-II.  The STFT + mel + log run in stito_logmel, the rest in stito_mfcc_stats."""
+
+    def __init__(self, sample_rate: int = 48000, n_mfcc: int = 25, n_fft: int = 2048, hop_length: int = 1024, n_mels: int = 128):
+        from .features import _create_triangular_filterbank_from
+
+        _hip.require_gpu()
+        self.sample_rate, self.n_mfcc, self.n_fft, self.hop, self.n_mels = sample_rate, n_mfcc, n_fft, hop_length, n_mels
+        self.embed_dim = n_mfcc * 3
+        self.device = dev = torch.device("cuda", torch.cuda.current_device())
+        # HTK mel filterbank (n_freqs, n_mels): torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk")
+        all_freqs = torch.linspace(0, sample_rate // 2, n_fft // 2 + 1)
+        m_max = 2595.0 * math.log10(1.0 + (float(sample_rate // 2) / 700.0))
+        m_pts = torch.linspace(0.0, m_max, n_mels + 2)
+        f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+        fb = _create_triangular_filterbank_from(all_freqs, f_pts).numpy()
+        starts, lens, offs, packed = [], [], [], []
+        for m in range(n_mels):
+            nz = np.nonzero(fb[:, m])[0]
+            s0, e0 = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 0)
+            starts.append(s0); lens.append(e0 - s0); offs.append(sum(len(a) for a in packed))
+            packed.append(fb[s0:e0, m].astype(np.float32))
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)  # noqa: E731
+        kk = np.arange(n_fft // 2)
+        tw = np.stack([np.cos(-2 * np.pi * kk / n_fft), np.sin(-2 * np.pi * kk / n_fft)], 1).astype(np.float32)
+        # orthonormal DCT-II (n_mels, n_mfcc): torchaudio.functional.create_dct(n_mfcc, n_mels, "ortho")
+        n = torch.arange(float(n_mels))
+        k = torch.arange(float(n_mfcc)).unsqueeze(1)
+        dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+        dct[0] *= 1.0 / math.sqrt(2.0)
+        dct *= math.sqrt(2.0 / float(n_mels))
+        self._keep = [torch.hann_window(n_fft, periodic=True).to(dev), torch.from_numpy(tw).to(dev).contiguous(), i32(starts), i32(lens),
+                      i32(offs), torch.from_numpy(np.concatenate(packed + [np.zeros(1, np.float32)])).to(dev), dct.t().contiguous().to(dev)]
+        FE = _hip.Frontend()
+        FE.n_fft, FE.hop, FE.n_mels, FE.norm_mode, FE.no_center = n_fft, hop_length, n_mels, _hip.NORM_NONE, 1
+        FE.window_dev, FE.twiddle_dev, FE.mel_start_dev, FE.mel_len_dev, FE.mel_off_dev, FE.mel_w_dev = (t.data_ptr() for t in self._keep[:6])
+        self.FE, self.dct = FE, self._keep[6]
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """(bs, chs, n) -> (bs, chs * 3 * n_mfcc): per channel [mean | std | max] over frames, rows L2-normalised."""
+        L = _hip.lib()
+        bs, chs, n = x.shape
+        xin = x.detach().to(self.device, torch.float32).reshape(bs * chs, 1, n).contiguous()
+        T = L.stito_num_frames_nocenter(n, self.n_fft, self.hop)
+        if T < 2:
+            raise ValueError("audio too short for MFCC statistics")
+        lm = torch.empty((bs * chs, T, self.n_mels), dtype=torch.float32, device=self.device)
+        _hip.check(L.stito_logmel(self.FE, _hip.ptr(xin), None, 0, bs * chs, 1, n, _hip.ptr(lm), _hip.stream_ptr()))
+        out = torch.empty((bs, chs * 3 * self.n_mfcc), dtype=torch.float32, device=self.device)
+        _hip.check(L.stito_mfcc_stats(_hip.ptr(lm), bs, chs, T, self.n_mels, _hip.ptr(self.dct), self.n_mfcc, 80.0, _hip.ptr(out),
+                                      _hip.stream_ptr()))
+        return out
+
+
+def load_mfcc_feature_extractor(use_gpu: bool = False):
+    """reference utils.py:101-113 (the extractor always lives on the GPU here)."""
+    return MFCCExtractor()
+
+
+def get_mfcc_feature_embeds(x: torch.Tensor, model, sample_rate: float, midside: bool = False, **kwargs):
+    """reference utils.py:116-159: mono (channel mean) or mid/side (L+R, L-R) MFCC statistics, {"mono": (bs, E)}."""
+    bs, chs, seq_len = x.shape
+    if sample_rate != 48000:
+        raise NotImplementedError("resampling to 48 kHz (torchaudio) is not part of this build; pass 48 kHz audio")
+    if chs == 2 and midside:
+        x = torch.stack([x[:, 0, :] + x[:, 1, :], x[:, 0, :] - x[:, 1, :]], dim=1)
+    else:
+        x = x.mean(dim=1, keepdim=True)
+    emb = model(x)
+    return {"mono": emb.to(x.device).type_as(x)}
 

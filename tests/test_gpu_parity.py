@@ -466,3 +466,21 @@ def test_dsp_module_random_effects(dev):
     assert abs(integrated_loudness(z.numpy().T, SR) - (-23.0)) < 0.05
     with pytest.raises(NotImplementedError):
         PD.apply_random_compressor(x, SR)
+
+
+def test_mfcc_feature_embeds_vs_oracle(dev):
+    """get_mfcc_feature_embeds (utils.py:116-159; torchaudio MFCC restated, unpinned): the STFT/mel/log part
+    runs through stito_logmel (no-centre mode, HTK mel bands), DCT and statistics in stito_mfcc_stats."""
+    from st_ito.utils import get_mfcc_feature_embeds, load_mfcc_feature_extractor
+    model = load_mfcc_feature_extractor()
+    assert model.embed_dim == 75
+    x = torch.stack([O.synth_audio(91, 2, 80000), 0.05 * O.synth_audio(92, 2, 80000)])
+    x[1, :, 40000:] = 0.0   # half of item 1 is digital silence: exercises the 1e-10 clamp and the 80 dB floor
+    for midside in (False, True):
+        got = get_mfcc_feature_embeds(x, model, SR, midside=midside)["mono"]
+        ref = O.mfcc_feature_embeds(x, SR, midside=midside)
+        assert got.shape == ref.shape == (2, 150 if midside else 75) and got.device == x.device
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(np.linalg.norm(got.numpy(), axis=1), 1.0, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        get_mfcc_feature_embeds(x, model, 44100)
