@@ -292,8 +292,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
 //     VGPRs); per 8-channel chunk it issues 12 ds_read_b128 and 32 MFMAs and nothing else, so the
 //     matrix pipes never wait for VALU work;
 //   * 4 producer waves: copy U (pre-transformed weights, [cin/8][16][cout][8]) by LDS-DMA, load
-//     each tile's 4x4 patch straight from the NHWC activations (bounds-checked = zero padding,
-//     stream boundaries included), form B^T d B and write V for the NEXT chunk (double buffered).
+//     each tile's 4x4 patch straight from the channel-blocked activations (bounds-checked = zero
+//     padding, stream boundaries included), form B^T d B for half of the tiles and write V for the
+//     NEXT chunk (double buffered); consumer waves 0-3 transform the other half after their MFMAs.
 //   One barrier per chunk; 3 waves per SIMD (2 consumers + 1 producer), 128 KB LDS.
 // The 16 positions of one output meet only in the epilogue: a wave reduces its row over nu in registers
 // (column half of A^T M A), the 4 x 2 partial results per (tile, channel) are exchanged through LDS
@@ -464,9 +465,12 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         const int xi = ptid & 3, p_quad = (ptid >> 2) & 1;
         const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
         const float sgn = xi == 1 ? 1.0f : -1.0f;   // T[xi] = d[ra] + sgn * d[rb]
-        int rowA[2], rowB[2], vdst[2];
+        // tiles 0..31 here (one item per producer thread); tiles 32..63 are transformed by four of the consumer
+        // waves once they have issued their MFMAs: two waves per SIMD then share the serial tail of a chunk
+        constexpr int NIT = 1;
+        int rowA[NIT], rowB[NIT], vdst[NIT];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int tile = (ptid >> 3) + 32 * it;
             const int vtr = vtr0 + tile / TTW;
             const int tcl = tile % TTW;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         }
         auto transform_store = [&](const float *pbuf, int v_boff) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < NIT; ++it) {
                 f32x4 T[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)  // native vector arithmetic -> v_pk_fma_f32 / v_pk_add_f32
@@ -551,9 +555,46 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.0f;
+    // helper role of consumer waves 0-3: B^T d B of tiles 32..63 for the next chunk (same item layout as the
+    // producers: row hx of the transform, channel quad, tile), done after the wave's own MFMAs (these waves
+    // finish issuing at ~2600 cycles of a chunk; waves 4-7 as helpers were slower: 84.1 against 81.8 ms).  While the two consumer waves of a SIMD stream MFMAs no other wave gets vector
+    // instructions issued at a useful rate (measured, whatever its priority or age), so the transform is a serial
+    // tail after the MFMA phase; sharing it between the producer and a consumer wave of each SIMD halves it.
+    const bool helper = wv < 4;
+    int h_rowA = 0, h_rowB = 0, h_vdst = 0;
+    float h_sgn = 0.0f;
+    {
+        const int hx = tid & 3, hq = (tid >> 2) & 1, tile = ((tid >> 3) & 31) + 32;
+        const int ra = hx == 0 ? 0 : (hx == 2 ? 2 : 1), rb = hx == 3 ? 3 : (hx == 2 ? 1 : 2);
+        h_sgn = hx == 1 ? 1.0f : -1.0f;
+        const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
+        const int s_ = vtr / g.TR, tr = vtr % g.TR;
+        const int pc0 = s_ * g.H + 2 * tr - 1 - iv_lo;
+        const int ha = 2 * tr - 1 + ra, hb = 2 * tr - 1 + rb;
+        const int zoff = g.pa_i * 256;
+        h_rowA = ((vtr < g.VTR && ha >= 0 && ha < g.H) ? ((pc0 + ra) * PWC + 2 * tcl) * 8 : zoff) + hq * 4;
+        h_rowB = ((vtr < g.VTR && hb >= 0 && hb < g.H) ? ((pc0 + rb) * PWC + 2 * tcl) * 8 : zoff) + hq * 4;
+        h_vdst = U_FLOATS + (hx * 4) * 64 * WK + ((tile + hx) & 63) * WK + hq * 4;
+    }
+// one transform item, streamed so that at most T0, T2 and one column pair are live next to the accumulators
+#define WINO_HELP(PBUF, VBOFF)                                                                      \
+    {                                                                                               \
+        const float *pb_ = (PBUF);                                                                   \
+        float *vb_ = smem + (VBOFF) + h_vdst;                                                        \
+        const f32x4 sg_ = (f32x4)(h_sgn), m1_ = (f32x4)(-1.0f);                                      \
+        const f32x4 T0 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB), sg_, *(const f32x4 *)(pb_ + h_rowA)); \
+        const f32x4 T2 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB + 16), sg_, *(const f32x4 *)(pb_ + h_rowA + 16)); \
+        *(f32x4 *)(vb_ + 0 * 64 * WK) = __builtin_elementwise_fma(T2, m1_, T0);                      \
+        const f32x4 T1 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB + 8), sg_, *(const f32x4 *)(pb_ + h_rowA + 8)); \
+        *(f32x4 *)(vb_ + 1 * 64 * WK) = T1 + T2;                                                     \
+        *(f32x4 *)(vb_ + 2 * 64 * WK) = __builtin_elementwise_fma(T1, m1_, T2);                      \
+        const f32x4 T3 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB + 24), sg_, *(const f32x4 *)(pb_ + h_rowA + 24)); \
+        *(f32x4 *)(vb_ + 3 * 64 * WK) = __builtin_elementwise_fma(T3, m1_, T1);                      \
+    }
 
     __syncthreads();  // B0 (producers: zero fill)
     __syncthreads();  // B1 (producers: first patch landed)
+    if (helper) WINO_HELP(patch0, 0)  // this wave's share of V(0); visible after the first chunk barrier
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const float *sb = smem + (chunk & 1) * BUF;
         WINO_T(0)
@@ -574,7 +615,9 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
             }
         }
         WINO_T(2)
+        if (helper && chunk + 1 < n_chunks) WINO_HELP(patch0 + ((chunk + 1) & 1) * pfl, BUF - (chunk & 1) * BUF)
     }
+#undef WINO_HELP
 
     // ---- epilogue: Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1].  Column half in registers:
     // c0 = m0 + m1 + m2, c1 = m1 - m2 - m3 over nu; exchange xch[2 xi + j][tile 0..63][channel 0..63]
