@@ -84,22 +84,48 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     }
     __syncthreads();
 
-    // ---- radix-2 Stockham autosort FFT of N2 complex points per stream ------------------------
+    // ---- Stockham autosort FFT of N2 complex points per stream: radix-4 stages (half the LDS round trips and
+    // barriers of radix-2), plus one radix-2 stage first when log2(N2) is odd ----------------------------------
     float2 *src = bufA, *dst = bufB;
-    const int half = N2 >> 1;
-    for (int p = 1, sh = fe.log2_n2; p < N2; p <<= 1, --sh) {
-        // twiddle exp(-i pi k / p) = table[k * N / (2p)] = table[k << sh], sh = log2(N2) - log2(p)
+    int p = 1, sh = fe.log2_n2;  // stage twiddles exp(-2 pi i k / (r p)) are table entries: table[t] = exp(-2 pi i t / N)
+    if (fe.log2_n2 & 1) {        // radix-2, p = 1: all twiddles are 1
+        const int half = N2 >> 1;
         for (int c = 0; c < C; ++c) {
             const float2 *s = src + c * N2;
             float2 *d = dst + c * N2;
             for (int i = tid; i < half; i += FE_THREADS) {
+                const float2 u0 = s[i], u1 = s[i + half];
+                d[2 * i] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                d[2 * i + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
+            }
+        }
+        __syncthreads();
+        float2 *tmp = src; src = dst; dst = tmp;
+        p = 2; --sh;
+    }
+    const int quarter = N2 >> 2;
+    for (; p < N2; p <<= 2, sh -= 2) {
+        // butterfly i: inputs s[i + q N2/4], twiddles w^q with w = exp(-2 pi i k / (4p)) = table[k << (sh - 1)],
+        // outputs d[4 (i - k) + k + q p]
+        for (int c = 0; c < C; ++c) {
+            const float2 *s = src + c * N2;
+            float2 *d = dst + c * N2;
+            for (int i = tid; i < quarter; i += FE_THREADS) {
                 const int k = i & (p - 1);
-                const int j = ((i - k) << 1) + k;
-                const float2 w = fe.twiddle[k << sh];
-                const float2 u0 = s[i];
-                const float2 u1 = cmul(s[i + half], w);
-                d[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-                d[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+                const int j = ((i - k) << 2) + k;
+                const int ti = k << (sh - 1);
+                const float2 w1 = fe.twiddle[ti], w2 = fe.twiddle[2 * ti];
+                const float2 w3 = cmul(w1, w2);
+                const float2 a0 = s[i];
+                const float2 a1 = cmul(s[i + quarter], w1);
+                const float2 a2 = cmul(s[i + 2 * quarter], w2);
+                const float2 a3 = cmul(s[i + 3 * quarter], w3);
+                const float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y), b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y), b3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+                d[j] = make_float2(b0.x + b2.x, b0.y + b2.y);
+                d[j + p] = make_float2(b1.x + b3.y, b1.y - b3.x);       // b1 - i b3
+                d[j + 2 * p] = make_float2(b0.x - b2.x, b0.y - b2.y);
+                d[j + 3 * p] = make_float2(b1.x - b3.y, b1.y + b3.x);   // b1 + i b3
             }
         }
         __syncthreads();

@@ -270,6 +270,23 @@ def test_logmel_vs_oracle_and_golden(dev, golden_dir, norm):
     assert np.abs(lmm - ref).max() < tol
 
 
+@pytest.mark.parametrize("n_fft,hop,mels", [(1024, 512, 64), (512, 128, 40), (4096, 2048, 128)])
+def test_logmel_other_window_sizes(dev, n_fft, hop, mels):
+    """Front ends other than the AFx-Rep one: log2(n_fft/2) odd (a radix-2 stage in front of the radix-4 ones)
+    and even, different hop / mel counts -- against the oracle's torchlibrosa restatement."""
+    from st_ito.models.panns import Cnn14
+    om = O.fill_deterministic(O.Cnn14(512, SR, n_fft, hop, mels, 20, 20000, True, "none"), 0).eval()
+    pm = Cnn14(512, SR, n_fft, hop, mels, 20, 20000, True, "none")
+    pm.load_state_dict(om.state_dict())
+    pm.eval().to(dev)
+    x = torch.stack([O.synth_audio(95, 2, 40000), 0.2 * O.synth_audio(96, 2, 40000)])
+    got = pm.logmel(x.to(dev)).cpu().numpy()
+    with torch.no_grad():
+        ref = om.logmel(x).numpy().reshape(got.shape)
+    assert got.shape == (4, 40000 // hop + 1, mels)
+    assert np.abs(got - ref).max() < 2e-3   # dB scale, like the "none" case above
+
+
 CONV_CASES = [  # (n, H, W, cin, cout, pool)
     (3, 29, 8, 64, 64, 0), (2, 117, 32, 64, 64, 0), (5, 7, 2, 64, 64, 0), (2, 13, 6, 8, 64, 1),
     (2, 33, 128, 1, 64, 0), (2, 33, 128, 64, 64, 1), (3, 16, 64, 64, 128, 0), (2, 17, 32, 128, 128, 1),
