@@ -193,7 +193,7 @@ class PopulationEvaluator:
         if self.tmid.shape[0] != self.n_inputs or self.tside.shape[0] != self.n_inputs:
             raise ValueError(f"{self.n_inputs} inputs but {self.tmid.shape[0]} target embeddings")
         self.max_cand = max_candidates_per_pass
-        self.flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         self._streams = None
 
     def _input(self, random_crop: bool, rng) -> torch.Tensor:
@@ -207,10 +207,11 @@ class PopulationEvaluator:
             return x
         return torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
 
-    def _groups(self, P: int, c_out: int) -> int:
+    def _groups(self, P: int) -> int:
         """Number of candidate groups pipelined over two HIP streams (STITO_PIPELINE_GROUPS, default
-        1 = off).  Measured on MI355X at pop 256 x 10 s stereo: 111.1 ms/step with 1 group, 113.4
-        with 2, 117.2 with 3 -- the render of group g+1 does overlap the trunk of group g, but its
+        1 = off).  Measured on MI355X at pop 256 x 10 s stereo: 101.1 ms/step with 1 group, 103.2
+        with 2 (111.1 / 113.4 / 117.2 with 1 / 2 / 3 groups earlier in the round) -- the render of
+        group g+1 does overlap the trunk of group g, but its
         time-serial kernels (compressor envelope, reverb) do not shrink with the group, their
         workgroups pin whole CUs away from the MFMA trunk, and the trunk loses efficiency at half the
         batch.  Kept as an option for populations much larger than one trunk pass."""
@@ -231,8 +232,7 @@ class PopulationEvaluator:
         if P % B:
             raise ValueError(f"{P} candidates cannot be split over {B} inputs")
         per = P // B  # candidates per input
-        c_out = _hip.lib().stito_chain_out_channels(self.chain[0], len(self.plugins), x.shape[-2])
-        G = self._groups(P, c_out)
+        G = self._groups(P)
         step = (P + G - 1) // G
         if self.max_cand:
             step = min(step, self.max_cand)
@@ -251,6 +251,7 @@ class PopulationEvaluator:
         else:
             s_render = s_embed = main
         losses, mids, sides, audios, keep = [], [], [], [], []
+        n_calls = 0
         for p0, p1 in bounds:
             b0, b1 = p0 // per, (p1 + per - 1) // per
             with torch.cuda.stream(s_render):
@@ -274,10 +275,11 @@ class PopulationEvaluator:
                 for b, q0, q1 in spans:  # candidates of pair b against target b
                     _hip.check(L.stito_embed_loss(_hip.ptr(md[q0:q1]), _hip.ptr(sd[q0:q1]), q1 - q0, mid.shape[1],
                                                   _hip.ptr(self.tmid[b]), _hip.ptr(self.tside[b]), _hip.ptr(loss[q0:q1]),
-                                                  _hip.ptr(self.flags), _hip.stream_ptr()))
+                                                  _hip.ptr(self.flags[n_calls % 256]), _hip.stream_ptr()))
+                    n_calls += 1
                 if dropout > 0.0:  # NaN scrub + L2 norm of the embeddings handed back
                     _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1], None, None, None,
-                                                  _hip.ptr(self.flags), _hip.stream_ptr()))
+                                                  _hip.ptr(self.flags[255]), _hip.stream_ptr()))
                 if want_audio:
                     audios.append(normalize_audio_(audio, peaks))
             losses.append(loss); mids.append(mid); sides.append(side)
@@ -289,4 +291,15 @@ class PopulationEvaluator:
         embeds = {"mid": torch.cat(mids), "side": torch.cat(sides)}
         audio_out = torch.cat(audios) if want_audio else None
         del keep  # side-stream buffers: reused only after the next evaluate() has made that stream wait on main
+        self._n_flag_rows = min(n_calls, 255)
         return loss, embeds, audio_out
+
+    def nan_warning(self) -> Optional[str]:
+        """The reference's "Warning: NaNs found in ..._embeddings" (utils.py:491-497) for the last evaluate();
+        reads the device flags, so call it after the fitness has been fetched (run_es does)."""
+        fl = self.flags[: getattr(self, "_n_flag_rows", 0)].sum(dim=0).cpu()
+        if fl.numel() and int(fl[0]):
+            return "Warning: NaNs found in mid_embeddings"
+        if fl.numel() and int(fl[1]):
+            return "Warning: NaNs found in side_embeddings"
+        return None

@@ -199,8 +199,12 @@ def run_es(
 
     def evaluate(W, dropout: float = 0.0, want_audio: bool = False):
         """GPU replacement of the reference's evaluate closure (474-573)."""
-        return sharded_evaluate(W, lambda Ws: evaluator.evaluate(Ws, random_crop=random_crop, rng=rng,
-                                                                 want_audio=want_audio, dropout=dropout))
+        out = sharded_evaluate(W, lambda Ws: evaluator.evaluate(Ws, random_crop=random_crop, rng=rng,
+                                                                want_audio=want_audio, dropout=dropout))
+        warn = evaluator.nan_warning()  # after the fitness download: no extra synchronisation
+        if warn:
+            print(warn)
+        return out
 
     # setup CMA-ES
     if find_w0:

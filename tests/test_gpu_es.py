@@ -236,3 +236,22 @@ def test_eval_pst_harness_synthetic(dev, tmp_path):
         y, sr = load_wav(str(tmp_path / "seq" / f))
         assert sr == SR and y.shape[0] == 2 and abs(integrated_loudness(y.numpy().T, sr) - (-22.0)) < 0.1
     assert (tmp_path / "seq" / "00_style-es_mastering-pb.json").exists()
+
+
+def test_nan_embeddings_are_scrubbed_with_the_reference_warning(dev, capsys):
+    """utils.py:491-497: NaNs in the raw embeddings print a warning and become 0 before the L2 norm; the
+    evaluate step keeps that behaviour (flags collected on the device, read after the fitness download)."""
+    from st_ito import effects as E
+    from st_ito.style_transfer import run_es
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    with torch.no_grad():
+        pm.fc_mid.bias[3] = float("nan")
+    pm._packed = None  # re-pack the weights
+    x = O.synth_audio(61, 2, 70000)[None]
+    tgt = O.synth_audio(62, 2, 70000)[None]
+    res = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, max_iters=1, popsize=4,
+                 find_w0=False, sigma0=0.33, seed=2)
+    out = capsys.readouterr().out
+    assert "Warning: NaNs found in mid_embeddings" in out
+    assert np.isfinite(res["fopt"]) and -1.0 <= res["fopt"] <= 1.0
