@@ -163,13 +163,20 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # STITO_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional check of the N > 1 path on a
+    # 1-GPU box; RCCL refuses two ranks on one device).  The driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("STITO_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from st_ito import effects as E, _hip
     from st_ito import cmaes
