@@ -258,6 +258,9 @@ def main():
                           "MACs, so it can exceed 1.0 of the MFMA peak",
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                # the MFMA work actually issued (Winograd: 16 of the 36 counted MACs per 2x2 outputs) against the same peak
+                "mfma_issued_frac": round(achieved * (16.0 / 36.0 if all(l["algo"] == "winograd" for l in layers if l["cin"] % 8 == 0) else 1.0)
+                                          / MFMA_F32_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic_per_launch(streams_per_launch), "traffic_unit": "HBM bytes per launch (PMC, "
                 "profiles/round1_p_conv_pmc_traffic.json)",
                 "flops_per_launch": fl_step * args.steps / n_l, "avg_launch_ms": round(conv_ms.value / n_l, 4),
