@@ -326,7 +326,9 @@ struct WinoGeom {
 // fed (s_nop 3 ... 15) stretches the MFMA phase by more than the tail it removes (88.6-89.8 ms against
 // 83.2).  Issuing the transform's 16 ds_read_b128 right after the barrier shortens the tail (1000 -> 640
 // cycles) but the reads collide with the consumers' operand reads and the MFMA phase grows by as much
-// (84.6 ms).  Variants measured and
+// (84.6 ms).  Double-buffered MFMA operand registers (reads of group nu+1 ahead of the MFMAs of group nu,
+// pinned with sched_group_barrier) do not shorten the MFMA phase either: with two consumer waves per SIMD
+// the matrix pipe is already fed (64 MFMAs x 64 cycles = 4096 of the ~4550).  Variants measured and
 // rejected: a dedicated copy wave + 3 transform waves (copies land by ~2600, but the transform, now
 // concurrent with the MFMA stream, gets about one issue slot per MFMA: 4900 cycles for 3 items; 87.2 ms
 // against 83.3); transform before the patch loads (no change); n-tile persistent workgroups with the
