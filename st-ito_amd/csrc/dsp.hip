@@ -26,6 +26,14 @@
 namespace stito {
 
 
+// What a stage's store may absorb from the stages that follow it: a Gain effect (x * 10^(g/20), effects.py:
+// 532-542) and the final per-candidate peak max|y| (style_transfer.py:113) -- both pointwise on the value being
+// stored, so the fused result is bit-identical to running them as separate passes over HBM.
+struct PostOp {
+    const double *gain_coef = nullptr;  // coefficient rows of the fused Gain stage (COEF_STRIDE doubles per candidate)
+    float *peaks = nullptr;             // (pop) zero-initialised; atomicMax on the uint view (order-independent)
+};
+
 // ------------------------------------------------------------------------------------------------
 // parameter tables: (min, max) of every Parameter, reference order
 //   EQ effects.py:822-841, compressor 885-888, distortion 903-904, delay 924-926,
@@ -168,7 +176,7 @@ __device__ __forceinline__ double eq_step(double x, const EqSec (&c)[6], double 
     return x;
 }
 
-__global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out, int64_t out_cand_stride,
+__global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__restrict__ out, int64_t out_cand_stride,
                                                int C, int64_t L, const double *__restrict__ coef) {
     __shared__ float tile[EQ_NC][EQ_TS + 1];
     __shared__ double zst[12][EQ_NC];
@@ -186,6 +194,8 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
         sec[k].a1 = cf[5 * k + 3]; sec[k].a2 = cf[5 * k + 4];
     }
     const int tid = threadIdx.x;
+    const float post_gain = post.gain_coef != nullptr ? (float)post.gain_coef[(int64_t)cand * COEF_STRIDE] : 1.0f;  // x * 1.0f == x
+    float post_max = 0.0f;
     const int64_t B = (L + EQ_NC - 1) / EQ_NC;  // chunk length
     const int64_t start = (int64_t)tid * B;
     int64_t len = L - start;
@@ -292,7 +302,23 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, float *__restrict__ out
         for (int it = 0; it < EQ_NC / 8; ++it) {
             const int r = it * 8 + lr;
             const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
-            if (pos < B && idx < L) y[idx] = tile[r][lj];
+            if (pos < B && idx < L) {
+                const float v = tile[r][lj] * post_gain;
+                y[idx] = v;
+                post_max = fmaxf(post_max, fabsf(v));
+            }
+        }
+    }
+    if (post.peaks != nullptr) {  // block max -> the candidate's peak
+        __shared__ float pk_red[EQ_NC / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) post_max = fmaxf(post_max, __shfl_xor(post_max, o));
+        if ((tid & 63) == 0) pk_red[tid >> 6] = post_max;
+        __syncthreads();
+        if (tid == 0) {
+            float m = pk_red[0];
+            for (int w = 1; w < EQ_NC / 64; ++w) m = fmaxf(m, pk_red[w]);
+            atomicMax((unsigned int *)&post.peaks[cand], __float_as_uint(m));
         }
     }
 }
@@ -941,8 +967,9 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
 
     InView in{x_dev, 0, L, in_channels, pop / n_inputs, (int64_t)in_channels * L};
     int C = in_channels;
-    bool in_buffer = false;
+    bool in_buffer = false, peaks_done = false;
     for (int i = 0; i < n_fx; ++i) {
+        bool fused_next = false;  // stage i + 1 was absorbed by stage i's store
         const stito_fx_desc &fx = chain[i];
         const int Cn = fx_channels_after(fx, C);
         const double *cf = coef + (int64_t)i * pop * COEF_STRIDE;
@@ -953,9 +980,23 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
             in = InView{audio_dev, cand_stride, L, Cn};
         }
         switch (fx.kind) {
-            case STITO_FX_PARAMETRIC_EQ:
-                hipLaunchKernelGGL(k_eq, dim3(S), dim3(EQ_NC), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
+            case STITO_FX_PARAMETRIC_EQ: {
+                // the store of the EQ absorbs a Gain stage that follows it and, when it is then the end of the
+                // chain, the final peak scan (bench chain: EQ -> gain -> peak = three passes over the audio less)
+                PostOp post;
+                if (i + 1 < n_fx && chain[i + 1].kind == STITO_FX_GAIN && fx_channels_after(chain[i + 1], Cn) == Cn &&
+                    !(fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER) && !(chain[i + 1].reserved & STITO_FX_FLAG_NORMALIZE_AFTER)) {
+                    post.gain_coef = coef + (int64_t)(i + 1) * pop * COEF_STRIDE;
+                    fused_next = true;
+                }
+                if (peaks_dev != nullptr && i + (fused_next ? 2 : 1) == n_fx && Cn == C_out && !(fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER)) {
+                    STITO_HIP_CHECK(hipMemsetAsync(peaks_dev, 0, sizeof(float) * pop, st));
+                    post.peaks = peaks_dev;
+                    peaks_done = true;
+                }
+                hipLaunchKernelGGL(k_eq, dim3(S), dim3(EQ_NC), 0, st, in, post, audio_dev, cand_stride, Cn, L, cf);
                 break;
+            }
             case STITO_FX_COMPRESSOR:
             {
                 const size_t lds = (size_t)CE_SLOTS * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *) + 128 * sizeof(float);
@@ -1009,6 +1050,7 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
         C = Cn;
         in = InView{audio_dev, cand_stride, L, C};
         in_buffer = true;
+        if (fused_next) ++i;
         if (fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER) {  // normalize_stages (style_transfer.py:106-107)
             int rc = peak_strided(audio_dev, pop, (int64_t)C * L, cand_stride, stage_peaks, st);
             if (rc) return rc;
@@ -1021,6 +1063,6 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
         hipLaunchKernelGGL(k_pointwise<-1>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, C_out, L, (const double *)workspace_dev);
         STITO_LAUNCH_CHECK();
     }
-    if (peaks_dev) return stito_peak(audio_dev, pop, C_out, L, peaks_dev, stream);
+    if (peaks_dev && !peaks_done) return stito_peak(audio_dev, pop, C_out, L, peaks_dev, stream);
     return STITO_OK;
 }
