@@ -501,3 +501,26 @@ def test_mfcc_feature_embeds_vs_oracle(dev):
         np.testing.assert_allclose(np.linalg.norm(got.numpy(), axis=1), 1.0, atol=1e-6)
     with pytest.raises(NotImplementedError):
         get_mfcc_feature_embeds(x, model, 44100)
+
+
+@pytest.mark.parametrize("kinds,chs", [(["ParametricEQ", "Gain", "Reverb"], 2), (["ParametricEQ", "Gain"], 1),
+                                        (["Gain", "ParametricEQ"], 2), (["ParametricEQ", "Gain", "ParametricEQ", "Gain"], 2)])
+def test_eq_store_fusion_paths(dev, kinds, chs):
+    """The EQ kernel's store absorbs a following Gain stage and, at the end of the chain, the peak scan
+    (dsp.hip PostOp).  Chains where the fused pair is in the middle, at the end, absent, and repeated; with and
+    without per-stage normalisation (which disables the fusion) -- all against the oracle's stage-by-stage path."""
+    from st_ito.style_transfer import process_audio
+    op, pp = _plugins_pair(kinds)
+    D = sum(p["num_params"] for p in op.values())
+    x = O.synth_audio(33, chs, 20011).numpy()
+    W = np.random.default_rng(len(kinds) * 7 + chs).random((3, D))
+    got, peaks = _render_gpu(pp, x, W, dev, normalize=False)
+    for p in range(3):
+        ref = _oracle_chain_raw(op, x, W[p])
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got[p] - ref).max() / scale < 2e-5
+        assert peaks[p] == np.abs(got[p]).max()          # fused or separate, the peak is the exact max of what was stored
+    for ns in (False, True):
+        ref = O.process_audio(x.copy(), W[0], SR, op, normalize_stages=ns)
+        out = process_audio(x.copy(), W[0], SR, pp, normalize_stages=ns)
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
