@@ -55,7 +55,7 @@ enum {
 };
 
 #define STITO_MAX_FX_PARAMS 32
-/* stito_fx_desc.reserved bit 0: joint peak normalisation of every candidate after this stage --
+/* stito_fx_desc.flags bit 0: joint peak normalisation of every candidate after this stage --
  * process_audio(normalize_stages=True), style_transfer.py:106-107. */
 #define STITO_FX_FLAG_NORMALIZE_AFTER 1u
 
@@ -68,7 +68,7 @@ typedef struct {
     int32_t has_bypass;   /* 1: slot 0 is the dead "our_bypass" dimension (style_transfer.py:28, 89-92) */
     uint32_t fixed_mask;  /* bit p set: parameter p comes from fixed_raw[p], but still consumes a w slot
                              (style_transfer.py:79-84) */
-    uint32_t reserved;    /* flags: STITO_FX_FLAG_* (the field keeps its first-round name) */
+    uint32_t flags;       /* STITO_FX_FLAG_* (ABI version 2 renamed this field from `reserved`; same offset) */
     double fixed_raw[STITO_MAX_FX_PARAMS]; /* raw [0,1] value = (v - min) / (max - min) */
     const float *aux_dev; /* STITO_FX_NOISE_REVERB: band-filtered noise bank (2, 12, aux_len) float32 on the device
                              (the library draws it afresh per call; here it is an input); NULL otherwise */
@@ -76,6 +76,7 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
+/* ABI version: 2 (1 = first round: stito_fx_desc.flags was called `reserved`, no stito_timing_* context). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
@@ -204,12 +205,13 @@ int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, i
  * pool != 0: 2x2 average pooling (floor). */
 /* Profiling aid: with buf_dev != NULL the Winograd launches use an instrumented instantiation whose
  * workgroup 100 records s_memtime stamps of 32 chunks x 12 waves x 8 phases (int64) into buf_dev;
- * NULL (default) restores the plain kernel.  See tools/wino_timeline.py. */
+ * NULL (default) restores the plain kernel.  Thread-local.  See tools/wino_timeline.py. */
 int stito_debug_wino_trace(long long *buf_dev);
 /* Measurement aid (bench.py "roofline"): while enabled, stito_cnn14_forward brackets every f32-MFMA
  * conv launch (cin % 8 == 0: 11 of the 12 convs) with hipEventRecord on the launch stream.
  * stito_conv_timing_read waits for the recorded events, returns their summed elapsed time and the
- * number of launches, and clears the list.  Not thread-safe (one host thread per GPU). */
+ * number of launches, and clears the list.  The switch and the event list are thread-local (one host thread per
+ * GPU, like stito_last_error): enable and read from the thread that calls stito_cnn14_forward. */
 int stito_conv_timing_enable(int on);
 int stito_conv_timing_read(double *total_ms, int *n_launches);
 /* 1 if stito_conv3x3_bn_relu can run this shape with `algo`, else 0. */
@@ -252,6 +254,13 @@ int stito_mfcc_stats(const float *logmel_dev, int n_items, int channels, int64_t
 int stito_embed_loss(float *mid_dev, float *side_dev, int n_cand, int embed_dim,
                      const float *target_mid_dev, const float *target_side_dev, float *loss_dev,
                      int32_t *flags_dev /* (2) scratch */, void *stream);
+
+/* Generic-metric form of the loss (any embed_func returning a dict of (n_cand, E_k) embeddings,
+ * style_transfer.py:544-571): loss[c] (+)= weight * -cosine_similarity(embed[c], target), eps 1e-8.
+ * The host walks the dict: first entry with accumulate = 0, the others with 1, weight = 1 / n_entries
+ * (the reference's mean over the stacked distances).  embed (n_cand, embed_dim), target (embed_dim). */
+int stito_neg_cosine(const float *embed_dev, int n_cand, int embed_dim, const float *target_dev, float weight,
+                     int accumulate, float *loss_dev, void *stream);
 
 #ifdef __cplusplus
 }

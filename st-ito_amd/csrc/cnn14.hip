@@ -855,6 +855,27 @@ __global__ __launch_bounds__(256) void k_embed_loss(float *__restrict__ mid, flo
     if (tmid != nullptr && threadIdx.x == 0) loss[cand] = ((-cosv[0]) + (-cosv[1])) / 2.0f;
 }
 
+// -cosine_similarity(emb[c], target) of one named embedding (style_transfer.py:544-559), written as
+// loss[c] = weight * (-cos) or accumulated onto loss[c]: the generic-metric form of the loss (the dict an
+// embed_func returns is walked by the host; the mean over its entries is weight = 1 / n_entries).
+__global__ __launch_bounds__(256) void k_neg_cosine(const float *__restrict__ emb, const float *__restrict__ tgt, int E,
+                                                     float weight, int accumulate, float *__restrict__ loss) {
+    __shared__ float red[4];
+    const float *e = emb + (int64_t)blockIdx.x * E;
+    float dot = 0.0f, s2 = 0.0f, t2 = 0.0f;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const float v = e[i], tv = tgt[i];
+        dot = fmaf(v, tv, dot); s2 = fmaf(v, v, s2); t2 = fmaf(tv, tv, t2);
+    }
+    dot = block_sum_256(dot, red);
+    s2 = block_sum_256(s2, red);
+    t2 = block_sum_256(t2, red);
+    if (threadIdx.x == 0) {
+        const float c = dot / (fmaxf(sqrtf(s2), 1e-8f) * fmaxf(sqrtf(t2), 1e-8f));  // torch.cosine_similarity, eps 1e-8
+        loss[blockIdx.x] = (accumulate ? loss[blockIdx.x] : 0.0f) + weight * (-c);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight preparation
 // ------------------------------------------------------------------------------------------------
@@ -964,7 +985,7 @@ static int launch_conv_tw(const float *in, const float *wpk, const float *scale,
 }
 
 
-static long long *g_wino_trace = nullptr;  // stito_debug_wino_trace
+static thread_local long long *g_wino_trace = nullptr;  // stito_debug_wino_trace (per host thread, like stito_last_error)
 
 template <int TTW, bool POOL>
 static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t &blocks) {
@@ -1149,7 +1170,8 @@ struct ConvTiming {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;  // created on demand, reused
     size_t used = 0;
-} g_conv_timing;
+};
+thread_local ConvTiming g_conv_timing;  // one host thread drives one GPU: the state is per thread, like stito_last_error
 }  // namespace
 
 extern "C" int stito_conv_timing_enable(int on) {
@@ -1252,6 +1274,16 @@ extern "C" int stito_embed_loss(float *mid_dev, float *side_dev, int n_cand, int
     STITO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_embed_loss, dim3(n_cand), dim3(256), 0, st, mid_dev, side_dev, embed_dim, target_mid_dev,
                        target_side_dev, loss_dev, flags_dev, 0);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+extern "C" int stito_neg_cosine(const float *embed_dev, int n_cand, int embed_dim, const float *target_dev, float weight,
+                                int accumulate, float *loss_dev, void *stream) {
+    STITO_REQUIRE(n_cand > 0 && embed_dim > 0, STITO_E_INVALID, "empty embeddings");
+    STITO_REQUIRE(embed_dev != nullptr && target_dev != nullptr && loss_dev != nullptr, STITO_E_INVALID, "null pointer");
+    hipLaunchKernelGGL(k_neg_cosine, dim3(n_cand), dim3(256), 0, (hipStream_t)stream, embed_dev, target_dev, embed_dim, weight,
+                       accumulate, loss_dev);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }

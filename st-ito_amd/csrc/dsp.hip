@@ -985,11 +985,11 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                 // chain, the final peak scan (bench chain: EQ -> gain -> peak = three passes over the audio less)
                 PostOp post;
                 if (i + 1 < n_fx && chain[i + 1].kind == STITO_FX_GAIN && fx_channels_after(chain[i + 1], Cn) == Cn &&
-                    !(fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER) && !(chain[i + 1].reserved & STITO_FX_FLAG_NORMALIZE_AFTER)) {
+                    !(fx.flags & STITO_FX_FLAG_NORMALIZE_AFTER) && !(chain[i + 1].flags & STITO_FX_FLAG_NORMALIZE_AFTER)) {
                     post.gain_coef = coef + (int64_t)(i + 1) * pop * COEF_STRIDE;
                     fused_next = true;
                 }
-                if (peaks_dev != nullptr && i + (fused_next ? 2 : 1) == n_fx && Cn == C_out && !(fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER)) {
+                if (peaks_dev != nullptr && i + (fused_next ? 2 : 1) == n_fx && Cn == C_out && !(fx.flags & STITO_FX_FLAG_NORMALIZE_AFTER)) {
                     STITO_HIP_CHECK(hipMemsetAsync(peaks_dev, 0, sizeof(float) * pop, st));
                     post.peaks = peaks_dev;
                     peaks_done = true;
@@ -1051,7 +1051,7 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
         in = InView{audio_dev, cand_stride, L, C};
         in_buffer = true;
         if (fused_next) ++i;
-        if (fx.reserved & STITO_FX_FLAG_NORMALIZE_AFTER) {  // normalize_stages (style_transfer.py:106-107)
+        if (fx.flags & STITO_FX_FLAG_NORMALIZE_AFTER) {  // normalize_stages (style_transfer.py:106-107)
             int rc = peak_strided(audio_dev, pop, (int64_t)C * L, cand_stride, stage_peaks, st);
             if (rc) return rc;
             rc = normalize_strided(audio_dev, pop, (int64_t)C * L, cand_stride, stage_peaks, st);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libstito_hip.so")
 
 FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB = range(7)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
-FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.reserved bit 0
+FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
 CONV_DIRECT, CONV_WINOGRAD = 0, 1
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
@@ -25,7 +25,7 @@ E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 class FxDesc(Structure):
     _fields_ = [
         ("kind", c_int32), ("num_channels", c_int32), ("w_offset", c_int32), ("has_bypass", c_int32),
-        ("fixed_mask", c_uint32), ("reserved", c_uint32), ("fixed_raw", c_double * MAX_FX_PARAMS),
+        ("fixed_mask", c_uint32), ("flags", c_uint32), ("fixed_raw", c_double * MAX_FX_PARAMS),
         ("aux_dev", c_void_p), ("aux_len", c_int64),
     ]
 
@@ -92,6 +92,7 @@ SIGNATURES = {
     "stito_spectral_centroid": (c_int, [c_void_p, c_int, c_int, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
     "stito_embed_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "stito_neg_cosine": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_int, c_void_p, c_void_p]),
 }
 
 

@@ -3,11 +3,14 @@
 The reference drives pycma (`cma.CMAEvolutionStrategy(w0, sigma0, {"bounds": [0, 1],
 "popsize": P})`, st_ito/style_transfer.py:614, 624, 651-652, 672-673); pycma is an un-pinned
 third-party package that is not available here, so this module implements the same interface
-(ask / tell / result / disp / stop) with the standard algorithm (Hansen, "The CMA Evolution
-Strategy: A Tutorial"): weighted recombination, CSA step-size control, rank-one + rank-mu
-covariance update, lazy eigendecomposition, and pycma's BoxConstraintsLinQuadTransformation for
-the [0, 1] bounds.  It is deterministic under `seed`, uses only fitness ranks plus the best
-value, and every rank of a multi-GPU run steps an identical replica.
+(ask / tell / result / disp / stop) with the algorithm pycma runs by default (Hansen, "The CMA
+Evolution Strategy: A Tutorial", 2016/2023 revision): weighted recombination, CSA step-size control
+with c_sigma = (mu_eff + 2) / (N + mu_eff + 3), rank-one + rank-mu covariance update with ACTIVE
+(negative) recombination weights (pycma `CMA_active=True`), lazy eigendecomposition, and pycma's
+BoxConstraintsLinQuadTransformation for the [0, 1] bounds -- the initial mean is the transformation's
+INVERSE image of x0, so the first distribution is centred on w0 itself.  It is deterministic under
+`seed`, uses only fitness ranks plus the best value, and every rank of a multi-GPU run steps an
+identical replica.  Not bit-compatible with pycma (different random stream); same update rule.
 """
 from __future__ import annotations
 
@@ -41,6 +44,19 @@ class BoundTransform:
         x[up] = ub - (y[up] - (ub + au)) ** 2 / (4.0 * au)
         return x
 
+    def inverse(self, x: np.ndarray) -> np.ndarray:
+        """Genotype in [lb - al, ub + au] whose image is x (x is clipped into [lb, ub] first), as pycma
+        maps x0 before the first ask(): identity in the linear region, y = lb - al + 2 sqrt(al (x - lb))
+        towards the lower bound and symmetrically towards the upper one."""
+        lb, ub, al, au = self.lb, self.ub, self.al, self.au
+        x = np.clip(np.asarray(x, dtype=np.float64), lb, ub)
+        y = x.copy()
+        low = x < lb + al
+        y[low] = (lb - al) + 2.0 * np.sqrt(al * (x[low] - lb))
+        up = x > ub - au
+        y[up] = (ub + au) - 2.0 * np.sqrt(au * (ub - x[up]))
+        return y
+
 
 class _Result(tuple):
     """es.result: indexable like pycma's (xbest, fbest, evals_best, evaluations, iterations, xmean, stds)."""
@@ -61,17 +77,32 @@ class CMAEvolutionStrategy:
         b = opts.get("bounds", None)
         self.boundary = BoundTransform(b[0], b[1]) if b is not None and b[0] is not None else None
         self.mean = np.asarray(x0, dtype=np.float64).copy()
+        if self.boundary is not None:
+            self.mean = self.boundary.inverse(self.mean)
         self.sigma = float(sigma0)
         self.sigma0 = float(sigma0)
+        self.active = bool(opts.get("CMA_active", True))
+        # recombination weights, Tutorial eq. (49)-(53): w'_i = ln((lam + 1) / 2) - ln i for all lam ranks
         self.mu = self.lam // 2
-        w = math.log((self.lam + 1) / 2.0) - np.log(np.arange(1, self.mu + 1))
-        self.weights = w / w.sum()
-        self.mueff = 1.0 / np.sum(self.weights ** 2)
+        wp = math.log((self.lam + 1) / 2.0) - np.log(np.arange(1, self.lam + 1))
+        pos, neg = wp[: self.mu], wp[self.mu:]
+        self.mueff = float(pos.sum() ** 2 / np.sum(pos ** 2))
+        mueff_neg = float(neg.sum() ** 2 / np.sum(neg ** 2)) if len(neg) and np.any(neg != 0) else 0.0
         self.cc = (4 + self.mueff / N) / (N + 4 + 2 * self.mueff / N)
-        self.cs = (self.mueff + 2) / (N + self.mueff + 5)
-        self.c1 = 2 / ((N + 1.3) ** 2 + self.mueff)
-        self.cmu = min(1 - self.c1, 2 * (self.mueff - 2 + 1 / self.mueff) / ((N + 2) ** 2 + self.mueff))
+        self.cs = (self.mueff + 2) / (N + self.mueff + 3)
+        alpha_cov = 2.0
+        self.c1 = alpha_cov / ((N + 1.3) ** 2 + self.mueff)
+        self.cmu = min(1 - self.c1, alpha_cov * (0.25 + self.mueff + 1 / self.mueff - 2) / ((N + 2) ** 2 + alpha_cov * self.mueff / 2))
         self.damps = 1 + 2 * max(0.0, math.sqrt((self.mueff - 1) / (N + 1)) - 1) + self.cs
+        w = np.zeros(self.lam)
+        w[: self.mu] = pos / pos.sum()
+        if self.active and len(neg) and neg.sum() != 0:
+            a_mu = 1 + self.c1 / self.cmu
+            a_mueff = 1 + 2 * mueff_neg / (self.mueff + 2)
+            a_posdef = (1 - self.c1 - self.cmu) / (N * self.cmu)
+            w[self.mu:] = min(a_mu, a_mueff, a_posdef) * neg / (-neg.sum())   # sum of negative weights = -min(...)
+        self.weights_all = w
+        self.weights = w[: self.mu]
         self.chiN = math.sqrt(N) * (1 - 1.0 / (4 * N) + 1.0 / (21 * N * N))
         self.pc = np.zeros(N)
         self.ps = np.zeros(N)
@@ -114,16 +145,23 @@ class CMAEvolutionStrategy:
             self.best_f = float(f[order[0]])
             self.best_x = np.asarray(solutions[order[0]], dtype=np.float64).copy()
             self.best_evals = self.counteval - self.lam + int(order[0]) + 1
-        X = self._geno[order[: self.mu]]
+        G = self._geno[order]
+        X = G[: self.mu]
         old = self.mean
         self.mean = self.weights @ X
         ymean = (self.mean - old) / self.sigma
         self.ps = (1 - self.cs) * self.ps + math.sqrt(self.cs * (2 - self.cs) * self.mueff) * (self.invsqrtC @ ymean)
         hsig = (np.linalg.norm(self.ps) / math.sqrt(1 - (1 - self.cs) ** (2 * self.countiter)) / self.chiN) < (1.4 + 2 / (N + 1))
         self.pc = (1 - self.cc) * self.pc + (math.sqrt(self.cc * (2 - self.cc) * self.mueff) * ymean if hsig else 0.0)
-        Y = (X - old[None, :]) / self.sigma
-        c1a = self.c1 * (1 - (0 if hsig else 1) * self.cc * (2 - self.cc))
-        self.C = (1 - c1a - self.cmu) * self.C + self.c1 * np.outer(self.pc, self.pc) + self.cmu * (Y.T * self.weights[None, :]) @ Y
+        Y = (G - old[None, :]) / self.sigma
+        wo = self.weights_all.copy()
+        nz = wo < 0
+        if nz.any():  # Tutorial eq. (46): negative weights scaled so that a negative update keeps C positive definite
+            mah2 = np.sum((Y[nz] @ self.invsqrtC.T) ** 2, axis=1)
+            wo[nz] = wo[nz] * N / np.maximum(mah2, 1e-300)
+        dh = (0 if hsig else 1) * self.cc * (2 - self.cc)
+        self.C = ((1 + self.c1 * dh - self.c1 - self.cmu * self.weights_all.sum()) * self.C + self.c1 * np.outer(self.pc, self.pc)
+                  + self.cmu * (Y.T * wo[None, :]) @ Y)
         self.sigma *= math.exp(min(1.0, (self.cs / self.damps) * (np.linalg.norm(self.ps) / self.chiN - 1)))
         if self.counteval - self.eigeneval > self.lam / (self.c1 + self.cmu) / N / 10:
             self.eigeneval = self.counteval

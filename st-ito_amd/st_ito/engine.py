@@ -68,7 +68,7 @@ def compile_chain(plugins: Dict[str, dict], normalize_stages: bool = False) -> T
                 d.fixed_raw[p] = prm.raw_value
                 mask |= 1 << p
         d.fixed_mask = mask
-        d.reserved = _hip.FX_FLAG_NORMALIZE_AFTER if normalize_stages else 0  # style_transfer.py:106-107
+        d.flags = _hip.FX_FLAG_NORMALIZE_AFTER if normalize_stages else 0  # style_transfer.py:106-107
         if kind == _hip.FX_NOISE_REVERB:  # the band-filtered noise bank is an input of the stage
             _hip.require_gpu()
             bank = inst.noise_bank_device(torch.device("cuda", torch.cuda.current_device()))
@@ -177,21 +177,35 @@ class PopulationEvaluator:
     scores the candidates of pair b against target b."""
 
     def __init__(self, x: torch.Tensor, sample_rate: int, plugins: Dict[str, dict], model, target_embeds: dict,
-                 device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None):
+                 device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None,
+                 embed_func=None, normalize_stages: bool = False):
+        """embed_func: None or st_ito.utils.get_param_embeds -> the fused AFx-Rep path (render -> log-mel with the
+        peak normalisations folded into the STFT loader -> Cnn14 -> loss).  Any other embed_func(x, model, sample_rate)
+        -> dict of (P, E_k) embeddings (the MIR / MFCC metrics of st_ito.utils, or a user function working on GPU
+        tensors) takes the generic path of style_transfer.py:531-571: the rendered population is peak-normalised in
+        HBM, handed to embed_func as one (P, C, L) GPU tensor, and every entry of the returned dict is scored against
+        the target's entry of the same name."""
         _hip.require_gpu()
+        from . import utils as _utils
+
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.sample_rate = sample_rate
         self.plugins = plugins
         self.model = model
-        self.chain = compile_chain(plugins)
+        self.chain = compile_chain(plugins, normalize_stages)
         self.ndims = self.chain[1]
         assert x.dim() == 3, "input audio must be (batch, chs, seq_len)"
         self.n_inputs = x.shape[0]
         self.x_full = x.to(self.device, torch.float32).contiguous()
-        self.tmid = target_embeds["mid"].to(self.device, torch.float32).contiguous().view(-1, target_embeds["mid"].shape[-1])
-        self.tside = target_embeds["side"].to(self.device, torch.float32).contiguous().view(-1, target_embeds["side"].shape[-1])
-        if self.tmid.shape[0] != self.n_inputs or self.tside.shape[0] != self.n_inputs:
-            raise ValueError(f"{self.n_inputs} inputs but {self.tmid.shape[0]} target embeddings")
+        self.embed_func = embed_func
+        self.fused = embed_func is None or embed_func is _utils.get_param_embeds
+        self.targets = {k: v.detach().to(self.device, torch.float32).contiguous().view(-1, v.shape[-1])
+                        for k, v in target_embeds.items()}
+        for k, v in self.targets.items():
+            if v.shape[0] != self.n_inputs:
+                raise ValueError(f"{self.n_inputs} inputs but {v.shape[0]} target embeddings ({k})")
+        if self.fused:
+            self.tmid, self.tside = self.targets["mid"], self.targets["side"]
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         self._streams = None
@@ -201,8 +215,8 @@ class PopulationEvaluator:
         x = self.x_full
         n = x.shape[-1]
         if n > CROP_LEN:
-            if random_crop and (n - CROP_LEN) > 16384:
-                start = int(rng.randint(16384, n - CROP_LEN))
+            if random_crop:  # 506-514: start 0 unless more than 16384 samples are spare (the crop still happens)
+                start = int(rng.randint(16384, n - CROP_LEN)) if (n - CROP_LEN) > 16384 else 0
                 return x[..., start:start + CROP_LEN].contiguous()
             return x
         return torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
@@ -250,7 +264,7 @@ class PopulationEvaluator:
             s_embed.wait_stream(main)
         else:
             s_render = s_embed = main
-        losses, mids, sides, audios, keep = [], [], [], [], []
+        losses, mids, sides, audios, keep, generic_embeds = [], [], [], [], [], []
         n_calls = 0
         for p0, p1 in bounds:
             b0, b1 = p0 // per, (p1 + per - 1) // per
@@ -260,6 +274,16 @@ class PopulationEvaluator:
                 audio, peaks = render_population(self.plugins, xin, Wc, self.sample_rate, chain=self.chain)
                 rendered = torch.cuda.Event()
                 rendered.record(s_render)
+            if not self.fused:
+                with torch.cuda.stream(s_embed):
+                    s_embed.wait_event(rendered)
+                    spans = [(0, 0, p1 - p0)] if B == 1 else [(b, (b - b0) * per, (b - b0 + 1) * per) for b in range(b0, b1)]
+                    loss, emb = self._generic_loss(normalize_audio_(audio, peaks), spans, dropout)
+                    if want_audio:
+                        audios.append(audio)
+                losses.append(loss); generic_embeds.append(emb)
+                keep.append((Wc, audio, peaks))
+                continue
             with torch.cuda.stream(s_embed):
                 s_embed.wait_event(rendered)
                 mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
@@ -288,11 +312,38 @@ class PopulationEvaluator:
             main.wait_stream(s_render)
             main.wait_stream(s_embed)
         loss = torch.cat(losses) if len(losses) > 1 else losses[0]
-        embeds = {"mid": torch.cat(mids), "side": torch.cat(sides)}
+        if self.fused:
+            embeds = {"mid": torch.cat(mids), "side": torch.cat(sides)}
+        else:
+            embeds = {k: torch.cat([e[k] for e in generic_embeds]) for k in generic_embeds[0]}
         audio_out = torch.cat(audios) if want_audio else None
         del keep  # side-stream buffers: reused only after the next evaluate() has made that stream wait on main
         self._n_flag_rows = min(n_calls, 255)
         return loss, embeds, audio_out
+
+    def _generic_loss(self, audio: torch.Tensor, spans, dropout: float):
+        """style_transfer.py:531-571 for an arbitrary metric: embed_func on the normalised population (GPU tensor),
+        then mean over the dict's entries of -cosine_similarity to the target entry (stito_neg_cosine)."""
+        L = _hip.lib()
+        embeds = self.embed_func(audio, self.model, self.sample_rate)
+        if not isinstance(embeds, dict) or not embeds:
+            raise ValueError("embed_func must return a non-empty dict of (batch, embed_dim) tensors")
+        n = audio.shape[0]
+        loss = torch.empty(n, dtype=torch.float32, device=self.device)
+        out = {}
+        for idx, (name, emb) in enumerate(embeds.items()):
+            if name not in self.targets:
+                raise KeyError(f"target embeddings have no entry {name!r}")
+            emb = emb.detach().to(self.device, torch.float32).contiguous().view(n, -1)
+            out[name] = emb
+            tgt = self.targets[name]
+            if tgt.shape[1] != emb.shape[1]:
+                raise ValueError(f"{name}: candidate embeddings have {emb.shape[1]} dims, the target {tgt.shape[1]}")
+            ed = torch.nn.functional.dropout(emb, p=dropout, training=True).contiguous() if dropout > 0.0 else emb
+            for b, q0, q1 in spans:
+                _hip.check(L.stito_neg_cosine(_hip.ptr(ed[q0:q1]), q1 - q0, emb.shape[1], _hip.ptr(tgt[b]), 1.0 / len(embeds),
+                                              0 if idx == 0 else 1, _hip.ptr(loss[q0:q1]), _hip.stream_ptr()))
+        return loss, out
 
     def nan_warning(self) -> Optional[str]:
         """The reference's "Warning: NaNs found in ..._embeddings" (utils.py:491-497) for the last evaluate();

@@ -85,15 +85,22 @@ def parameters_to_dict(w: np.ndarray, plugins: List[dict]):
     return w_dict
 
 
-def savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir: str, sample_rate: int):
-    """reference style_transfer.py:362-396: one wav per candidate, sorted by fitness."""
+def savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir: str, sample_rate: int, first: int = 0):
+    """reference style_transfer.py:362-396: one wav per candidate, sorted by fitness.
+
+    `fvals` is the full population's fitness; `output_audios` holds candidates [first, first + len)
+    of it -- under torch.distributed every rank passes its own shard and writes only its own
+    candidates' files, named by their rank in the global ordering, so the directory ends up with the
+    same files a single process writes (no audio is communicated)."""
     from .audio_io import save_wav
 
     pop_dir = os.path.join(run_dir, f"pop_{iteration}")
     os.makedirs(pop_dir, exist_ok=True)
     order = sorted(range(len(fvals)), key=lambda i: fvals[i])
     for idx, i in enumerate(order):
-        audio = output_audios[i]
+        if not first <= i < first + len(output_audios):
+            continue
+        audio = output_audios[i - first]
         audio = audio / torch.max(torch.abs(audio)).clamp(min=1e-8)
         save_wav(os.path.join(pop_dir, f"output_audio_pop_{idx}_fval_{fvals[i]:0.4e}.wav"), audio.cpu(), sample_rate)
 
@@ -183,6 +190,13 @@ def run_es(
         raise NotImplementedError("content_model is not built (unused by run_optim.py)")
     total_num_params = sum([plugin["num_params"] for plugin in plugins.values()])
     bs, chs, seq_len = input_audio.shape
+    dist, rank, world = _dist_info()
+    if world > 1 and seed is None:
+        # every rank steps a replica of the CMA-ES state and slices the same ask() batch: the replicas (and the
+        # find_w0 / random-crop draws) must be identical, so an unseeded run agrees on rank 0's draw of a seed
+        box = [int(np.random.SeedSequence().generate_state(1)[0] & 0x7FFFFFFF) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
     rng = np.random.RandomState(seed) if seed is not None else np.random
 
     # peak normalize (in place like the reference, 452-453)
@@ -192,10 +206,11 @@ def run_es(
     # compute target embedding (only once)
     target_embed = embed_func(target_audio, model, sample_rate)
 
-    evaluator = engine.PopulationEvaluator(input_audio, sample_rate, plugins, model, target_embed)
+    # (run_optim.py:608 passes normalize_stages=...; the reference's run_es swallows it in **kwargs and its evaluate
+    # never forwards it to process_audio, so the population is rendered without per-stage normalisation here too)
+    evaluator = engine.PopulationEvaluator(input_audio, sample_rate, plugins, model, target_embed, embed_func=embed_func)
     if evaluator.ndims != total_num_params:
         raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
-    _, rank, world = _dist_info()
 
     def evaluate(W, dropout: float = 0.0, want_audio: bool = False):
         """GPU replacement of the reference's evaluate closure (474-573)."""
@@ -213,8 +228,9 @@ def run_es(
         fvals, output_embeds, output_audios = evaluate(tmp_w0s, dropout=dropout, want_audio=savepop)
         print(fvals)
         w0 = tmp_w0s[int(np.argmin(fvals))]
-        if savepop and rank == 0:
-            savepop_to_disk(-1, fvals, output_embeds, output_audios, run_dir, sample_rate)
+        if savepop:
+            savepop_to_disk(-1, fvals, output_embeds, output_audios, run_dir, sample_rate,
+                            first=shard_bounds(len(fvals), rank, world)[0])
     else:
         if w0 is None:
             w0 = np.ones(total_num_params) * 0.5
@@ -244,8 +260,9 @@ def run_es(
         wopt_history.append(es.result[0])
         fval_history.append(es.result[1])
 
-        if savepop and rank == 0:
-            savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir, sample_rate)
+        if savepop:
+            savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir, sample_rate,
+                            first=shard_bounds(len(fvals), rank, world)[0])
         es.tell(W, fvals)
         if rank == 0:
             es.disp()
@@ -323,7 +340,7 @@ def run_es_batch(
         xs /= xs.abs().amax(dim=(1, 2), keepdim=True).clamp(min=1e-8)
         ts /= ts.abs().amax(dim=(1, 2), keepdim=True).clamp(min=1e-8)
         target_embed = embed_func(ts, model, sample_rate)
-        evaluator = engine.PopulationEvaluator(xs, sample_rate, plugins, model, target_embed)
+        evaluator = engine.PopulationEvaluator(xs, sample_rate, plugins, model, target_embed, embed_func=embed_func)
         if evaluator.ndims != total_num_params:
             raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
         rng = np.random.RandomState(seed) if seed is not None else np.random

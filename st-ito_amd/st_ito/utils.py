@@ -68,6 +68,35 @@ def get_param_embeds(
     return {"mid": mid.type_as(x_device), "side": side.type_as(x_device)}
 
 
+def _load_checkpoint(ckpt_path: str) -> dict:
+    """torch.load of a (downloaded) Lightning checkpoint WITHOUT executing pickled code.
+
+    The reference calls torch.load(ckpt_path, map_location="cpu") (utils.py:536), which on the torch it
+    was written for unpickles arbitrary objects.  Here the file is read with weights_only=True; classes
+    the checkpoint mentions outside torch's allow-list (Lightning / jsonargparse hyper-parameter
+    containers, callbacks state, ...) are mapped to inert stand-ins of the same qualified name -- their
+    attributes are restored as plain data, no constructor or reducer of the real class ever runs -- since
+    only checkpoint["state_dict"] is used.  STITO_TRUST_CHECKPOINT=1 restores the reference's full unpickle."""
+    import pickle
+    import re
+
+    if os.environ.get("STITO_TRUST_CHECKPOINT", "0") == "1":
+        return torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    stand_ins = []
+    for _ in range(64):
+        try:
+            with torch.serialization.safe_globals(stand_ins):
+                return torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            m = re.search(r"Unsupported global: GLOBAL ([\w\.]+) was not an allowed global", str(e))
+            if m is None or any(f"{c.__module__}.{c.__qualname__}" == m.group(1) for c in stand_ins):
+                raise
+            module, _, name = m.group(1).rpartition(".")
+            stand_ins.append(type(name, (), {"__module__": module, "__qualname__": name,
+                                             "__setstate__": lambda self, state: None}))
+    raise pickle.UnpicklingError(f"{ckpt_path}: too many foreign classes in the checkpoint")
+
+
 def load_param_model(ckpt_path: str = None, use_gpu: bool = False):
     """reference utils.py:511-551.  Reads config.yaml next to the checkpoint, builds the encoder
     (class path `lcap.*`/`st_ito.*` -> this package), loads the `encoder.*` weights strictly.
@@ -91,7 +120,7 @@ def load_param_model(ckpt_path: str = None, use_gpu: bool = False):
     module_path = module_path.replace("lcap", "st_ito")
     module = import_module(module_path)
     model = getattr(module, class_name)(**encoder_configs["init_args"])
-    checkpoint = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    checkpoint = _load_checkpoint(ckpt_path)
     state_dict = {}
     for k, v in checkpoint["state_dict"].items():
         if k.startswith("encoder"):

@@ -255,3 +255,63 @@ def test_nan_embeddings_are_scrubbed_with_the_reference_warning(dev, capsys):
     out = capsys.readouterr().out
     assert "Warning: NaNs found in mid_embeddings" in out
     assert np.isfinite(res["fopt"]) and -1.0 <= res["fopt"] <= 1.0
+
+
+def test_run_es_on_mfcc_metric_matches_oracle_driven_es(dev):
+    """run_es takes any embed_func (style_transfer.py:531-571 walks whatever dict it returns).
+    ES on the MFCC metric (get_mfcc_feature_embeds, utils.py:116-159): the HIP-driven run (render ->
+    stito_normalize_audio -> stito_logmel / stito_mfcc_stats -> stito_neg_cosine) and the oracle-driven run of the
+    same seeded CMA-ES select a bit-identical parameter vector."""
+    from st_ito import effects as E, cmaes
+    from st_ito.style_transfer import run_es
+    from st_ito.utils import get_mfcc_feature_embeds, load_mfcc_feature_extractor
+    model = load_mfcc_feature_extractor()
+    n, P, iters, seed, D = 96000, 8, 4, 7, 22
+    x = O.synth_audio(81, 2, n)[None]
+    op = O.make_plugins(["ParametricEQ", "Compressor"])
+    tgt = torch.from_numpy(O.process_audio(O.synth_audio(82, 2, n).numpy(), np.random.default_rng(3).random(D), SR, op))[None]
+    o_embed = lambda a, m, sr: {"mono": O.mfcc_feature_embeds(a, sr)}  # noqa: E731
+    xc, tc = x.clone(), tgt.clone()
+    xc /= xc.abs().max().clamp(min=1e-8); tc /= tc.abs().max().clamp(min=1e-8)
+    te = o_embed(tc, None, SR)
+    es = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P, "seed": seed})
+    for _ in range(iters):
+        W = es.ask()
+        f, _, _ = O.evaluate(W, xc, SR, op, te, None, embed_func=o_embed)
+        es.tell(W, f)
+    res = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq-comp"), model, get_mfcc_feature_embeds, max_iters=iters,
+                 popsize=P, find_w0=False, sigma0=0.33, seed=seed, early_stop=False)
+    np.testing.assert_array_equal(res["wopt"], es.result[0])
+    assert abs(res["fopt"] - es.result[1]) < 1e-4
+
+
+def test_generic_metric_path_mir_features_and_dropout(dev):
+    """The generic path with a multi-entry dict (get_mir_feature_embeds: lufs, rms, crest, barkspectrum,
+    spectral_centroid): loss = mean over the entries of -cosine_similarity, checked against torch on the
+    embeddings the evaluator hands back; multi-pair batches score pair b against target b; a missing
+    target entry is an error like the reference's KeyError."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_mir_feature_embeds, load_mir_feature_extractor
+    model = load_mir_feature_extractor()
+    B, P, n = 2, 3, 70000
+    xs = torch.stack([O.synth_audio(83 + b, 2, n) for b in range(B)])
+    ts = torch.stack([O.synth_audio(93 + b, 2, n) * (0.5 + 0.2 * b) for b in range(B)])
+    te = get_mir_feature_embeds(ts, model, SR)
+    assert set(te) == {"lufs", "rms", "crest", "barkspectrum", "spectral_centroid"}
+    ev = PopulationEvaluator(xs, SR, E.make_plugins("eq-comp"), model, te, embed_func=get_mir_feature_embeds)
+    W = np.random.default_rng(5).random((B * P, 22))
+    loss, emb, audio = ev.evaluate(W, want_audio=True)
+    assert audio.abs().amax(dim=(1, 2)).eq(1.0).all()           # embed_func saw the peak-normalised population
+    ref = torch.stack([-torch.cosine_similarity(emb[k].cpu(), te[k].cpu().repeat_interleave(P, 0), dim=-1) for k in te]).mean(0)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)
+    for b in range(B):   # pair b alone == pair b inside the batch
+        ev1 = PopulationEvaluator(xs[b:b + 1], SR, E.make_plugins("eq-comp"), model, {k: v[b:b + 1] for k, v in te.items()},
+                                  embed_func=get_mir_feature_embeds)
+        assert torch.equal(ev1.evaluate(W[b * P:(b + 1) * P])[0], loss[b * P:(b + 1) * P])
+    torch.manual_seed(0)
+    ld, ed, _ = ev.evaluate(W, dropout=0.5)
+    assert not torch.equal(ld, loss) and torch.equal(ed["barkspectrum"], emb["barkspectrum"])
+    bad = dict(te); bad.pop("crest")
+    with pytest.raises(KeyError):
+        PopulationEvaluator(xs, SR, E.make_plugins("eq-comp"), model, bad, embed_func=get_mir_feature_embeds).evaluate(W)

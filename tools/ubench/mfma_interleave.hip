@@ -1,0 +1,105 @@
+// Micro-benchmark: how many VALU / LDS instructions of its OWN stream can a wave issue between two
+// back-to-back v_mfma_f32_32x32x2_f32 (64 cycles of matrix pipe each) without slowing the MFMAs down,
+// with one or two such waves per SIMD?  (mfma_coissue.hip showed that a wave streaming MFMAs starves
+// every OTHER wave of its SIMD; the question here is what the wave itself may interleave.)
+//   hipcc --offload-arch=gfx950 -O3 mfma_interleave.hip -o mfma_interleave
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// TYPE 0: v_fma_f32   1: v_pk_fma_f32   2: ds_read_b128   3: ds_write_b128   4: v_add_f32 (different regs)
+// 5: mix: per 4 slots = 1 ds_read_b128 + 2 v_add_f32 + 1 ds_write_b128
+template <int TYPE>
+__device__ __forceinline__ void one(int i, f32x4 &a, f32x4 &b, f32x2 &p, f32x2 &q, unsigned addr) {
+    if (TYPE == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a.x) : "v"(b.x), "v"(b.y));
+    if (TYPE == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(q));
+    if (TYPE == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(addr) : "memory");
+    if (TYPE == 3) asm volatile("ds_write_b128 %1, %0" :: "v"(a), "v"(addr) : "memory");
+    if (TYPE == 4) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a.y) : "v"(b.z));
+    if (TYPE == 5) {
+        if ((i & 3) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(addr) : "memory");
+        if ((i & 3) == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a.y) : "v"(a.z));
+        if ((i & 3) == 2) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a.w) : "v"(a.z));
+        if ((i & 3) == 3) asm volatile("ds_write_b128 %1, %0 offset:8192" :: "v"(a), "v"(addr) : "memory");
+    }
+}
+
+template <int K, int TYPE, int MW>
+__global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 16384; i += 256 * MW) lds[i] = (float)i;
+    __syncthreads();
+    f32x16 acc[8];
+    for (int j = 0; j < 8; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float av = 1.0f + lane * 1e-3f, bv = 0.5f;
+    f32x4 a = {1.f, 2.f, 3.f, 4.f}, b = {1e-3f, 1.f, 1e-3f, 1.f};
+    f32x2 p = {1.f, 2.f}, q = {1e-3f, 1.f};
+    const unsigned addr = wv * 1024 + lane * 16;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < nm / 8; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(av), "v"(bv));
+#pragma unroll
+            for (int i = 0; i < K; ++i) one<TYPE>(j * K + i, a, b, p, q, addr);
+        }
+        if (TYPE == 2 || TYPE == 3 || TYPE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + p.x + p.y;
+    for (int j = 0; j < 8; ++j)
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * 512 + tid] = s;
+    if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; }
+}
+
+template <int K, int TYPE, int MW>
+static void run(int nm, float *out, long long *res_d) {
+    hipFuncSetAttribute((const void *)k<K, TYPE, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    long long res[16];
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((k<K, TYPE, MW>), dim3(256), dim3(256 * MW), 64 * 1024, 0, nm, out, res_d);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+    long long lo = res[0], hi = res[1];
+    for (int w = 0; w < 4 * MW; ++w) { lo = res[2 * w] < lo ? res[2 * w] : lo; hi = res[2 * w + 1] > hi ? res[2 * w + 1] : hi; }
+    static const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "ds_read_b128", "ds_write_b128", "v_add_f32", "mix rd/add/sub/wr"};
+    printf("%-18s K=%2d waves/SIMD=%d : %7.1f cyc per MFMA slot (64 = pipe-bound)\n", names[TYPE], K, MW, (double)(hi - lo) / ((double)nm * MW));
+}
+
+template <int TYPE, int MW>
+static void sweep(int nm, float *out, long long *res_d) {
+    run<0, TYPE, MW>(nm, out, res_d);
+    run<2, TYPE, MW>(nm, out, res_d);
+    run<4, TYPE, MW>(nm, out, res_d);
+    run<6, TYPE, MW>(nm, out, res_d);
+    run<8, TYPE, MW>(nm, out, res_d);
+    run<12, TYPE, MW>(nm, out, res_d);
+    run<16, TYPE, MW>(nm, out, res_d);
+}
+
+int main() {
+    float *out;
+    long long *res_d;
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&res_d, 16 * 8);
+    const int nm = 2048;
+    sweep<0, 1>(nm, out, res_d);
+    sweep<0, 2>(nm, out, res_d);
+    sweep<1, 1>(nm, out, res_d);
+    sweep<1, 2>(nm, out, res_d);
+    sweep<2, 1>(nm, out, res_d);
+    sweep<2, 2>(nm, out, res_d);
+    sweep<3, 1>(nm, out, res_d);
+    sweep<3, 2>(nm, out, res_d);
+    sweep<5, 1>(nm, out, res_d);
+    sweep<5, 2>(nm, out, res_d);
+    return 0;
+}
