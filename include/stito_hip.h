@@ -117,6 +117,16 @@ int stito_peak(const float *audio_dev, int pop, int channels, int64_t n_samples,
 int stito_normalize_audio(float *audio_dev, int pop, int channels, int64_t n_samples,
                           const float *peaks_dev, void *stream);
 
+/* ---- resampling in front of the path -------------------------------------------------------- */
+/* torchaudio.functional.resample(x, orig_freq, new_freq) with the library defaults (sinc_interp_hann,
+ * lowpass_filter_width 6, rolloff 0.99) -- st_ito/utils.py:462-463, scripts/run_optim.py:446, 526.
+ * orig / newf are the two rates divided by their gcd; width = ceil(6 * orig / (min(orig, newf) * 0.99));
+ * kernel_t_dev (2 * width + orig, newf) float32: the library's kernel table transposed (host-built);
+ * x_dev (rows, n_in) -> out_dev (rows, n_out), n_out = stito_resample_num_samples = ceil(newf * n_in / orig). */
+int64_t stito_resample_num_samples(int64_t n_in, int orig, int newf);
+int stito_resample_sinc(const float *x_dev, int rows, int64_t n_in, const float *kernel_t_dev, int orig, int newf,
+                        int width, float *out_dev, int64_t n_out, void *stream);
+
 /* ---- front end --------------------------------------------------------------------------- */
 enum { STITO_NORM_NONE = 0, STITO_NORM_MINMAX = 1, STITO_NORM_BATCHNORM = 2 };
 

@@ -4,7 +4,8 @@
     python scripts/run_optim.py input.wav target.wav --algorithm es --effect-type basic --metric param
 
 Same flags as the reference; the ones whose code paths are outside this build raise a clear
-error (--effect-type vst, --algorithm autodiff, --metric clap, --staged).  Extensions:
+error (--effect-type vst, --algorithm autodiff, --metric clap); --staged runs the fixed run_staged_es
+(st_ito.style_transfer).  Extensions:
 --target (README.md:18 spelling), --seed, --chain, --ckpt, --synthetic, --no-early-stop,
 --no-find-w0.  Multi-GPU: launch with torch.distributed.run, one rank per GPU; the population
 is sharded and fitness all-gathered (RCCL).
@@ -21,7 +22,7 @@ import torch  # noqa: E402
 
 from st_ito import effects  # noqa: E402
 from st_ito.audio_io import load_wav, resample, save_wav  # noqa: E402
-from st_ito.style_transfer import process_audio, run_es  # noqa: E402
+from st_ito.style_transfer import process_audio, run_es, run_staged_es  # noqa: E402
 from st_ito.utils import get_param_embeds, load_param_model, make_synthetic_param_model  # noqa: E402
 
 
@@ -59,8 +60,6 @@ def main(argv=None):
     sample_rate = 48000
     if args.algorithm != "es":
         raise NotImplementedError("--algorithm autodiff (run_optim.py:237-297) is outside this build: ES path only")
-    if args.staged:
-        raise NotImplementedError("--staged (run_staged_es) is outside this build")
     if args.metric != "param":
         raise NotImplementedError("--metric clap needs laion_clap + downloaded weights; only the AFx-Rep metric is built")
     if args.effect_type == "vst" and args.chain is None:
@@ -121,7 +120,8 @@ def main(argv=None):
 
     sigma0 = 0.33
     print(f"Running ES with sigma0 = {sigma0}")
-    result = run_es(
+    es_func = run_staged_es if args.staged else run_es  # run_optim.py:582
+    result = es_func(
         input_audio.unsqueeze(0), target_audio.unsqueeze(0), sample_rate, plugins, model, embed_func,
         max_iters=args.max_iters, popsize=args.popsize, w0=w0, find_w0=not args.no_find_w0, sigma0=sigma0,
         distance="cosine", parallel=args.parallel, dropout=args.dropout, savepop=args.savepop,

@@ -92,6 +92,8 @@ SIGNATURES = {
     "stito_spectral_centroid": (c_int, [c_void_p, c_int, c_int, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
     "stito_embed_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "stito_resample_num_samples": (c_int64, [c_int64, c_int, c_int]),
+    "stito_resample_sinc": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "stito_neg_cosine": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_int, c_void_p, c_void_p]),
 }
 

@@ -1,6 +1,7 @@
 """Inference-time optimisation (ES) of the reference, st_ito/style_transfer.py: `load_plugins`
 (17-42), `process_audio` (45-115), `parameters_to_dict` (324-359), `savepop_to_disk` (362-396)
-and `run_es` (399-692), with the evaluate-population step on the MI355X.
+and `run_es` (399-692), with the evaluate-population step on the MI355X; `run_staged_es` is the fixed variant
+of scripts/run_optim.py:39-234 on the same evaluate step.
 
 Only the ES path is built; the baselines of the reference file (run_input, run_random,
 run_rule_based, run_deepafx_st) are outside this build's scope.  `run_es_batch` is an extension
@@ -294,6 +295,113 @@ def run_es(
         "wopt": wopt,
         "fval_history": fval_history,
         "wopt_history": wopt_history,
+        "num_evals": n_evals,
+    }
+
+
+def run_staged_es(
+    input_audio: torch.Tensor,
+    target_audio: torch.Tensor,
+    sample_rate: int,
+    plugins: List[dict],
+    model: torch.nn.Module,
+    embed_func: callable,
+    normalization: str = "peak",
+    max_iters: int = 100,
+    w0: torch.Tensor = None,
+    popsize: int = 10,
+    sigma0: float = 0.1,
+    distance: str = "cosine",
+    parallel: bool = False,
+    save_pop: bool = False,
+    savepop: bool = False,
+    run_dir: str = ".",
+    seed: int = None,
+    *args,
+    **kwargs,
+):
+    """Stage-wise CMA-ES (reference scripts/run_optim.py:39-234, `--staged`): stage k optimises ONLY the
+    parameters of plugin k on the sub-chain plugins[0..k], with the earlier plugins held at their stage optima;
+    every stage starts from 0.5 in its own dimensions and gets max_iters // len(plugins) iterations (147-188).
+
+    The reference variant cannot run as written (it calls an undefined `parameters_to_dict`, writes to a global
+    `run_dir`, takes the cosine of the embedding *dict*, adds a fourth dimension to the target, and returns a
+    tuple where its caller reads a dict).  This is the fixed variant on the GPU evaluate step: the stage's
+    candidates are the reference's composed vectors `[wopt_overall, w]` (161-166), rendered and scored by
+    PopulationEvaluator like run_es does (same length policy, same loss: mean over the embed_func dict of
+    -cosine), input and target peak-normalised in place like run_es (452-453), population sharded over the
+    ranks like run_es.  Returns run_es's dict; fval_history / wopt_history hold the stage-local best after
+    every tell (181-185), `stage_wopts` the per-stage optima.  Stage k's CMA-ES is seeded with seed + k."""
+    if distance != "cosine":
+        raise ValueError(f"Unknown distance: {distance}")
+    savepop = bool(savepop or save_pop)
+    dist, rank, world = _dist_info()
+    if world > 1 and seed is None:
+        box = [int(np.random.SeedSequence().generate_state(1)[0] & 0x7FFFFFFF) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
+    input_audio /= torch.max(torch.abs(input_audio)).clamp(min=1e-8)
+    target_audio /= torch.max(torch.abs(target_audio)).clamp(min=1e-8)
+    target_embed = embed_func(target_audio, model, sample_rate)
+
+    names = list(plugins.keys())
+    iters_per_stage = max_iters // len(plugins)
+    wopt_overall, fopt = None, float("inf")
+    fval_history, wopt_history, stage_wopts = [], [], []
+    n_evals = 0
+    output_audio = None
+    for stage_idx in range(len(plugins)):
+        stage_plugins = {k: plugins[k] for k in names[: stage_idx + 1]}
+        print(f"Optimizing stage {stage_idx} ({list(stage_plugins.keys())})")
+        total_num_params = sum(p["num_params"] for p in stage_plugins.values())
+        n_stage = plugins[names[stage_idx]]["num_params"]
+        evaluator = engine.PopulationEvaluator(input_audio, sample_rate, stage_plugins, model, target_embed, embed_func=embed_func)
+        if evaluator.ndims != total_num_params:
+            raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
+        opts = {"bounds": [0, 1], "popsize": popsize}
+        if seed is not None:
+            opts["seed"] = seed + stage_idx
+        es = cma.CMAEvolutionStrategy(np.ones(n_stage) * 0.5, sigma0, opts)
+        for iteration in range(iters_per_stage):
+            W = es.ask()
+            if stage_idx > 0:
+                W_stage = [np.concatenate([wopt_overall, w]) for w in W]
+            else:
+                W_stage = W
+            fvals, _, output_audios = sharded_evaluate(W_stage, lambda Ws: evaluator.evaluate(Ws, want_audio=savepop))
+            n_evals += len(W)
+            es.tell(W, fvals)
+            if rank == 0:
+                es.disp()
+            if savepop:  # 171-179: one file per candidate, overwritten every iteration of the stage
+                from .audio_io import save_wav
+
+                lo = shard_bounds(len(fvals), rank, world)[0]
+                for j, audio in enumerate(output_audios):
+                    audio = audio / torch.max(torch.abs(audio)).clamp(min=1e-8)
+                    save_wav(os.path.join(run_dir, f"output_audio_stage_{stage_idx}_pop_{lo + j}_fval_{fvals[lo + j]:0.3f}.wav"),
+                             audio.cpu(), sample_rate)
+            fval_history.append(es.result[1])
+            wopt_history.append(es.result[0])
+        wopt, fopt = es.result[0], es.result[1]
+        if wopt is None:  # max_iters < len(plugins): no iteration ran
+            wopt = np.ones(n_stage) * 0.5
+        stage_wopts.append(wopt)
+        wopt_overall = wopt if wopt_overall is None else np.concatenate([wopt_overall, wopt])
+        output_audio = torch.from_numpy(process_audio(input_audio.squeeze(0).cpu().numpy(), wopt_overall, sample_rate, stage_plugins))
+        if rank == 0 and run_dir is not None and os.path.isdir(run_dir):
+            from .audio_io import save_wav
+
+            save_wav(os.path.join(run_dir, f"output_audio_stage_{stage_idx}.wav"), output_audio, sample_rate)
+    param_dict = parameters_to_dict(wopt_overall, plugins)
+    return {
+        "output_audio": output_audio,
+        "params": param_dict,
+        "fopt": fopt,
+        "wopt": wopt_overall,
+        "fval_history": fval_history,
+        "wopt_history": wopt_history,
+        "stage_wopts": stage_wopts,
         "num_evals": n_evals,
     }
 

@@ -39,8 +39,6 @@ def get_param_embeds(
         raise ValueError("expected (bs, chs, seq_len)")
     if requires_grad:
         raise NotImplementedError("get_param_embeds(requires_grad=True) (the autodiff path) is not built here")
-    if sample_rate != 48000:
-        raise NotImplementedError("resampling to 48 kHz (torchaudio) is not part of this build; pass 48 kHz audio")
     _hip.require_gpu()
     from .models.panns import Cnn14
 
@@ -49,6 +47,10 @@ def get_param_embeds(
     x_device = x
     dev = next(model.parameters()).device
     xin = x.detach().to(dev, torch.float32).contiguous()
+    if sample_rate != 48000:  # utils.py:462-463
+        from .audio_io import resample
+
+        xin = resample(xin, int(sample_rate), 48000).contiguous()
     bs, chs, n = xin.shape
     L = _hip.lib()
     st = _hip.stream_ptr()
@@ -251,8 +253,10 @@ def load_mfcc_feature_extractor(use_gpu: bool = False):
 def get_mfcc_feature_embeds(x: torch.Tensor, model, sample_rate: float, midside: bool = False, **kwargs):
     """reference utils.py:116-159: mono (channel mean) or mid/side (L+R, L-R) MFCC statistics, {"mono": (bs, E)}."""
     bs, chs, seq_len = x.shape
-    if sample_rate != 48000:
-        raise NotImplementedError("resampling to 48 kHz (torchaudio) is not part of this build; pass 48 kHz audio")
+    if sample_rate != 48000:  # utils.py:130-131
+        from .audio_io import resample
+
+        x = resample(x, int(sample_rate), 48000)
     if chs == 2 and midside:
         x = torch.stack([x[:, 0, :] + x[:, 1, :], x[:, 0, :] - x[:, 1, :]], dim=1)
     else:

@@ -42,8 +42,6 @@ def test_error_paths(dev, pm):
         pm(torch.zeros(1, 3, 70000))
     with pytest.raises(ValueError):                      # too short for five 2x2 poolings (torch raises in avg_pool2d)
         get_param_embeds(O.synth_audio(2, 2, 8000)[None], pm, SR)
-    with pytest.raises(NotImplementedError):             # resampling is outside this build
-        get_param_embeds(O.synth_audio(2, 2, 70000)[None], pm, 44100)
     lib = _hip.lib()
     assert lib.stito_conv3x3_supported(4, 16, 16, 12, 64, 0, 0) == 0   # cin not a multiple of the K chunk
     rc = lib.stito_conv3x3_bn_relu(None, None, None, None, None, 4, 16, 16, 12, 64, 0, 0, None)
@@ -132,3 +130,31 @@ def test_config3_length_30s(dev, pm):
     f_ref, _, _ = O.evaluate([W[0]], x, SR, O.make_plugins(kinds), te_ref, om)
     assert abs(loss[0].item() - f_ref[0]) < 1e-4 * max(1.0, abs(f_ref[0]))
     assert np.isfinite(loss.cpu().numpy()).all()
+
+
+def test_resample_front_door_vs_oracle(dev, pm):
+    """utils.py:462-463: get_param_embeds resamples to 48 kHz when handed another rate (the README path with 44.1 kHz
+    files).  stito_resample_sinc against the oracle's restatement of torchaudio.functional.resample (library defaults)
+    on 44.1k -> 48k, 48k -> 44.1k, 96k -> 48k and an awkward ratio; then the embeddings of 44.1 kHz audio against the
+    oracle's get_param_embeds at the same rate."""
+    from st_ito.audio_io import resample
+    from st_ito.utils import get_param_embeds
+    g = torch.Generator().manual_seed(0)
+    for o, n_, length in ((44100, 48000, 44100), (48000, 44100, 50001), (96000, 48000, 30000), (22050, 48000, 7777), (44100, 48000, 1)):
+        x = torch.randn(2, 2, length, generator=g)
+        got = resample(x, o, n_)
+        ref = O.resample_sinc(x, o, n_)
+        assert got.shape == ref.shape and got.device == x.device
+        assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item()), (o, n_)
+    assert resample(x, 48000, 48000) is x
+    gpu_in = resample(x.to(dev), 44100, 48000)
+    assert gpu_in.is_cuda                                  # stays on the caller's device
+    om = O.make_synthetic_model(0)
+    pm2 = type(pm)(512, SR, 2048, 1024, 128, 20, 20000, True, "minmax")
+    pm2.load_state_dict(om.state_dict())
+    pm2.eval().to(dev)
+    a = O.synth_audio(3, 2, 88200)[None]
+    e = get_param_embeds(a.clone(), pm2, 44100)
+    e_ref = O.get_param_embeds(a.clone(), om, 44100)
+    for k in ("mid", "side"):
+        assert (e[k] - e_ref[k]).abs().max() / e_ref[k].abs().max() < 1e-4

@@ -315,3 +315,97 @@ def test_generic_metric_path_mir_features_and_dropout(dev):
     bad = dict(te); bad.pop("crest")
     with pytest.raises(KeyError):
         PopulationEvaluator(xs, SR, E.make_plugins("eq-comp"), model, bad, embed_func=get_mir_feature_embeds).evaluate(W)
+
+
+def test_run_staged_es_equals_hand_driven_stages(dev, tmp_path):
+    """run_staged_es on EQ -> compressor (2 stages): stage 0 is bitwise run_es on the EQ-only chain (same seed,
+    w0 = 0.5, no find_w0, no early stop); stage 1 is bitwise a hand-driven CMA-ES over the compressor's 4 dims on
+    the 2-plugin chain with the EQ slots held at stage 0's optimum.  Then the CLI's --staged flag end to end."""
+    from st_ito import effects as E, cmaes
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.style_transfer import run_es, run_staged_es
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    n, P, iters, seed = 70000, 6, 6, 21
+    x = O.synth_audio(71, 2, n)[None]
+    tgt = O.synth_audio(72, 2, n)[None] * 0.4
+    res = run_staged_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq-comp"), pm, get_param_embeds, max_iters=iters, popsize=P,
+                        sigma0=0.33, seed=seed, run_dir=str(tmp_path))
+    assert res["wopt"].shape == (22,) and len(res["fval_history"]) == iters and res["num_evals"] == iters * P
+    assert (tmp_path / "output_audio_stage_0.wav").exists() and (tmp_path / "output_audio_stage_1.wav").exists()
+    assert list(res["params"]) == ["ParametricEQ", "Compressor"]
+    # stage 0 by hand: run_es on the EQ alone
+    r0 = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, max_iters=iters // 2, popsize=P,
+                find_w0=False, sigma0=0.33, seed=seed, early_stop=False)
+    np.testing.assert_array_equal(res["stage_wopts"][0], r0["wopt"])
+    assert res["fval_history"][iters // 2 - 1] == r0["fopt"]
+    # stage 1 by hand
+    xn, tn = x.clone(), tgt.clone()
+    xn /= xn.abs().max(); tn /= tn.abs().max()
+    ev = PopulationEvaluator(xn, SR, E.make_plugins("eq-comp"), pm, get_param_embeds(tn, pm, SR))
+    es = cmaes.CMAEvolutionStrategy(np.ones(4) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P, "seed": seed + 1})
+    for _ in range(iters // 2):
+        W = es.ask()
+        es.tell(W, ev.evaluate([np.concatenate([r0["wopt"], w]) for w in W])[0].tolist())
+    np.testing.assert_array_equal(res["stage_wopts"][1], es.result[0])
+    assert res["fopt"] == es.result[1]
+    np.testing.assert_array_equal(res["wopt"], np.concatenate([r0["wopt"], es.result[0]]))
+    # CLI
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import run_optim
+    from st_ito.audio_io import save_wav
+    save_wav(str(tmp_path / "in.wav"), O.synth_audio(11, 2, 60000), SR)
+    save_wav(str(tmp_path / "tgt.wav"), O.synth_audio(12, 2, 60000), SR)
+    out = run_optim.main([str(tmp_path / "in.wav"), str(tmp_path / "tgt.wav"), "--effect-type", "basic", "--chain", "eq-comp",
+                          "--staged", "--max-iters", "4", "--popsize", "4", "--synthetic", "--seed", "3",
+                          "--output-dir", str(tmp_path / "out")])
+    assert out["num_evals"] == 4 * 4 and (tmp_path / "out" / "in_to_tgt_es" / "parameters_sigma=0.33.json").exists()
+
+
+_RANK_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r} + "/st-ito_amd"); sys.path.insert(0, {root!r} + "/oracle")
+import numpy as np, torch, torch.distributed as dist
+import st_ito_oracle as O
+from st_ito import effects as E
+from st_ito.style_transfer import run_es
+from st_ito.utils import get_param_embeds, make_synthetic_param_model
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+torch.cuda.set_device(0)                      # both ranks share the one GPU of the box: gloo, not RCCL
+if world > 1:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+pm = make_synthetic_param_model(0)
+x = O.synth_audio(61, 2, 70000)[None]; tgt = O.synth_audio(62, 2, 70000)[None] * 0.5
+res = {{}}
+for tag, seed in (("seeded", 13), ("unseeded", None)):
+    r = run_es(x.clone(), tgt.clone(), 48000, E.make_plugins("eq-comp"), pm, get_param_embeds, max_iters=3, popsize=16,
+               find_w0=True, sigma0=0.33, seed=seed, early_stop=False, savepop=(tag == "seeded"), run_dir=out)
+    res[tag] = np.concatenate([r["wopt"], [r["fopt"]], r["output_audio"].numpy().ravel()[:64]])
+np.savez(out + f"/r{{world}}_{{rank}}.npz", **res)
+if world > 1:
+    dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_select_the_single_rank_wopt(dev, tmp_path):
+    """SURVEY 8(e) determinism across G, on the real evaluator: 2 ranks (gloo; both on this box's one GPU) shard a
+    population of 16, all-gather the fitness and must end with the bit-identical wopt / fopt / output audio of the
+    1-rank run; with seed=None (rank 0's seed is broadcast) the two ranks still agree with each other; --savepop
+    under 2 ranks writes each candidate once."""
+    import subprocess
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER.format(root=ROOT))
+    port = str(35500 + os.getpid() % 2000)
+    (tmp_path / "w2").mkdir(); (tmp_path / "w1").mkdir()
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(tmp_path / "w2")]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    assert subprocess.call([sys.executable, str(script), "0", "1", port, str(tmp_path / "w1")]) == 0
+    a0, a1, s = (np.load(tmp_path / "w2" / "r2_0.npz"), np.load(tmp_path / "w2" / "r2_1.npz"), np.load(tmp_path / "w1" / "r1_0.npz"))
+    np.testing.assert_array_equal(a0["seeded"], a1["seeded"])
+    np.testing.assert_array_equal(a0["seeded"], s["seeded"])
+    np.testing.assert_array_equal(a0["unseeded"], a1["unseeded"])
+    for it in ("-1", "0", "2"):
+        n2 = sorted(os.listdir(tmp_path / "w2" / f"pop_{it}")); n1 = sorted(os.listdir(tmp_path / "w1" / f"pop_{it}"))
+        assert n2 == n1 and len(n1) == 16

@@ -499,8 +499,9 @@ def test_mfcc_feature_embeds_vs_oracle(dev):
         assert got.shape == ref.shape == (2, 150 if midside else 75) and got.device == x.device
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
         np.testing.assert_allclose(np.linalg.norm(got.numpy(), axis=1), 1.0, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        get_mfcc_feature_embeds(x, model, 44100)
+    got = get_mfcc_feature_embeds(x, model, 44100)["mono"]       # utils.py:130-131: resampled to 48 kHz first
+    ref = O.mfcc_feature_embeds(O.resample_sinc(x, 44100, 48000), SR)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize("kinds,chs", [(["ParametricEQ", "Gain", "Reverb"], 2), (["ParametricEQ", "Gain"], 1),
