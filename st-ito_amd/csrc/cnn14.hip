@@ -22,6 +22,7 @@
 // happen in registers.  Details of the data movement are at k_conv3x3.
 #include "common.h"
 
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -681,6 +682,369 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_conv_wino8: the same Winograd F(2x2,3x3) tile (64 tiles x 64 output channels x 16 positions, 8-channel
+// chunks, same LDS layouts and epilogue as k_conv_wino) with EIGHT SYMMETRIC WAVES and no producer role.
+//
+// Why (tools/ubench/mfma_coissue.hip, mfma_interleave.hip, measured on MI355X):
+//   * a wave that streams independent v_mfma_f32_32x32x2_f32 starves every OTHER wave of its SIMD almost
+//     completely -- VALU, LDS, SALU alike, whatever their age or s_setprio -- until it blocks on a counter or a
+//     barrier (a filler wave got 3 instruction groups in 263 000 cycles).  k_conv_wino's producer waves therefore
+//     only ran once the consumers sat at the chunk barrier: every chunk paid the MFMA phase PLUS a serial
+//     transform tail (mfma_issued_frac 0.66).
+//   * instructions of the wave's OWN stream do issue between its MFMAs: a ds_read_b128 costs ~1.5 cycles of
+//     MFMA time, a VALU instruction 4-6 (the f32 matrix pipe is the f32 VALU pipe: VALU time is additive, it
+//     cannot be hidden, only kept small), a ds_write_b128 ~13 cycles of the CU's LDS write path.
+// So every wave does an eighth of everything, interleaved by hand into its MFMA stream:
+//   MFMA   row xi = w / 2 of the Winograd domain x 64 tiles x half (w % 2) of the channels: 32 MFMAs per chunk,
+//          operands of group nu+1 read (3 ds_read_b128) while group nu runs;
+//   U      4 of the 32 scalar-addressed LDS-DMA copies of the next chunk's weight slab;
+//   patch  2 float4 of the halo patch, HBM -> registers two periods ahead -> LDS (no VALU: scalar base + lane offset);
+//   V      one transform item (tile, channel quad, row of B^T d B): 8 ds_read_b128, 16 packed VALU, 4 ds_write_b128.
+// The loop is rotated so that ONE barrier per chunk is enough and nothing waits behind it: barrier(k) sits after
+// the operand reads of (chunk k, nu = 3); the period that follows runs those 8 MFMAs from registers while the
+// first reads of chunk k+1 are in flight, then (k+1, nu = 0..2).  V(k+1) / U(k+1) are produced during period k
+// into the buffer whose last reader passed barrier(k-1).
+// ------------------------------------------------------------------------------------------------
+static constexpr int WINO8_THREADS = 512;
+
+// Packed f32 arithmetic, issued explicitly: in this kernel hipcc splits native-vector f32x4 expressions into scalar
+// v_fma / v_sub (twice the VALU instructions, and every VALU instruction is taken out of the MFMA stream's time).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {  // a + (-b): exact, bit-identical to v_sub_f32
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// LDS-DMA as glds16_s, without saving M0: nothing else in k_conv_wino8 reads M0 (gfx950 LDS instructions do not, and the
+// kernel has no movrel / sendmsg / interp); hipcc rejects "m0" in a clobber list as reserved, so this is by inspection
+// of the ISA (grep m0: only these statements write it)
+__device__ __forceinline__ void glds16_m0(const float *sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+template <int TTW, bool POOL, bool TRACE = false>
+__global__ __launch_bounds__(WINO8_THREADS) void k_conv_wino8(const float *__restrict__ in, const float *__restrict__ upk,
+                                                               const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, float *__restrict__ out,
+                                                               WinoGeom g) {
+    constexpr int TTH = 64 / TTW;
+    constexpr int U_FLOATS = 16 * 64 * WK;  // [pos][cout][8]
+    constexpr int V_FLOATS = 16 * 64 * WK;  // [pos][(tile + pos/4) % 64][8]
+    constexpr int BUF = U_FLOATS + V_FLOATS;
+    constexpr int PWC = 2 * TTW + 2;        // patch columns
+    constexpr int NPL = 2;                  // float4 of patch per thread per chunk: 2 PR PWC <= 1024 (geometry check)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = g.Cout / 64;
+    const int m_blk = blockIdx.x / n_tiles;  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    const int n0 = (blockIdx.x % n_tiles) * 64;
+    const int cb = m_blk % g.n_col_blocks;
+    const int rb = m_blk / g.n_col_blocks;
+    const int vtr0 = rb * TTH;
+    const int tc0 = cb * TTW;
+    const int n_chunks = g.Cin / WK;
+    const int pfl = g.pa_i * 256 + 512;  // floats per patch buffer: pixels + a row of zeros + a trash row
+    float *patch0 = smem + 2 * BUF;
+    const int iv_lo = (vtr0 / g.TR) * g.H + 2 * (vtr0 % g.TR) - 1;  // input virtual row (s*H + h) of patch row 0
+
+    // ---- MFMA role: row xi of the Winograd domain, channel half nh -------------------------------------
+    const int half = lane >> 5, l31 = lane & 31;
+    const int xi = wv >> 1, nh = wv & 1;
+    // operand offsets of nu = 0 inside a U/V buffer (floats); nu adds 64 * WK
+    const int a_off0 = U_FLOATS + (4 * xi) * 64 * WK + ((l31 + xi) & 63) * WK + half * 4;
+    const int a_off1 = U_FLOATS + (4 * xi) * 64 * WK + ((32 + l31 + xi) & 63) * WK + half * 4;
+    const int b_off = (4 * xi) * 64 * WK + (nh * 32 + l31) * WK + half * 4;
+
+    // ---- transform item: thread = (tile, channel quad, row t_xi of B^T d B) --------------------------------
+    const int t_xi = tid & 3, t_quad = (tid >> 2) & 1, t_tile = tid >> 3;
+    int rowA, rowB, vdst;
+    float sgn;
+    {
+        const int ra = t_xi == 0 ? 0 : (t_xi == 2 ? 2 : 1), rbb = t_xi == 3 ? 3 : (t_xi == 2 ? 1 : 2);
+        sgn = t_xi == 1 ? 1.0f : -1.0f;  // T[t_xi] = d[ra] + sgn * d[rbb]
+        const int vtr = vtr0 + t_tile / TTW, tcl = t_tile % TTW;
+        const int s_ = vtr / g.TR, tr = vtr % g.TR;
+        const int pc0 = s_ * g.H + 2 * tr - 1 - iv_lo;  // patch row of this tile's first input row
+        const int ha = 2 * tr - 1 + ra, hb = 2 * tr - 1 + rbb;
+        const int zoff = g.pa_i * 256;                   // the row of zeros: rows outside the stream / map
+        rowA = ((vtr < g.VTR && ha >= 0 && ha < g.H) ? ((pc0 + ra) * PWC + 2 * tcl) * 8 : zoff) + t_quad * 4;
+        rowB = ((vtr < g.VTR && hb >= 0 && hb < g.H) ? ((pc0 + rbb) * PWC + 2 * tcl) * 8 : zoff) + t_quad * 4;
+        // V plane p = 4 t_xi + nu keeps tile t at slot (t + t_xi) % 64 (bank spread of the four writers of a tile)
+        vdst = U_FLOATS + (t_xi * 4) * 64 * WK + ((t_tile + t_xi) & 63) * WK + t_quad * 4;
+    }
+
+    // ---- U slab copies: 32 wave-instructions per chunk (position ii / 2, half ii % 2 of its 2 KB), 4 per wave ----
+    const float *u_base = upk + (int64_t)n0 * WK;
+    const int64_t u_pos_stride = (int64_t)g.Cout * WK, u_chunk_stride = 16 * u_pos_stride;  // floats
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+
+    // ---- halo patch staging: float4 q = tid + 512 j of the patch ((pixel, half) linear), scalar base + lane offset ----
+    const int s_first = (iv_lo < 0 ? 0 : iv_lo) / g.H;  // first stream the patch touches (wave-uniform)
+    const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W);
+    const int64_t plane8 = (int64_t)g.H * g.W * 8;      // floats per 8-channel plane of one stream
+    unsigned p_off[NPL];                                // byte offset from p_base (+ chunk * plane8 floats)
+    int p_dst[NPL];                                     // float offset in a patch buffer; lanes without a pixel hit the trash row
+    {
+        const int npix2 = g.PR * PWC * 2;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int q = tid + WINO8_THREADS * j, pix = q >> 1;
+            const int pr = pix / PWC, pc = pix % PWC;
+            const int iv = iv_lo + pr;
+            const int w = 2 * tc0 - 1 + pc;
+            const bool ok = q < npix2 && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
+            const int s_ = ok ? iv / g.H : s_first, h_ = ok ? iv % g.H : 0, w_ = ok ? w : 0;
+            p_off[j] = (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8 + (q & 1) * 4) * 4);
+            p_dst[j] = ok ? q * 4 : g.pa_i * 256 + 256 + lane * 4;
+        }
+    }
+    f32x4 rpA[NPL], rpB[NPL];
+
+#define W8_COPY_U1(CH, BOFF, K_) /* copy K_ (0..3) of this wave's four */                               \
+    if ((CH) < n_chunks) {                                                                               \
+        const int ii = wv * 4 + (K_);                                                                    \
+        glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + (ii >> 1) * u_pos_stride + (ii & 1) * 256,   \
+                  (unsigned)lane * 16u, lds0 + (unsigned)((BOFF) + (ii >> 1) * 64 * WK + (ii & 1) * 256) * 4u); \
+    }
+#define W8_COPY_U(CH, BOFF) W8_COPY_U1(CH, BOFF, 0) W8_COPY_U1(CH, BOFF, 1) W8_COPY_U1(CH, BOFF, 2) W8_COPY_U1(CH, BOFF, 3)
+#define W8_LOAD_P(rp, CH)                                                                               \
+    {                                                                                                   \
+        const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                           \
+        const char *pb_ = (const char *)(p_base + (int64_t)cc_ * plane8);                                \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) rp[j] = *(const f32x4 *)(pb_ + p_off[j]);        \
+    }
+#define W8_WRITE_P(rp, PBUF)                                                                            \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) *(f32x4 *)((PBUF) + p_dst[j]) = rp[j];           \
+    }
+// transform, in three steps that the main loop places between MFMA groups: reads, row combination, column combination + stores
+#define LO2(v) __builtin_shufflevector(v, v, 0, 1)
+#define HI2(v) __builtin_shufflevector(v, v, 2, 3)
+#define CAT4(a, b) __builtin_shufflevector(a, b, 0, 1, 2, 3)
+#define W8_T_READ(PBUF, J0) /* columns J0, J0 + 1 of the two patch rows this item combines */           \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j = (J0); j < (J0) + 2; ++j) {                                        \
+            tA[j] = *(const f32x4 *)((PBUF) + rowA + j * 8);                                             \
+            tB[j & 1] = *(const f32x4 *)((PBUF) + rowB + j * 8);                                         \
+        }                                                                                                \
+    }
+#define W8_T_ROWS(J0) /* T = A + sgn B, as fma(B, sgn, A): exact */                                      \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j = (J0); j < (J0) + 2; ++j)                                          \
+            tA[j] = CAT4(pk_fma(LO2(tB[j & 1]), sg2, LO2(tA[j])), pk_fma(HI2(tB[j & 1]), sg2, HI2(tA[j]))); \
+    }
+#define W8_T_STORE1(VBOFF, P_, EXPR_LO, EXPR_HI)                                                        \
+    *(f32x4 *)(smem + (VBOFF) + vdst + (P_) * 64 * WK) = CAT4(EXPR_LO, EXPR_HI);
+#define W8_T_STORE_0(VBOFF) W8_T_STORE1(VBOFF, 0, pk_sub(LO2(tA[0]), LO2(tA[2])), pk_sub(HI2(tA[0]), HI2(tA[2])))
+#define W8_T_STORE_1(VBOFF) W8_T_STORE1(VBOFF, 1, pk_add(LO2(tA[1]), LO2(tA[2])), pk_add(HI2(tA[1]), HI2(tA[2])))
+#define W8_T_STORE_2(VBOFF) W8_T_STORE1(VBOFF, 2, pk_sub(LO2(tA[2]), LO2(tA[1])), pk_sub(HI2(tA[2]), HI2(tA[1])))
+#define W8_T_STORE_3(VBOFF) W8_T_STORE1(VBOFF, 3, pk_sub(LO2(tA[1]), LO2(tA[3])), pk_sub(HI2(tA[1]), HI2(tA[3])))
+#define W8_T_STORE(VBOFF) W8_T_STORE_0(VBOFF) W8_T_STORE_1(VBOFF) W8_T_STORE_2(VBOFF) W8_T_STORE_3(VBOFF)
+#define W8_LOAD_OPS(S, SB, NU)                                                                          \
+    {                                                                                                   \
+        S##a0 = *(const f32x4 *)((SB) + a_off0 + (NU) * 64 * WK);                                        \
+        S##a1 = *(const f32x4 *)((SB) + a_off1 + (NU) * 64 * WK);                                        \
+        S##b = *(const f32x4 *)((SB) + b_off + (NU) * 64 * WK);                                          \
+    }
+#define W8_MFMA1(S, NU, MB, KK)                                                                         \
+    acc[NU][MB] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a##MB[KK], S##b[KK], acc[NU][MB], 0, 0, 0);
+#define W8_MFMA2(S, NU, KK) W8_MFMA1(S, NU, 0, KK) W8_MFMA1(S, NU, 1, KK)
+#define W8_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define W8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.0f;
+    f32x4 tA[4], tB[2];
+    const f32x2 sg2 = {sgn, sgn};
+// TRACE instantiation (stito_debug_wino_trace): s_memtime stamps of the workgroups with blockIdx % 256 == 100, lane 0 of
+// waves 0 and 4: [wg / 256][wave / 4][slot]: 0 entry, 1 prologue done, 2 main loop done, 3 epilogue done, 4.. barrier(k) of
+// the first 12 periods (tools/wino_timeline.py)
+#define W8_STAMP(SLOT)                                                                                  \
+    if (TRACE && (blockIdx.x & 255) == 100 && (blockIdx.x >> 8) < 8 && lane == 0 && (wv & 3) == 0)      \
+        g.trace[((blockIdx.x >> 8) * 2 + (wv >> 2)) * 16 + (SLOT)] = (long long)__builtin_readcyclecounter();
+    W8_STAMP(0)
+    f32x4 xa0, xa1, xb, ya0, ya1, yb;  // two operand sets: one feeds the running MFMA group, the other is being read
+
+    // ---- prologue: patch(0), patch(1) in LDS, V(0) and U(0) in buffer 0 -------------------------------------
+    W8_COPY_U(0, 0)
+    W8_LOAD_P(rpA, 0)
+    W8_LOAD_P(rpB, 1)
+    for (int i = tid; i < 2 * pfl; i += WINO8_THREADS) patch0[i] = 0.0f;  // both patch buffers + zero / trash rows
+    W8_BARRIER()
+    W8_WRITE_P(rpA, patch0)        // (the compiler's wait for the loaded registers also covers the older U(0) copies)
+    W8_WRITE_P(rpB, patch0 + pfl)
+    W8_LOAD_P(rpA, 2)
+    W8_LOAD_P(rpB, 3)
+    W8_BARRIER()
+    W8_T_READ(patch0, 0)
+    W8_T_ROWS(0)
+    W8_T_READ(patch0, 2)
+    W8_T_ROWS(2)
+    W8_T_STORE(0)
+    W8_BARRIER()                   // B(-1): V(0), U(0) complete
+    W8_STAMP(1)
+
+// one period: k = chunk whose groups nu = 0..2 run here; FIRST: there is no (k-1, nu = 3) group in flight.
+// Operand sets alternate x, y, x, y over the four groups of a period, so no register is ever copied.  One piece of
+// non-MFMA work per MFMA gap (64 cycles of matrix pipe), the production of chunk k+1 in the first half of the period.
+#define W8_G(S, NU, MB, KK, WORK) W8_MFMA1(S, NU, MB, KK) WORK W8_FENCE()
+#define W8_PERIOD(rp, FIRST)                                                                            \
+    {                                                                                                   \
+        const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
+        const float *sb = smem + cur;                                                                    \
+        float *pb_w = patch0 + (k & 1) * pfl;           /* patch(k+2) goes where patch(k) was */         \
+        const float *pb_r = patch0 + ((k + 1) & 1) * pfl; /* patch(k+1) */                               \
+        const bool more = k + 1 < n_chunks;                                                              \
+        W8_LOAD_OPS(y, sb, 0)                                                                            \
+        W8_WRITE_P(rp, pb_w)                                                                             \
+        W8_FENCE()                                                                                       \
+        if (!(FIRST)) { W8_G(x, 3, 0, 0, W8_COPY_U1(k + 1, nxt, 0)) } else { W8_COPY_U1(k + 1, nxt, 0) } \
+        if (!(FIRST)) { W8_G(x, 3, 1, 0, W8_COPY_U1(k + 1, nxt, 1)) } else { W8_COPY_U1(k + 1, nxt, 1) } \
+        if (!(FIRST)) { W8_G(x, 3, 0, 1, W8_COPY_U1(k + 1, nxt, 2)) } else { W8_COPY_U1(k + 1, nxt, 2) } \
+        if (!(FIRST)) { W8_G(x, 3, 1, 1, W8_COPY_U1(k + 1, nxt, 3)) } else { W8_COPY_U1(k + 1, nxt, 3) } \
+        if (!(FIRST)) { W8_G(x, 3, 0, 2, W8_LOAD_P(rp, k + 4)) } else { W8_LOAD_P(rp, k + 4) }           \
+        if (!(FIRST)) { W8_G(x, 3, 1, 2, if (more) W8_T_READ(pb_r, 0)) } else { if (more) W8_T_READ(pb_r, 0) } \
+        if (!(FIRST)) { W8_G(x, 3, 0, 3, ) }                                                             \
+        if (!(FIRST)) { W8_G(x, 3, 1, 3, ) }                                                             \
+        W8_FENCE()                                                                                       \
+        W8_G(y, 0, 0, 0, W8_LOAD_OPS(x, sb, 1))                                                          \
+        W8_G(y, 0, 1, 0, if (more) W8_T_ROWS(0))                                                         \
+        W8_G(y, 0, 0, 1, if (more) W8_T_READ(pb_r, 2))                                                   \
+        W8_G(y, 0, 1, 1, )                                                                               \
+        W8_G(y, 0, 0, 2, )                                                                               \
+        W8_G(y, 0, 1, 2, if (more) W8_T_ROWS(2))                                                         \
+        W8_G(y, 0, 0, 3, if (more) W8_T_STORE_0(nxt))                                                    \
+        W8_G(y, 0, 1, 3, if (more) W8_T_STORE_1(nxt))                                                    \
+        W8_G(x, 1, 0, 0, W8_LOAD_OPS(y, sb, 2))                                                          \
+        W8_G(x, 1, 1, 0, if (more) W8_T_STORE_2(nxt))                                                    \
+        W8_G(x, 1, 0, 1, if (more) W8_T_STORE_3(nxt))                                                    \
+        W8_G(x, 1, 1, 1, )                                                                               \
+        W8_G(x, 1, 0, 2, )                                                                               \
+        W8_G(x, 1, 1, 2, )                                                                               \
+        W8_G(x, 1, 0, 3, )                                                                               \
+        W8_G(x, 1, 1, 3, )                                                                               \
+        W8_G(y, 2, 0, 0, W8_LOAD_OPS(x, sb, 3))                                                          \
+        W8_MFMA1(y, 2, 1, 0)                                                                             \
+        W8_MFMA2(y, 2, 1)                                                                                \
+        W8_MFMA2(y, 2, 2)                                                                                \
+        W8_MFMA2(y, 2, 3)                                                                                \
+        W8_FENCE()                                                                                       \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); /* U(k+1) landed; the NPL younger patch loads may fly on */ \
+        W8_BARRIER()                                     /* B(k) */                                      \
+        if (TRACE && k < 12) { W8_STAMP(4 + k) }                                                         \
+    }
+    static_assert(NPL == 2, "the vmcnt immediate of W8_PERIOD is written for 2 patch loads per set");
+
+    {
+        int k = 0;
+        W8_PERIOD(rpA, true)
+        for (k = 1; k + 1 < n_chunks; k += 2) {
+            W8_PERIOD(rpB, false)
+            ++k;
+            W8_PERIOD(rpA, false)
+            --k;
+        }
+        if (k < n_chunks) W8_PERIOD(rpB, false)
+    }
+    W8_MFMA2(x, 3, 0)
+    W8_MFMA2(x, 3, 1)
+    W8_MFMA2(x, 3, 2)
+    W8_MFMA2(x, 3, 3)
+    W8_STAMP(2)
+#undef W8_PERIOD
+#undef W8_G
+#undef W8_COPY_U
+#undef W8_COPY_U1
+#undef W8_MFMA1
+#undef W8_T_STORE1
+#undef W8_T_STORE_0
+#undef W8_T_STORE_1
+#undef W8_T_STORE_2
+#undef W8_T_STORE_3
+#undef W8_LOAD_P
+#undef W8_WRITE_P
+#undef W8_T_READ
+#undef W8_T_ROWS
+#undef W8_T_STORE
+#undef W8_LOAD_OPS
+#undef W8_MFMA2
+#undef W8_FENCE
+
+    // ---- epilogue (as k_conv_wino): column half of A^T M A in registers, exchange through LDS, row half + BN +
+    // ReLU (+ 2x2 average pool) per (tile, channel)
+    constexpr int XT = 72, XP = 64 * XT;
+    float *xch = smem;
+    W8_BARRIER()  // every wave is past its last LDS read of the main loop
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float *xp = xch + (2 * xi) * XP + mb * 32 * XT + nh * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float m0 = acc[0][mb][r], m1 = acc[1][mb][r], m2 = acc[2][mb][r], m3 = acc[3][mb][r];
+            xp[row * XT] = (m0 + m1) + m2;
+            xp[XP + row * XT] = (m1 - m2) - m3;
+        }
+    }
+    W8_BARRIER()
+#undef W8_BARRIER
+    const int e_co = tid & 63, e_t0 = tid >> 6;  // thread -> channel, tiles e_t0 + 8*k
+    const int co = n0 + e_co;
+    const float sc = scale[co], sh = shift[co];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int tl = e_t0 + 8 * it;
+        float c0[4], c1[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            c0[x] = xch[(2 * x) * XP + tl * XT + e_co];
+            c1[x] = xch[(2 * x + 1) * XP + tl * XT + e_co];
+        }
+        float y[4];
+        y[0] = (c0[0] + c0[1]) + c0[2];
+        y[1] = (c1[0] + c1[1]) + c1[2];
+        y[2] = (c0[1] - c0[2]) - c0[3];
+        y[3] = (c1[1] - c1[2]) - c1[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(y[e], sc, sh), 0.0f);
+        const int vtr = vtr0 + tl / TTW;
+        const int tc = tc0 + tl % TTW;
+        if (vtr < g.VTR && tc < g.TC) {
+            const int s = vtr / g.TR;
+            const int tr = vtr % g.TR;
+            if (POOL) {
+                out[act_off(s, co, tr, tc, g.Cout, g.Ho, g.Wo)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int hh = 2 * tr + (e >> 1), ww = 2 * tc + (e & 1);
+                    if (hh < g.H && ww < g.W) out[act_off(s, co, hh, ww, g.Cout, g.H, g.W)] = y[e];
+                }
+            }
+        }
+    }
+    W8_STAMP(3)
+#undef W8_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_block1.conv1: one input channel (the log-mel image) -> 64 channels.  K = 9: no matrix
 // shape to speak of; direct, output-bandwidth bound (writes S*T*M*64 floats).
 // thread = (pixel slot, 4 output channels); output in the channel-blocked layout (32 B per pixel per block).
@@ -1012,6 +1376,11 @@ static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t 
     return g.pa_i >= 8 && g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
 }
 
+static int wino_variant() {  // STITO_WINO=12: the first-round 12-wave producer/consumer kernel (kept for A/B runs)
+    static const int v = [] { const char *e = getenv("STITO_WINO"); return e ? atoi(e) : 8; }();
+    return v;
+}
+
 template <int TTW, bool POOL>
 static int launch_wino(const float *in, const float *upk, const float *scale, const float *shift, float *out,
                        const ConvShape &c, hipStream_t st) {
@@ -1020,6 +1389,14 @@ static int launch_wino(const float *in, const float *upk, const float *scale, co
     int64_t blocks;
     STITO_REQUIRE((wino_geometry<TTW, POOL>(c, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd): %dx%d map does not fit the LDS-resident halo patch", c.H, c.W);
+    if (wino_variant() == 8) {
+        g.trace = g_wino_trace;
+        auto kern8 = g_wino_trace ? k_conv_wino8<TTW, POOL, true> : k_conv_wino8<TTW, POOL, false>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern8, dim3((unsigned)blocks), dim3(WINO8_THREADS), lds, st, in, upk, scale, shift, out, g);
+        STITO_LAUNCH_CHECK();
+        return STITO_OK;
+    }
     g.trace = g_wino_trace;
     if (g_wino_trace) {
         lds += 16 * 12 * 8 * sizeof(unsigned);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Phase timeline of one Winograd workgroup (s_memtime stamps recorded by the TRACE instantiation).
+"""Phase timeline of k_conv_wino8 workgroups (s_memtime stamps recorded by the TRACE instantiation): entry, prologue
+done, main loop done, epilogue done and the first barriers, for the workgroups 100, 356, 612, ... of the grid.
     python tools/wino_timeline.py [H W cin cout pool]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,18 +19,18 @@ sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
 out = torch.empty((S, cout // 8, H // 2 if pool else H, W // 2 if pool else W, 8), device=dev)
 args = (_hip.ptr(x), _hip.ptr(upk), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), S, H, W, cin, cout, pool, 1, st)
 _hip.check(L.stito_conv3x3_bn_relu(*args)); torch.cuda.synchronize()
-dbg = torch.zeros(16 * 12 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(8 * 2 * 16, dtype=torch.int64, device=dev)
 _hip.check(L.stito_debug_wino_trace(_hip.ptr(dbg)))
 _hip.check(L.stito_conv3x3_bn_relu(*args)); torch.cuda.synchronize()
 _hip.check(L.stito_debug_wino_trace(None))
-t = dbg.cpu().numpy().reshape(16, 12, 8)
-per = np.diff(t[:, 0, 1])
-P = np.median(per)
-print(f"{H}x{W} {cin}->{cout} pool={pool}: chunk period median {P:.0f}  min {per.min()}  max {per.max()} cycles (MFMA-bound floor: 4096)")
-c = t[1:15]
-rel = lambda w_, s_: np.median(c[:, w_, s_] - c[:, 0, 1])
-for w_ in (0, 1, 4, 7):
-    print(f"consumer wave {w_:2d}: at barrier {rel(w_, 0) + P:6.0f} (= prev chunk)  released {rel(w_, 1):5.0f}  mfma done {rel(w_, 2):5.0f}")
-for w_ in (8, 9, 10, 11):
-    print(f"producer wave {w_:2d}: at barrier {rel(w_, 0) + P:6.0f} (= prev chunk)  released {rel(w_, 1):5.0f}  patch written + U copies issued {rel(w_, 2):5.0f}  "
-          f"patch loads issued {rel(w_, 3):5.0f}  transform done {rel(w_, 4):5.0f}")
+t = dbg.cpu().numpy().reshape(8, 2, 16)
+n_chunks = cin // 8
+print(f"{H}x{W} {cin}->{cout} pool={pool}: {n_chunks} chunks per workgroup; cycles (s_memtime)")
+for i in range(8):
+    if t[i, 0, 0] == 0:
+        continue
+    for wv in (0, 1):
+        a = t[i, wv]
+        per = np.diff(a[4:4 + min(12, n_chunks)])
+        print(f"wg {100 + 256 * i:5d} wave {4 * wv}: start {a[0] - t[0, 0, 0]:9d}  prologue {a[1] - a[0]:6d}  loop {a[2] - a[1]:8d} "
+              f"({(a[2] - a[1]) / n_chunks:7.1f} / chunk; MFMA floor 4096)  epilogue {a[3] - a[2]:6d}  periods {per.tolist()}")
