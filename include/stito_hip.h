@@ -76,7 +76,7 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 2 (1 = first round: stito_fx_desc.flags was called `reserved`, no stito_timing_* context). */
+/* ABI version: 3 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
@@ -164,9 +164,11 @@ int stito_logmel(const stito_frontend *fe, const float *audio_dev, const float *
 
 /* ---- Cnn14 trunk -------------------------------------------------------------------------- */
 #define STITO_CNN14_NUM_CONVS 12
-/* 3x3 conv algorithm: direct implicit GEMM, or Winograd F(2x2,3x3) (2.25x fewer MACs; needs
- * cin % 8 == 0, cout % 64 == 0 and a feature map whose halo patch fits LDS). */
-enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1 };
+/* 3x3 conv algorithm: direct implicit GEMM; Winograd F(2x2,3x3) (16 MACs per 2x2 outputs instead of 36);
+ * Winograd F(4x4,3x3) (36 MACs per 4x4 outputs instead of 144: 4x fewer than direct, 1.78x fewer than F(2x2,3x3)).
+ * Both Winograd forms need cin % 8 == 0, cout % 64 == 0 and a feature map whose halo patch fits LDS
+ * (stito_conv3x3_supported). */
+enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 2 };
 
 typedef struct {
     int32_t embed_dim;
@@ -176,8 +178,9 @@ typedef struct {
     /* conv weights in the packed layout produced by stito_cnn14_pack_conv; BN folded to
      * per-channel scale/shift applied after the convolution (eval mode, panns.py:67-68) */
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
-    const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* STITO_CONV_WINOGRAD packing, or NULL: used per
+    const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD or STITO_CONV_WINOGRAD_F4 (ABI version 3) */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -189,7 +192,7 @@ typedef struct {
 /* Number of floats of a packed conv weight for (cout, cin) and algorithm. */
 size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo);
 /* (cout, cin, 3, 3) PyTorch layout -> packed layout used by the MFMA kernel of `algo`
- * (Winograd: the weights are transformed, U = G g G^T). */
+ * (Winograd: the weights are transformed, U = G g G^T, in float64, rounded once). */
 int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream);
 /* BN(eval) -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  gamma_dev == NULL:
  * identity (use_batchnorm=False). */

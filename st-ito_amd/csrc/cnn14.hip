@@ -21,6 +21,7 @@
 // C layout leaves in 4 consecutive accumulator registers of one lane, so BN+ReLU+avg-pool
 // happen in registers.  Details of the data movement are at k_conv3x3.
 #include "common.h"
+#include "conv_layout.h"
 
 #include <cstdlib>
 #include <utility>
@@ -28,23 +29,7 @@
 
 namespace stito {
 
-// Activation layout: channel-blocked NC8HW8 -- element (stream s, channel c, row h, column w) of a map
-// with C channels lives at (((s * C/8 + c/8) * H + h) * W + w) * 8 + c%8.  Eight consecutive
-// channels of a pixel are 32 B, and for one channel block consecutive pixels are contiguous: a
-// K-chunk's halo patch rows are dense 32-B-per-pixel runs (NHWC would touch one 32-B piece out of
-// every 4*C-byte pixel vector per chunk: 4x line over-fetch, measured as the Winograd limiter).
-__device__ __forceinline__ int64_t act_off(int64_t s, int c, int h, int w, int C, int H, int W) {
-    return ((((s * (C >> 3)) + (c >> 3)) * H + h) * (int64_t)W + w) * 8 + (c & 7);
-}
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 static constexpr int CK = 4;      // input channels per chunk (16 B per pixel / per weight row)
-
-struct ConvShape {
-    int S, H, W, Cin, Cout;
-};
 
 // Same copy with everything but the per-lane byte offset on the scalar unit: global address =
 // sbase (SGPR pair, wave-uniform) + voff (32-bit per-lane offset), LDS base wave-uniform.  No VALU
@@ -707,31 +692,6 @@ __global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restr
 // ------------------------------------------------------------------------------------------------
 static constexpr int WINO8_THREADS = 512;
 
-// Packed f32 arithmetic, issued explicitly: in this kernel hipcc splits native-vector f32x4 expressions into scalar
-// v_fma / v_sub (twice the VALU instructions, and every VALU instruction is taken out of the MFMA stream's time).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {  // a + (-b): exact, bit-identical to v_sub_f32
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// LDS-DMA as glds16_s, without saving M0: nothing else in k_conv_wino8 reads M0 (gfx950 LDS instructions do not, and the
-// kernel has no movrel / sendmsg / interp); hipcc rejects "m0" in a clobber list as reserved, so this is by inspection
-// of the ISA (grep m0: only these statements write it)
-__device__ __forceinline__ void glds16_m0(const float *sbase, unsigned voff, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-}
-
 template <int TTW, bool POOL, bool TRACE = false>
 __global__ __launch_bounds__(WINO8_THREADS) void k_conv_wino8(const float *__restrict__ in, const float *__restrict__ upk,
                                                                const float *__restrict__ scale,
@@ -946,11 +906,13 @@ __global__ __launch_bounds__(WINO8_THREADS) void k_conv_wino8(const float *__res
         W8_MFMA2(y, 2, 2)                                                                                \
         W8_MFMA2(y, 2, 3)                                                                                \
         W8_FENCE()                                                                                       \
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); /* U(k+1) landed; the NPL younger patch loads may fly on */ \
+        /* U(k+1) landed.  vmcnt(0), not vmcnt(NPL): LDS-DMA copies and register loads do not complete in issue order on */ \
+        /* this part (tools/conv_stress.py caught k_conv_wino43 consuming a slab early under a partial wait), so the patch */ \
+        /* loads of this period are drained too -- they were issued 28 MFMA gaps ago.                                      */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
         W8_BARRIER()                                     /* B(k) */                                      \
         if (TRACE && k < 12) { W8_STAMP(4 + k) }                                                         \
     }
-    static_assert(NPL == 2, "the vmcnt immediate of W8_PERIOD is written for 2 patch loads per set");
 
     {
         int k = 0;
@@ -1454,10 +1416,14 @@ using namespace stito;
 static bool wino_ok(int cout, int cin) { return cin % WK == 0 && cout % 64 == 0; }
 
 extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo) {
-    return (size_t)cout * cin * (algo == STITO_CONV_WINOGRAD ? 16 : 9);
+    return (size_t)cout * cin * (algo == STITO_CONV_WINOGRAD_F4 ? 36 : algo == STITO_CONV_WINOGRAD ? 16 : 9);
 }
 
 extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream) {
+    if (algo == STITO_CONV_WINOGRAD_F4) {
+        STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
+        return pack_wino43(w_oihw_dev, cout, cin, packed_dev, (hipStream_t)stream);
+    }
     if (algo == STITO_CONV_WINOGRAD) {
         STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
         const int64_t n = (int64_t)cout * cin;
@@ -1491,6 +1457,7 @@ extern "C" int stito_debug_wino_trace(long long *buf_dev) {
 extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo) {
     if (n <= 0 || H <= 0 || W <= 0 || cout % 4 != 0) return 0;
     if (pool && (H < 2 || W < 2)) return 0;
+    if (algo == STITO_CONV_WINOGRAD_F4) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD) return wino_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (cin == 1) return (!pool && 256 % (cout / 4) == 0) ? 1 : 0;
     return (cin % 8 == 0 && cout % 64 == 0) ? 1 : 0;  // channel-blocked activations: 8 channels per block
@@ -1508,6 +1475,10 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
     STITO_REQUIRE(cout % 64 == 0, STITO_E_UNSUPPORTED, "conv: cout=%d must be a multiple of 64", cout);
     STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
     ConvShape g{n, H, W, cin, cout};
+    if (algo == STITO_CONV_WINOGRAD_F4) {
+        STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
+        return launch_wino43(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, pool != 0, g_wino_trace, st);
+    }
     if (algo == STITO_CONV_WINOGRAD) {
         STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
         return pool ? launch_wino_tw<true>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st)
@@ -1603,7 +1574,8 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             const int i = 2 * blk + j;
             const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
             // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
-            const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, STITO_CONV_WINOGRAD);
+            const int walgo = w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 ? STITO_CONV_WINOGRAD_F4 : STITO_CONV_WINOGRAD;
+            const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
             const bool timed = g_conv_timing.on && ci % 8 == 0;
             if (timed) {
                 if (g_conv_timing.used == g_conv_timing.pool.size()) {
@@ -1616,7 +1588,7 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             }
             const int rc = stito_conv3x3_bn_relu(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
                                                  w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
-                                                 wino ? STITO_CONV_WINOGRAD : STITO_CONV_DIRECT, stream);
+                                                 wino ? walgo : STITO_CONV_DIRECT, stream);
             if (rc) return rc;
             if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
         }

@@ -1,0 +1,62 @@
+// conv_layout.h -- pieces shared by the 3x3-conv kernels of the Cnn14 trunk (cnn14.hip, conv_wino43.hip): the
+// channel-blocked activation layout, native vector types, explicit packed-f32 arithmetic and the LDS-DMA copy.
+#pragma once
+#include "common.h"
+
+namespace stito {
+
+// Activation layout: channel-blocked NC8HW8 -- element (stream s, channel c, row h, column w) of a map
+// with C channels lives at (((s * C/8 + c/8) * H + h) * W + w) * 8 + c%8.  Eight consecutive
+// channels of a pixel are 32 B, and for one channel block consecutive pixels are contiguous: a
+// K-chunk's halo patch rows are dense 32-B-per-pixel runs (NHWC would touch one 32-B piece out of
+// every 4*C-byte pixel vector per chunk: 4x line over-fetch, measured as the Winograd limiter).
+__device__ __forceinline__ int64_t act_off(int64_t s, int c, int h, int w, int C, int H, int W) {
+    return ((((s * (C >> 3)) + (c >> 3)) * H + h) * (int64_t)W + w) * 8 + (c & 7);
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct ConvShape {
+    int S, H, W, Cin, Cout;
+};
+
+// Packed f32 arithmetic, issued explicitly: inside the MFMA loops hipcc splits native-vector f32x4 expressions into
+// scalar v_fma / v_sub (twice the VALU instructions, and every VALU instruction is taken out of the MFMA stream's time).
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {  // a + (-b): exact, bit-identical to v_sub_f32
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// LDS-DMA: 16 B per lane, global (sbase SGPR pair, wave-uniform, + voff per-lane byte offset) -> LDS at M0 + lane * 16,
+// no VGPR round trip and no VALU instruction.  M0 is not saved: nothing else in the kernels that use this reads it
+// (gfx950 LDS instructions do not, and they have no movrel / sendmsg / interp); hipcc rejects "m0" in a clobber list as
+// reserved, so that is checked by inspection of the ISA (grep m0: only these statements write it).
+__device__ __forceinline__ void glds16_m0(const float *sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+// conv_wino43.hip
+bool wino43_supported(const ConvShape &c, bool pool);
+int launch_wino43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                  bool pool, long long *trace, hipStream_t st);
+int pack_wino43(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
+
+}  // namespace stito

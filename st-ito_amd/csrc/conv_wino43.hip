@@ -1,0 +1,522 @@
+// conv_wino43.hip -- 3x3 conv (pad 1) + BN + ReLU (+ 2x2 average pool) of the Cnn14 trunk (reference
+// st_ito/models/panns.py:25-80, 250-261) by Winograd F(4x4, 3x3) on exact-f32 MFMA.
+//
+// Per 6x6 input tile d (stride 4):  Y(4x4) = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A   (Lavin & Gray 2016, points
+// 0, +-1, +-2, inf).  The 36 element-wise products are 36 independent GEMMs M_p[tile, cout] = V_p[tile, cin] U_p[cin, cout]:
+// 36 MACs per 16 outputs = 2.25 per output, against 4 for F(2x2,3x3) (k_conv_wino8) and 9 for the direct form.  The f32
+// matrix pipe is the bound of the whole step, so this is 1.78x fewer of its cycles than F(2x2,3x3).
+// Accuracy: the transforms carry coefficients up to 8 and 1/24; simulated through the whole trunk in float32 against a
+// float64 direct convolution (all 11 layers Winograd, synthetic AFx-Rep weights) the pooled features differ by 4e-7 of
+// their maximum (F(2x2,3x3): 2e-7, float32 direct: 1e-7) -- far inside the 1e-4 bar; the per-layer parity tests hold the
+// kernel to 5e-5 of the layer's output maximum against a float64 conv2d on random SIGNED inputs (the worst case for the
+// cancellation in A^T M A: 3.3e-5 at cin = 2048, against 6e-6 for the direct kernel); on the real trunk (tools/
+// trunk_accuracy.py, 10 s stereo, embeddings against the float64 oracle) all three algorithms sit at 1-2e-6.
+//
+// Workgroup = 32 tiles (512 output pixels) x 64 output channels x 36 positions, 4-channel chunks, 8 symmetric waves
+// (512 threads, 2 per SIMD), built like k_conv_wino8 on the findings of tools/ubench/mfma_{coissue,interleave}.hip: a wave
+// streaming f32 MFMAs starves the other waves of its SIMD, so there are no producer waves -- every wave interleaves its
+// share of the production into its own MFMA stream:
+//   MFMA   wave (g = w / 2, nh = w % 2): positions 9g .. 9g+8 x 32 tiles x channel half nh: 9 MFMA blocks = 144
+//          accumulator VGPRs, 18 MFMAs per chunk, operands of the next three blocks read while three run;
+//   U      [cin/4][36][cout][4] pre-transformed weights: 36 scalar-addressed 1 KB LDS-DMA copies per chunk, 4-5 per wave;
+//   patch  raw halo patch (4 channels = 16 B per pixel): LDS-DMA too, lanes without a pixel masked off through EXEC (the
+//          two patch buffers are zero-filled once = the padding), issued first thing in the period BEFORE the one that
+//          transforms it;
+//   every period ends with s_waitcnt vmcnt(0): partial waits (vmcnt(n) leaving the youngest copies in flight) are NOT safe
+//          here -- LDS-DMA loads, and register loads mixed with them, were observed to complete out of issue order (one
+//          workgroup in ~10^2..10^4 consumed a U slab before it had landed; tools/conv_stress.py), so everything a
+//          period issues has to land inside it and is issued in its first third;
+//   V      item = (tile, row i of B^T d B, channel pair), 48 items per wave: the row combination with per-lane
+//          coefficients (4 ds_read_b64 + 4 packed VALU per column), then the column combination (12 packed VALU) and 6
+//          ds_write_b64.
+// One barrier per chunk in a rotated loop (barrier(k) sits after the operand reads of chunk k's last block group).
+// Epilogue: the 36 positions of an output meet in three passes over the position rows {1,2}, {3,4}, {0,5}: the owning
+// waves write those accumulators to LDS (12 x 32 x 64 floats), thread (tile, channel quad) reduces each row over j
+// (column half of A^T M A) and accumulates its contribution to the 4x4 outputs; then BN + ReLU (+ pool) and 16-byte
+// stores into the channel-blocked activation layout.
+#include "conv_layout.h"
+
+namespace stito {
+
+static constexpr int W43_THREADS = 512;
+static constexpr int W43_K = 4;                          // input channels per chunk
+static constexpr int W43_U = 36 * 64 * W43_K;            // floats: [pos][cout][4]
+static constexpr int W43_V = 36 * 32 * W43_K;            // floats: [pos][tile][4]
+static constexpr int W43_BUF = W43_U + W43_V;
+static constexpr int W43_XT = 68;                        // exchange: floats per tile row ([pos][tile][64 cout], +4 pad)
+
+struct Wino43Geom {
+    int S, H, W, Cin, Cout;
+    int TR, TC;        // tile rows per stream / tile columns that produce output
+    int64_t VTR;       // S * TR
+    int n_col_blocks;
+    int Ho, Wo;        // output map (pooled when POOL)
+    int PR;            // halo patch rows
+    int zoff;          // float offset of the zero pixels inside a patch buffer
+    int pfl;           // floats per patch buffer
+    long long *trace;  // TRACE instantiation only
+};
+
+// -a as fma operand helper: (T3 - T1) etc. stay packed
+#define P2(v, h) __builtin_shufflevector(v, v, 2 * (h), 2 * (h) + 1)
+
+// v_pk_fma_f32 with one packed operand taken from ONE half of a register pair for both results (op_sel / op_sel_hi):
+// d = x * c.lo + y   and   d = x * c.hi + y.  The row-combination coefficients are per lane (the lane's row i), two per pair.
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 x, f32x2 c, f32x2 y) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(c), "v"(y));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 x, f32x2 c, f32x2 y) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(c), "v"(y));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 x, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(c));
+    return d;
+}
+
+template <int TTW, bool POOL, bool TRACE>
+__global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__restrict__ in, const float *__restrict__ upk,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, float *__restrict__ out,
+                                                              Wino43Geom g) {
+    constexpr int TTH = 32 / TTW;
+    constexpr int PWC = 4 * TTW + 2;  // patch columns
+    constexpr int NPL = 2;            // float4 of patch per thread per chunk (PR * PWC <= 1024, host check)
+    constexpr int BUF = W43_BUF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = g.Cout / 64;
+    const int m_blk = blockIdx.x / n_tiles;  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    const int n0 = (blockIdx.x % n_tiles) * 64;
+    const int cb = m_blk % g.n_col_blocks;
+    const int rb = m_blk / g.n_col_blocks;
+    const int vtr0 = rb * TTH;  // first virtual tile row (s * TR + tr) of the block
+    const int tc0 = cb * TTW;
+    const int n_chunks = g.Cin / W43_K;
+    float *patch0 = smem + 2 * BUF;
+    const int iv_lo = (vtr0 / g.TR) * g.H + 4 * (vtr0 % g.TR) - 1;  // input virtual row (s*H + h) of patch row 0
+
+#define W43_STAMP(SLOT)                                                                                 \
+    if (TRACE && (blockIdx.x & 255) == 100 && (blockIdx.x >> 8) < 8 && lane == 0 && (wv & 3) == 0)      \
+        g.trace[((blockIdx.x >> 8) * 2 + (wv >> 2)) * 16 + (SLOT)] = (long long)__builtin_readcyclecounter();
+    W43_STAMP(0)
+
+    // ---- MFMA role ----------------------------------------------------------------------------------------
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nh = wv & 1, pg = wv >> 1;
+    const int a_off = W43_U + (9 * pg) * 32 * W43_K + l31 * W43_K + half * 2;  // V[p][tile][4], this lane's channel pair
+    const int b_off = (9 * pg) * 64 * W43_K + (nh * 32 + l31) * W43_K + half * 2;  // U[p][cout][4]
+
+    // ---- transform item: (row i of B^T d B, tile, channel pair); 48 items per wave so that all 8 waves carry the same load ----
+    int roff[4];   // float offsets (inside a patch buffer) of the four input rows the lane's row i combines
+    f32x2 cab, ccd;  // their coefficients (a, b), (c, d)
+    int vdst;
+    {
+        // lanes 48..63 mirror lanes 32..47 (same reads, same values, same addresses written): no divergent branch in the loop
+        const int it = wv * 48 + (lane < 48 ? lane : lane - 16);
+        const int cp = it & 1, tile = (it >> 1) & 31, ti = it >> 6;
+        // B^T (Lavin & Gray):  row 0: 4 d0 - 5 d2 + d4        row 1: -4 d1 - 4 d2 + d3 + d4   row 2: 4 d1 - 4 d2 - d3 + d4
+        //                      row 3: -2 d1 - d2 + 2 d3 + d4  row 4: 2 d1 - d2 - 2 d3 + d4     row 5: 4 d1 - 5 d3 + d5
+        int kr[4];
+        float cf[4];
+        switch (ti) {
+            case 0: kr[0] = 0; kr[1] = 2; kr[2] = 4; kr[3] = -1; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
+            case 1: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -4.f; cf[1] = -4.f; cf[2] = 1.f; cf[3] = 1.f; break;
+            case 2: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 4.f; cf[1] = -4.f; cf[2] = -1.f; cf[3] = 1.f; break;
+            case 3: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -2.f; cf[1] = -1.f; cf[2] = 2.f; cf[3] = 1.f; break;
+            case 4: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 2.f; cf[1] = -1.f; cf[2] = -2.f; cf[3] = 1.f; break;
+            default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = -1; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
+        }
+        const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
+        const int s_ = vtr / g.TR, tr = vtr % g.TR;
+        const int pc0 = s_ * g.H + 4 * tr - 1 - iv_lo;  // patch row of this tile's first input row
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int hh = 4 * tr - 1 + kr[x];
+            const bool ok = kr[x] >= 0 && vtr < g.VTR && hh >= 0 && hh < g.H;  // rows outside the map / stream: the zero pixels
+            roff[x] = (ok ? ((pc0 + kr[x]) * PWC + 4 * tcl) * W43_K : g.zoff) + cp * 2;
+        }
+        cab = (f32x2){cf[0], cf[1]};
+        ccd = (f32x2){cf[2], cf[3]};
+        vdst = W43_U + (ti * 6) * 32 * W43_K + tile * W43_K + cp * 2;  // V[6 ti + j][tile][cp]
+    }
+
+    // ---- U slab copies: position ii = wv + 8 j, 1 KB each --------------------------------------------------
+    const float *u_base = upk + (int64_t)n0 * W43_K;
+    const int64_t u_pos_stride = (int64_t)g.Cout * W43_K, u_chunk_stride = 36 * u_pos_stride;  // floats
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+
+    // ---- halo patch staging: pixel q = tid + 512 j, 16 B (4 channels) each, by LDS-DMA ------------------------------
+    const int s_first = (iv_lo < 0 ? 0 : iv_lo) / g.H;
+    const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W);
+    const int64_t plane8 = (int64_t)g.H * g.W * 8;  // floats per 8-channel plane of one stream
+    unsigned p_off[NPL];                             // per-lane byte offset from the chunk's base
+    uint64_t p_mask[NPL];                            // lanes of this wave that have a pixel (wave-uniform)
+    {
+        const int npix = g.PR * PWC;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int q = tid + W43_THREADS * j;
+            const int pr = q / PWC, pc = q % PWC;
+            const int iv = iv_lo + pr;
+            const int w = 4 * tc0 - 1 + pc;
+            const bool ok = q < npix && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
+            const int s_ = ok ? iv / g.H : s_first, h_ = ok ? iv % g.H : 0, w_ = ok ? w : 0;
+            p_off[j] = (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
+            p_mask[j] = __builtin_amdgcn_ballot_w64(ok);
+        }
+    }
+    const unsigned lds_patch = lds0 + (unsigned)(2 * BUF) * 4u;  // byte address of patch buffer 0
+
+#define W43_COPY_U1(CH, BOFF, J_) /* callers guarantee CH < n_chunks */                                  \
+    {                                                                                                    \
+        const int ii = wv + 8 * (J_) < 36 ? wv + 8 * (J_) : wv + 8 * (J_) - 8;                           \
+        glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + ii * u_pos_stride, (unsigned)lane * 16u,     \
+                  lds0 + (unsigned)((BOFF) + ii * 64 * W43_K) * 4u);                                     \
+    }
+// patch(CH) -> patch buffer PB (0, 1): two masked LDS-DMA instructions per wave (pixels wv*64 + 512 j + lane)
+#define W43_COPY_P(CH, PB)                                                                              \
+    {                                                                                                   \
+        const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                           \
+        const float *pb_ = p_base + (int64_t)(cc_ >> 1) * plane8 + (cc_ & 1) * 4;                        \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) {                                                \
+            uint64_t keep_;                                                                              \
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"  \
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                          \
+                         : "=&s"(keep_)                                                                  \
+                         : "v"(p_off[j]), "s"(pb_), "s"(lds_patch + (unsigned)((PB) * g.pfl + (wv * 64 + W43_THREADS * j) * W43_K) * 4u), \
+                           "s"(p_mask[j])                                                                \
+                         : "memory");                                                                    \
+        }                                                                                                \
+    }
+// transform: row combination of column L (4 reads), T[L] = ((ca da + cb db) + cc dc) + cd dd
+#define W43_T_RD(PBUF, L, R)                                                                            \
+    {                                                                                                   \
+        R[0] = *(const f32x2 *)((PBUF) + roff[0] + (L) * W43_K);                                         \
+        R[1] = *(const f32x2 *)((PBUF) + roff[1] + (L) * W43_K);                                         \
+        R[2] = *(const f32x2 *)((PBUF) + roff[2] + (L) * W43_K);                                         \
+        R[3] = *(const f32x2 *)((PBUF) + roff[3] + (L) * W43_K);                                         \
+    }
+#define W43_T_ROW(L, R) tT[L] = pk_fma_hi(R[3], ccd, pk_fma_lo(R[2], ccd, pk_fma_hi(R[1], cab, pk_mul_lo(R[0], cab))));
+// column combination (the same B^T along the columns) and stores: V[6 i + j] for j = 0..5
+#define W43_T_COLS_A(VBOFF)                                                                             \
+    {                                                                                                   \
+        float *vb_ = smem + (VBOFF) + vdst;                                                              \
+        const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, cm4 = {-4.f, -4.f};                             \
+        *(f32x2 *)(vb_ + 0 * 32 * W43_K) = pk_fma(c4, tT[0], pk_fma(cm5, tT[2], tT[4]));                 \
+        const f32x2 p_ = pk_fma(cm4, tT[2], tT[4]), q_ = pk_fma(cm4, tT[1], tT[3]);                      \
+        *(f32x2 *)(vb_ + 1 * 32 * W43_K) = pk_add(p_, q_);                                               \
+        *(f32x2 *)(vb_ + 2 * 32 * W43_K) = pk_sub(p_, q_);                                               \
+    }
+#define W43_T_COLS_B(VBOFF)                                                                             \
+    {                                                                                                   \
+        float *vb_ = smem + (VBOFF) + vdst;                                                              \
+        const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f};            \
+        const f32x2 s_ = pk_sub(tT[4], tT[2]), u_ = pk_sub(tT[3], tT[1]);                                \
+        *(f32x2 *)(vb_ + 3 * 32 * W43_K) = pk_fma(c2, u_, s_);                                           \
+        *(f32x2 *)(vb_ + 4 * 32 * W43_K) = pk_fma(cm2, u_, s_);                                          \
+        *(f32x2 *)(vb_ + 5 * 32 * W43_K) = pk_fma(c4, tT[1], pk_fma(cm5, tT[3], tT[5]));                 \
+    }
+// MFMA operands of block group G (blocks 3G .. 3G+2 of this wave's nine) into register set S
+#define W43_LOAD_OPS(S, SB, G)                                                                          \
+    {                                                                                                   \
+        _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                               \
+            S##a[t_] = *(const f32x2 *)((SB) + a_off + (3 * (G) + t_) * 32 * W43_K);                     \
+            S##b[t_] = *(const f32x2 *)((SB) + b_off + (3 * (G) + t_) * 64 * W43_K);                     \
+        }                                                                                                \
+    }
+#define W43_MFMA(S, G, T_, E_)                                                                          \
+    acc[3 * (G) + (T_)] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[T_][E_], S##b[T_][E_], acc[3 * (G) + (T_)], 0, 0, 0);
+#define W43_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define W43_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define W43_GAP(S, G, T_, E_, WORK) W43_MFMA(S, G, T_, E_) WORK W43_FENCE()
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    f32x2 tT[6], rX[4], rY[4];
+    f32x2 xa[3], xb[3], ya[3], yb[3];
+
+    // ---- prologue: zero the patch buffers (= the padding), then patch(0), patch(1), U(0) by LDS-DMA; V(0) from patch(0) ------
+    for (int i = tid * 4; i < 2 * g.pfl; i += W43_THREADS * 4) *(f32x4 *)(patch0 + i) = (f32x4)(0.0f);
+    W43_BARRIER()  // no copy may land under the zero fill
+    W43_COPY_P(0, 0)
+    W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4)
+    W43_COPY_P(1, 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W43_BARRIER()
+    W43_T_RD(patch0, 0, rX) W43_T_RD(patch0, 1, rY)
+    W43_T_ROW(0, rX) W43_T_RD(patch0, 2, rX)
+    W43_T_ROW(1, rY) W43_T_RD(patch0, 3, rY)
+    W43_T_ROW(2, rX) W43_T_RD(patch0, 4, rX)
+    W43_T_ROW(3, rY) W43_T_RD(patch0, 5, rY)
+    W43_T_ROW(4, rX) W43_T_ROW(5, rY)
+    W43_T_COLS_A(0)
+    W43_T_COLS_B(0)
+    W43_BARRIER()  // B(-1): V(0), U(0) complete
+    W43_STAMP(1)
+
+// One period: chunk k's block groups 0 and 1 run here, preceded by group 2 of chunk k-1 from registers (not FIRST).
+// S0 holds group 2 of the previous chunk on entry; the sets alternate S0, S1, S0 and the next period starts on S1.
+// MORE: chunk k+1 exists -- its production (U copies, transform) and the patch copy of chunk k+2 are spread over the first
+// MFMA gaps; patch(c) lives in buffer c % 2.
+#define W43_PERIOD(S0, S1, FIRST, MORE)                                                                 \
+    {                                                                                                   \
+        const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
+        const float *sb = smem + cur;                                                                    \
+        const float *pb_r = patch0 + ((k + 1) & 1) * g.pfl; /* patch(k+1); patch(k+2) goes where patch(k) was */ \
+        if (!(FIRST)) {                                                                                  \
+            W43_GAP(S0, 2, 0, 0, if (MORE) W43_COPY_P(k + 2, k & 1))                                     \
+            W43_GAP(S0, 2, 1, 0, W43_LOAD_OPS(S1, sb, 0) if (MORE) W43_COPY_U1(k + 1, nxt, 0))           \
+            W43_GAP(S0, 2, 2, 0, if (MORE) W43_COPY_U1(k + 1, nxt, 1))                                   \
+            W43_GAP(S0, 2, 0, 1, if (MORE) W43_COPY_U1(k + 1, nxt, 2))                                   \
+            W43_GAP(S0, 2, 1, 1, if (MORE) W43_COPY_U1(k + 1, nxt, 3))                                   \
+            W43_GAP(S0, 2, 2, 1, if (MORE) W43_COPY_U1(k + 1, nxt, 4))                                   \
+        } else {                                                                                         \
+            W43_COPY_P(k + 2, k & 1)                                                                     \
+            W43_LOAD_OPS(S1, sb, 0)                                                                      \
+            W43_COPY_U1(k + 1, nxt, 0) W43_COPY_U1(k + 1, nxt, 1) W43_COPY_U1(k + 1, nxt, 2)             \
+            W43_COPY_U1(k + 1, nxt, 3) W43_COPY_U1(k + 1, nxt, 4)                                        \
+            W43_FENCE()                                                                                  \
+        }                                                                                                \
+        W43_GAP(S1, 0, 0, 0, W43_LOAD_OPS(S0, sb, 1))                                                    \
+        W43_GAP(S1, 0, 1, 0, if (MORE) { W43_T_RD(pb_r, 0, rX) W43_T_RD(pb_r, 1, rY) })                  \
+        W43_GAP(S1, 0, 2, 0, )                                                                           \
+        W43_GAP(S1, 0, 0, 1, if (MORE) { W43_T_ROW(0, rX) W43_T_RD(pb_r, 2, rX) })                       \
+        W43_GAP(S1, 0, 1, 1, if (MORE) { W43_T_ROW(1, rY) W43_T_RD(pb_r, 3, rY) })                       \
+        W43_GAP(S1, 0, 2, 1, if (MORE) { W43_T_ROW(2, rX) W43_T_RD(pb_r, 4, rX) })                       \
+        W43_GAP(S0, 1, 0, 0, W43_LOAD_OPS(S1, sb, 2))                                                    \
+        W43_GAP(S0, 1, 1, 0, if (MORE) { W43_T_ROW(3, rY) W43_T_RD(pb_r, 5, rY) })                       \
+        W43_GAP(S0, 1, 2, 0, if (MORE) W43_T_ROW(4, rX))                                                 \
+        W43_GAP(S0, 1, 0, 1, if (MORE) W43_T_ROW(5, rY))                                                 \
+        W43_GAP(S0, 1, 1, 1, if (MORE) W43_T_COLS_A(nxt))                                                \
+        W43_GAP(S0, 1, 2, 1, if (MORE) W43_T_COLS_B(nxt))                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* U(k+1), patch(k+2) landed (no partial waits: see the header) */ \
+        W43_BARRIER()                                     /* B(k) */                                     \
+        if (TRACE && k < 12) { W43_STAMP(4 + k) }                                                        \
+    }
+
+    {
+        // n_chunks is even and >= 2 (Cin % 8 == 0).  Periods 0 .. n_chunks-2 produce the next chunk; the last one does not.
+        int k = 0;
+        W43_PERIOD(x, y, true, true)  // leaves group 2 of chunk 0 in set y
+        for (k = 1; k + 2 < n_chunks; k += 2) {
+            W43_PERIOD(y, x, false, true)
+            ++k;
+            W43_PERIOD(x, y, false, true)
+            --k;
+        }
+        W43_PERIOD(y, x, false, false)  // k = n_chunks - 1
+        W43_MFMA(x, 2, 0, 0) W43_MFMA(x, 2, 1, 0) W43_MFMA(x, 2, 2, 0)
+        W43_MFMA(x, 2, 0, 1) W43_MFMA(x, 2, 1, 1) W43_MFMA(x, 2, 2, 1)
+    }
+    W43_STAMP(2)
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Three passes over the position rows
+    // {1,2}, {3,4}, {0,5} (the pairs whose contributions share sums and differences); reader thread = (tile, channel
+    // quad) keeps the 4x4 outputs of its 4 channels (64 VGPRs).  Packed arithmetic on register halves throughout.
+#define A4(a, b) __builtin_shufflevector(pk_add(P2(a, 0), P2(b, 0)), pk_add(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
+#define S4(a, b) __builtin_shufflevector(pk_sub(P2(a, 0), P2(b, 0)), pk_sub(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
+#define F4(c2, a, b) __builtin_shufflevector(pk_fma(c2, P2(a, 0), P2(b, 0)), pk_fma(c2, P2(a, 1), P2(b, 1)), 0, 1, 2, 3) /* c a + b */
+    float *xch = smem;                      // [12 positions of the pass][32 tiles][W43_XT]
+    constexpr int XP = 32 * W43_XT;
+    const int e_quad = tid & 15, e_tile = tid >> 4;
+    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
+    f32x4 Yo[4][4];
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        W43_BARRIER()  // the main loop's (or the previous pass's) LDS reads are done
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int p = 9 * pg + q;  // wave-uniform
+            // exchange slot of position p in this pass: rows {1,2} -> p - 6, rows {3,4} -> p - 18, rows {0,5} -> p or p - 24
+            const int slot = pass == 0 ? p - 6 : pass == 1 ? p - 18 : (p < 6 ? p : p - 24);
+            const bool mine = pass == 0 ? (p >= 6 && p < 18) : pass == 1 ? (p >= 18 && p < 30) : (p < 6 || p >= 30);
+            if (mine) {
+                float *xp = xch + slot * XP + nh * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int trow = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    xp[trow * W43_XT] = acc[q][r];
+                }
+            }
+        }
+        W43_BARRIER()
+        f32x4 Z[2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            f32x4 m[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[j] = *(const f32x4 *)(xch + (ii * 6 + j) * XP + e_tile * W43_XT + e_quad * 4);
+            // column half: Z[c] = sum_j M[i][j] A[j][c]
+            const f32x4 s12 = A4(m[1], m[2]), d12 = S4(m[1], m[2]), s34 = A4(m[3], m[4]), d34 = S4(m[3], m[4]);
+            Z[ii][0] = A4(A4(m[0], s12), s34);
+            Z[ii][1] = F4(k2, d34, d12);
+            Z[ii][2] = F4(k4, s34, s12);
+            Z[ii][3] = A4(F4(k8, d34, d12), m[5]);
+        }
+        // row half: Y[r][c] += A^T[r][i] Z_i[c]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (pass == 0) {         // rows 1, 2: A^T columns (1,1,1,1) and (1,-1,1,-1); first pass: initialises Y
+                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
+                Yo[0][c] = sm; Yo[1][c] = df; Yo[2][c] = sm; Yo[3][c] = df;
+            } else if (pass == 1) {  // rows 3, 4: (1,2,4,8) and (1,-2,4,-8)
+                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
+                Yo[0][c] = A4(Yo[0][c], sm); Yo[1][c] = F4(k2, df, Yo[1][c]); Yo[2][c] = F4(k4, sm, Yo[2][c]); Yo[3][c] = F4(k8, df, Yo[3][c]);
+            } else {                 // rows 0, 5: (1,0,0,0) and (0,0,0,1)
+                Yo[0][c] = A4(Yo[0][c], Z[0][c]); Yo[3][c] = A4(Yo[3][c], Z[1][c]);
+            }
+        }
+    }
+#undef A4
+#undef S4
+#undef F4
+    // BN + ReLU (+ 2x2 average pool), 16-byte stores (4 channels) into NC8HW8
+    {
+        const int co = n0 + e_quad * 4;
+        const f32x4 sc = *(const f32x4 *)(scale + co), sh = *(const f32x4 *)(shift + co);
+        const int vtr = vtr0 + e_tile / TTW;
+        const int tc = tc0 + e_tile % TTW;
+        if (vtr < g.VTR && tc < g.TC) {
+            const int s = vtr / g.TR, tr = vtr % g.TR;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Yo[r][c] = __builtin_elementwise_max(Yo[r][c] * sc + sh, (f32x4)(0.0f));
+            if (POOL) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int oh = 2 * tr + pr, ow = 2 * tc + pc;
+                        if (oh < g.Ho && ow < g.Wo)
+                            *(f32x4 *)(out + act_off(s, co, oh, ow, g.Cout, g.Ho, g.Wo)) =
+                                (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int hh = 4 * tr + r, ww = 4 * tc + c;
+                        if (hh < g.H && ww < g.W) *(f32x4 *)(out + act_off(s, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r][c];
+                    }
+            }
+        }
+    }
+    W43_STAMP(3)
+}
+
+// Winograd F(4x4,3x3) weight transform U = G g G^T (float64, rounded once), packed [cin/4][36][cout][4].
+// G (Lavin & Gray) = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1].
+__global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double gk[3][3], t[6][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) gk[a][b] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + b];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * gk[0][b] + G[a][1] * gk[1][b] + G[a][2] * gk[2][b];
+    const int chunk = ci / W43_K, c4 = ci % W43_K;
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+            o[(((int64_t)chunk * 36 + a * 6 + b) * Cout + co) * W43_K + c4] = (float)u;
+        }
+}
+
+static int w43_ttw(const ConvShape &c, bool pool) {
+    const int tc = pool ? (c.W / 2 + 1) / 2 : (c.W + 3) / 4;
+    return tc >= 8 ? 8 : (tc >= 4 ? 4 : (tc >= 2 ? 2 : 1));
+}
+
+template <int TTW>
+static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &lds, int64_t &blocks) {
+    constexpr int TTH = 32 / TTW, PWC = 4 * TTW + 2;
+    g = Wino43Geom{};
+    g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
+    g.Ho = pool ? c.H / 2 : c.H;
+    g.Wo = pool ? c.W / 2 : c.W;
+    g.TR = pool ? (g.Ho + 1) / 2 : (c.H + 3) / 4;
+    g.TC = pool ? (g.Wo + 1) / 2 : (c.W + 3) / 4;
+    if (g.TR < 1 || g.TC < 1) return false;
+    g.VTR = (int64_t)g.S * g.TR;
+    g.n_col_blocks = (g.TC + TTW - 1) / TTW;
+    const int64_t nrb = (g.VTR + TTH - 1) / TTH;
+    blocks = nrb * g.n_col_blocks * (g.Cout / 64);
+    if (nrb * g.n_col_blocks >= (1 << 30) || blocks >= (1ll << 31)) return false;
+    if ((int64_t)g.S * g.H >= (1ll << 31) - 64 || g.VTR >= (1ll << 31) - 64) return false;  // 32-bit row arithmetic in the kernel
+    // patch rows: 4 per tile row + 2 halo, plus the input rows skipped at every stream boundary a block can straddle
+    const int skip = g.H - 4 * g.TR > 0 ? g.H - 4 * g.TR : 0;
+    g.PR = 4 * TTH + 2 + ((TTH - 1) / g.TR + 1) * skip;
+    const int npix = g.PR * PWC;
+    if (npix > 2 * W43_THREADS) return false;
+    g.zoff = (npix * W43_K + 255) / 256 * 256;
+    g.pfl = g.zoff + 64;  // + 16 zero pixels (a transform row reads 6 of them)
+    // 32-bit byte offsets of the patch loads relative to the block's first stream
+    if ((int64_t)((TTH - 1) / g.TR + 2) * (g.Cin / 8) * g.H * g.W * 32 >= (1ll << 32)) return false;
+    lds = ((size_t)2 * W43_BUF + 2 * g.pfl) * sizeof(float);
+    return lds <= 160 * 1024 && (size_t)12 * 32 * W43_XT <= (size_t)2 * W43_BUF;
+}
+
+bool wino43_supported(const ConvShape &c, bool pool) {
+    if (c.Cin % 8 != 0 || c.Cout % 64 != 0) return false;
+    if (pool && (c.H < 2 || c.W < 2)) return false;
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    switch (w43_ttw(c, pool)) {
+        case 8: return w43_geometry<8>(c, pool, g, lds, blocks);
+        case 4: return w43_geometry<4>(c, pool, g, lds, blocks);
+        case 2: return w43_geometry<2>(c, pool, g, lds, blocks);
+        default: return w43_geometry<1>(c, pool, g, lds, blocks);
+    }
+}
+
+template <int TTW, bool POOL>
+static int launch_w43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                      long long *trace, hipStream_t st) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
+    g.trace = trace;
+    auto kern = trace ? k_conv_wino43<TTW, POOL, true> : k_conv_wino43<TTW, POOL, false>;
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+int launch_wino43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                  bool pool, long long *trace, hipStream_t st) {
+    switch (w43_ttw(c, pool)) {
+        case 8: return pool ? launch_w43<8, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<8, false>(in, upk, scale, shift, out, c, trace, st);
+        case 4: return pool ? launch_w43<4, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<4, false>(in, upk, scale, shift, out, c, trace, st);
+        case 2: return pool ? launch_w43<2, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<2, false>(in, upk, scale, shift, out, c, trace, st);
+        default: return pool ? launch_w43<1, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<1, false>(in, upk, scale, shift, out, c, trace, st);
+    }
+}
+
+int pack_wino43(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st) {
+    const int64_t n = (int64_t)cout * cin;
+    hipLaunchKernelGGL(k_pack_wino43, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, packed);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+}  // namespace stito

@@ -12,12 +12,12 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 import torch  # noqa: F401  (must be imported first: brings in the process' libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libstito_hip.so")
+LIB_PATH = os.environ.get("STITO_LIB_PATH") or os.path.join(_HERE, "_lib", "libstito_hip.so")  # env: A/B builds of the library
 
 FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB = range(7)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
 FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
-CONV_DIRECT, CONV_WINOGRAD = 0, 1
+CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4 = 0, 1, 2
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 
@@ -43,7 +43,8 @@ class Frontend(Structure):
 class Cnn14Weights(Structure):
     _fields_ = [
         ("embed_dim", c_int32), ("n_mels", c_int32), ("channels", c_int32 * 7), ("reserved", c_int32),
-        ("conv_w_dev", c_void_p * 12), ("conv_wino_dev", c_void_p * 12), ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
+        ("conv_w_dev", c_void_p * 12), ("conv_wino_dev", c_void_p * 12), ("conv_wino_algo", c_int32 * 12),
+        ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
         ("fc_mid_wt_dev", c_void_p), ("fc_mid_b_dev", c_void_p),
         ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
     ]

@@ -117,9 +117,9 @@ class Cnn14(nn.Module):
         self._packed_key = None
         self._ws = None
         self.max_streams_per_pass = int(os.environ.get("STITO_MAX_STREAMS", "512"))
-        # 3x3 conv algorithm of the trunk: "winograd" (F(2x2,3x3), default) or "direct"
-        self.conv_algo = {"direct": _hip.CONV_DIRECT, "winograd": _hip.CONV_WINOGRAD}[
-            os.environ.get("STITO_CONV_ALGO", "winograd")]
+        # 3x3 conv algorithm of the trunk: "winograd_f4" (F(4x4,3x3), default), "winograd" (F(2x2,3x3)) or "direct"
+        self.conv_algo = {"direct": _hip.CONV_DIRECT, "winograd": _hip.CONV_WINOGRAD, "winograd_f4": _hip.CONV_WINOGRAD_F4}[
+            os.environ.get("STITO_CONV_ALGO", "winograd_f4")]
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -163,10 +163,11 @@ class Cnn14(nn.Module):
                 cout, cin = w.shape[0], w.shape[1]
                 packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, _hip.CONV_DIRECT), dtype=torch.float32, device=dev)
                 _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.CONV_DIRECT, _hip.ptr(packed), st))
-                if self.conv_algo == _hip.CONV_WINOGRAD and cin % 8 == 0 and cout % 64 == 0:
-                    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, _hip.CONV_WINOGRAD), dtype=torch.float32, device=dev)
-                    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.CONV_WINOGRAD, _hip.ptr(upk), st))
+                if self.conv_algo != _hip.CONV_DIRECT and cin % 8 == 0 and cout % 64 == 0:
+                    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, self.conv_algo), dtype=torch.float32, device=dev)
+                    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, self.conv_algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()
+                    W.conv_wino_algo[2 * b + j] = self.conv_algo
                     keep.append(upk)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)

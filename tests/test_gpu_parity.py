@@ -292,10 +292,13 @@ CONV_CASES = [  # (n, H, W, cin, cout, pool)
     (2, 33, 128, 1, 64, 0), (2, 33, 128, 64, 64, 1), (3, 16, 64, 64, 128, 0), (2, 17, 32, 128, 128, 1),
     (2, 9, 16, 256, 256, 1), (3, 4, 8, 128, 256, 0), (5, 2, 4, 256, 128, 0), (3, 14, 4, 64, 128, 0), (1, 7, 4, 64, 64, 0),
     (2, 29, 8, 64, 128, 1),
+    # wide layers (no per-layer case had cin > 256) and shapes that straddle streams / partial tiles
+    (2, 14, 4, 512, 512, 0), (1, 14, 4, 1024, 2048, 0), (1, 14, 4, 2048, 2048, 0), (2, 29, 8, 512, 1024, 0),
+    (3, 58, 16, 256, 512, 1), (2, 234, 64, 64, 128, 1), (2, 30, 10, 64, 64, 1), (4, 5, 5, 64, 64, 0), (7, 14, 4, 64, 64, 0),
 ]
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
 def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     from st_ito import _hip
@@ -319,7 +322,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     xd = blocked(x).to(dev)
     wd = w.contiguous().to(dev)
     if not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
-        assert algo == 1, "the direct kernel must cover every Cnn14-shaped layer"
+        assert algo != 0, "the direct kernel must cover every Cnn14-shaped layer"
         pytest.skip("shape not covered by the Winograd kernel (direct is used instead)")
     packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), device=dev)
     st = _hip.stream_ptr()
@@ -332,7 +335,10 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     assert not torch.isnan(got).any(), "unwritten outputs"
     err = (got - ref).abs().max().item()
     print(f"conv algo {algo} {n}x{H}x{W} {cin}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
-    assert err < 2e-5 * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
+    # F(4x4,3x3): random SIGNED inputs are the worst case for the cancellation in its output transform (3.3e-5 of the
+    # maximum at cin = 2048); on real trunk activations it is as accurate as the direct kernel (tools/trunk_accuracy.py)
+    tol = 5e-5 if algo == 2 else 2e-5
+    assert err < tol * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
 
 
 @pytest.mark.parametrize("norm", ["minmax", "batchnorm", "none"])

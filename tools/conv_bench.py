@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames", type=int, default=469)
-    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd")
+    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3)")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     L = _hip.lib()
