@@ -12,13 +12,17 @@ not available offline).  For N > 1 every GPU evaluates its own 256 candidates of
 population (weak scaling, configs[3] shape) and the fitness scalars are all-gathered over RCCL.
 
 The JSON line also carries
-  roofline     : the f32-MFMA conv kernel family (k_conv_wino / k_conv3x3): algorithmic FLOPs per
-                 launch / average launch duration, measured with HIP events recorded by the library
-                 on its launch stream around every conv launch of the TIMED steps
-                 (stito_conv_timing_enable/read), against the 157.3 TFLOP/s f32-MFMA peak; traffic =
-                 HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/);
-  cpu_baseline : the CPU oracle (port of the reference path) timed on this box's host cores on
-                 a bounded sample of the same workload (rank 0, N = 1 only).
+  roofline     : the f32-MFMA conv kernel family (k_conv_wino43 / k_conv_wino8 / k_conv3x3, the 11 MFMA conv launches of
+                 a trunk pass = ~75 % of the step).  achieved = FLOPs of the MFMA instructions those launches actually
+                 ISSUE (tile padding included; stito_conv3x3_issued_flops) / their summed duration, measured with HIP
+                 events the library records on its launch stream around every such launch of the TIMED steps
+                 (stito_conv_timing_enable/read); peak = 157.3 TFLOP/s (dense f32 MFMA); frac = achieved / peak <= 1.
+                 algorithmic_tflops counts the direct-convolution FLOPs 2*9*cin*cout*H*W of the same launches (the
+                 Winograd kernels need 2.25 / 4 of them), so it may exceed the peak.  traffic = HBM bytes per launch
+                 from the committed rocprofv3 PMC passes, used only if they were taken on THIS kernel source (hash check);
+  cpu_baseline : the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample of the
+                 same workload (rank 0, N = 1 only): mode A = the reference's serial loop (parallel=False), and
+                 parallel_pool16 = its mp.Pool(16) render re-created per evaluate call (style_transfer.py:499-502).
 """
 import argparse
 import ctypes
@@ -68,22 +72,40 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round1_p_conv_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round2_conv_pmc_traffic.json")
+
+
+def kernel_source_hash():
+    """sha256 over the conv kernels' sources: a PMC measurement is only quoted for the source it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "st-ito_amd", "csrc")
+    for name in ("cnn14.hip", "conv_wino43.hip", "conv_layout.h", "common.h"):
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic_per_launch(n_streams):
-    """HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the
-    same 11 launches at the same stream count), or None if no committed measurement matches."""
+    """HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the same 11 launches
+    at the same stream count).  -> (bytes or None, note).  Refused when the committed file was taken on other sources."""
     try:
         d = json.load(open(PMC_TRAFFIC_JSON))
     except OSError:
-        return None
-    return float(d["traffic_bytes_per_launch"]) if d.get("n_streams") == n_streams else None
+        return None, "no committed PMC file"
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{os.path.basename(PMC_TRAFFIC_JSON)} was taken on kernel sources {d.get('kernel_source_hash')}, this tree is {kernel_source_hash()}"
+    if d.get("n_streams") != n_streams:
+        return None, f"PMC file is for {d.get('n_streams')} streams"
+    return float(d["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(PMC_TRAFFIC_JSON)}"
+
+
+ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)"}
 
 
 def conv_layer_times(model, n_streams, T, reps=3):
-    """Per-layer table (informational): every conv launch of the trunk timed on its own with HIP
-    events on the launch stream (torch's current stream is the stream the C ABI launches on)."""
+    """Per-layer table (informational): every conv launch of the trunk timed on its own with HIP events on the launch
+    stream (torch's current stream is the stream the C ABI launches on).  -> (layers, issued MFMA FLOPs of the 11 MFMA
+    launches of one trunk pass at n_streams)."""
     from st_ito import _hip
     L = _hip.lib()
     W, FE, _ = model._ensure()
@@ -93,14 +115,15 @@ def conv_layer_times(model, n_streams, T, reps=3):
     x = torch.randn((n_streams, T, 128), device=dev).clamp_(-1, 1)
     layers = []
     cur = x
-    tot_flops = tot_ms = 0.0
-    mfma_flops = mfma_ms = 0.0
+    issued_total = 0.0
     for i, r in enumerate(rows):
         Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
         out = torch.empty((n_streams, r["cout"] // 8, Ho, Wo, 8), device=dev)
-        wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 1)
+        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2) else 1
+        wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], walgo)
+        algo = walgo if wino else 0
         args = (_hip.ptr(cur), W.conv_wino_dev[i] if wino else W.conv_w_dev[i], W.bn_scale_dev[i], W.bn_shift_dev[i],
-                _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 1 if wino else 0, st)
+                _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo, st)
         _hip.check(L.stito_conv3x3_bn_relu(*args))  # warm
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in ev:
@@ -110,19 +133,40 @@ def conv_layer_times(model, n_streams, T, reps=3):
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         fl = r["flops"] * n_streams
-        layers.append(dict(layer=f"conv_block{i // 2 + 1}.conv{i % 2 + 1}", algo="winograd" if wino else "direct", H=r["H"], W=r["W"], cin=r["cin"], cout=r["cout"],
-                           ms=round(ms, 4), tflops=round(fl / ms / 1e9, 2)))
-        tot_flops += fl; tot_ms += ms
-        if r["cin"] % 8 == 0:
-            mfma_flops += fl; mfma_ms += ms
+        issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
+        issued_total += issued
+        row = dict(layer=f"conv_block{i // 2 + 1}.conv{i % 2 + 1}", algo=ALGO_NAMES[algo] if r["cin"] % 8 == 0 else "direct (VALU, cin = 1)",
+                   H=r["H"], W=r["W"], cin=r["cin"], cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2))
+        if issued:
+            row["mfma_issued_tflops"] = round(issued / ms / 1e9, 2)
+            row["mfma_frac"] = round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)
+        layers.append(row)
         cur = out
-    return layers, mfma_flops / mfma_ms / 1e9
+    return layers, issued_total
+
+
+def _pool_render(args):
+    """mp.Pool worker of CPU mode B: process_audio of one candidate (style_transfer.py:499-502)."""
+    xnp, w, kinds = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import st_ito_oracle as O
+    global _POOL_PLUGINS
+    try:
+        _POOL_PLUGINS
+    except NameError:
+        _POOL_PLUGINS = {}
+    key = tuple(kinds)
+    if key not in _POOL_PLUGINS:
+        _POOL_PLUGINS[key] = O.make_plugins(list(kinds))
+    return O.process_audio(xnp, w, SR, _POOL_PLUGINS[key])
 
 
 def cpu_baseline(n_samples, kinds, budget_s=12.0):
-    """The CPU oracle (a port of the reference path: serial per-candidate render + torch-CPU
-    Cnn14) on a bounded sample: candidates are evaluated one at a time until ~budget_s of CPU
-    work has been spent."""
+    """The CPU oracle (a port of the reference path) on a bounded sample of the bench workload.
+    Mode A (value): the reference's serial loop, parallel=False (style_transfer.py:504-521): candidates evaluated one
+    at a time (C effects + torch-CPU Cnn14) until ~budget_s of CPU work has been spent.
+    Mode B (parallel_pool16): parallel=True (499-502): multiprocessing.Pool(16) created and torn down inside every
+    evaluate call, the candidates rendered by the pool, one batched Cnn14 forward; 32 candidates per call, 2 calls."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import st_ito_oracle as O
     op = O.make_plugins(kinds)
@@ -139,9 +183,27 @@ def cpu_baseline(n_samples, kinds, budget_s=12.0):
         O.evaluate([W[n + 1]], x, SR, op, te, om)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "candidate-evals/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n} candidates x 10 s stereo, same chain, serial oracle.evaluate "
-            f"(C effects + torch-CPU Cnn14, {torch.get_num_threads()} threads of {os.cpu_count()} cpus), {dt:.1f} s"}
+    out = {"value": round(n / dt, 4), "unit": "candidate-evals/s", "cores": torch.get_num_threads(),
+           "kind": "port", "sample": f"mode A (serial, parallel=False): {n} candidates x 10 s stereo, same chain, oracle.evaluate "
+           f"one candidate at a time (C effects + torch-CPU Cnn14, {torch.get_num_threads()} threads of {os.cpu_count()} cpus), {dt:.1f} s"}
+    try:
+        import multiprocessing as mp
+        P_b, calls = 32, 2
+        xnp = x[0].numpy()
+        t0 = time.perf_counter()
+        for c in range(calls):
+            with mp.get_context("fork").Pool(processes=16) as pool:   # re-created per evaluate call, like the reference
+                audios = pool.map(_pool_render, [(xnp, W[(c * P_b + i) % len(W)], tuple(kinds)) for i in range(P_b)])
+            batch = torch.stack([torch.from_numpy(a) for a in audios], 0)
+            emb = O.get_param_embeds(batch, om, SR)
+            _ = [(-torch.cosine_similarity(emb[k], te[k], dim=-1)) for k in emb]
+        dtb = time.perf_counter() - t0
+        out["parallel_pool16"] = {"value": round(P_b * calls / dtb, 4), "unit": "candidate-evals/s", "cores": 16,
+                                  "sample": f"mode B (parallel=True): {calls} evaluate calls x {P_b} candidates, mp.Pool(16) per call + one "
+                                            f"batched torch-CPU Cnn14 forward ({torch.get_num_threads()} threads), {dtb:.1f} s"}
+    except Exception as e:  # a box without fork / enough memory: mode A stands alone
+        out["parallel_pool16"] = {"value": None, "note": f"not measured: {e}"}
+    return out
 
 
 def main():
@@ -245,28 +307,32 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             T = n // 1024 + 1
-            # algorithmic conv FLOPs (direct-convolution count 2*9*cin*cout*H*W) of one step on this rank
+            streams_per_launch = min(2 * args.pop_per_gpu, model.max_streams_per_pass)
+            passes_per_step = (2 * args.pop_per_gpu + streams_per_launch - 1) // streams_per_launch
+            layers, issued_pass = conv_layer_times(model, streams_per_launch, T)
+            # algorithmic conv FLOPs (direct-convolution count 2*9*cin*cout*H*W) of the MFMA launches of one step on this rank
             fl_step = sum(r["flops"] for r in conv_layer_table(T) if r["cin"] % 8 == 0) * 2 * args.pop_per_gpu
             n_l = max(conv_launches.value, 1)
-            achieved = fl_step * args.steps / conv_ms.value / 1e9  # TFLOP/s over the timed region's conv launches
-            streams_per_launch = min(2 * args.pop_per_gpu, model.max_streams_per_pass)
-            layers, _ = conv_layer_times(model, streams_per_launch, T)
+            issued_timed = issued_pass * passes_per_step * args.steps      # FLOPs the timed launches issued (full passes)
+            achieved = issued_timed / conv_ms.value / 1e9                  # TFLOP/s of MFMA work over the timed region's conv launches
+            traffic, traffic_note = pmc_traffic_per_launch(streams_per_launch)
+            algos = sorted({l["algo"] for l in layers if l["cin"] % 8 == 0})
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "k_conv_wino<*> / k_conv3x3<*>: the 11 f32-MFMA 3x3-conv launches of a trunk pass. achieved counts "
-                          "direct-convolution FLOPs (2*9*cin*cout*H*W); the Winograd F(2x2,3x3) kernel issues 16/36 of those "
-                          "MACs, so it can exceed 1.0 of the MFMA peak",
+                "kernel": "the 11 f32-MFMA 3x3-conv launches of a trunk pass (" + ", ".join(algos) + "; v_mfma_f32_32x32x2_f32). achieved = "
+                          "FLOPs of the MFMA instructions actually issued (tile padding included) / launch time; algorithmic_tflops "
+                          "counts direct-convolution FLOPs (2*9*cin*cout*H*W) of the same launches and may exceed the peak",
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                # the MFMA work actually issued (Winograd: 16 of the 36 counted MACs per 2x2 outputs) against the same peak
-                "mfma_issued_frac": round(achieved * (16.0 / 36.0 if all(l["algo"] == "winograd" for l in layers if l["cin"] % 8 == 0) else 1.0)
-                                          / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic_per_launch(streams_per_launch), "traffic_unit": "HBM bytes per launch (PMC, "
-                "profiles/round1_p_conv_pmc_traffic.json)",
-                "flops_per_launch": fl_step * args.steps / n_l, "avg_launch_ms": round(conv_ms.value / n_l, 4),
+                "algorithmic_tflops": round(fl_step * args.steps / conv_ms.value / 1e9, 2),
+                "algorithmic_frac": round(fl_step * args.steps / conv_ms.value / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
+                "flops_per_launch": issued_timed / n_l, "algorithmic_flops_per_launch": fl_step * args.steps / n_l,
+                "avg_launch_ms": round(conv_ms.value / n_l, 4),
                 "launches_timed": conv_launches.value, "n_streams": streams_per_launch,
-                # whole path (DSP + front end + trunk + host) against the same peak
-                "end_to_end_frac": round(fl_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "conv_share_of_step": round(conv_ms.value / (dt * 1e3), 4),
+                # whole path (DSP + front end + trunk + host) in direct-convolution FLOPs against the same peak
+                "end_to_end_algorithmic_frac": round(fl_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 "layers": layers,
             }
         if world == 1 and not args.no_cpu_baseline:

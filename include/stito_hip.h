@@ -227,6 +227,9 @@ int stito_debug_wino_trace(long long *buf_dev);
  * GPU, like stito_last_error): enable and read from the thread that calls stito_cnn14_forward. */
 int stito_conv_timing_enable(int on);
 int stito_conv_timing_read(double *total_ms, int *n_launches);
+/* FLOPs of the MFMA instructions one launch of this shape issues with `algo`, tile padding included (0 if unsupported or
+ * cin % 8 != 0).  Measurement aid: bench.py divides it by the launch time for `roofline.achieved`. */
+double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int cout, int pool, int algo);
 /* 1 if stito_conv3x3_bn_relu can run this shape with `algo`, else 0. */
 int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,

@@ -1463,6 +1463,29 @@ extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, i
     return (cin % 8 == 0 && cout % 64 == 0) ? 1 : 0;  // channel-blocked activations: 8 channels per block
 }
 
+// FLOPs of the MFMA instructions one launch issues, tile padding included (bench.py "roofline": the hardware-side
+// numerator, <= peak by construction; the algorithmic count 2*9*cin*cout*H*W is larger for the Winograd kernels)
+extern "C" double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int cout, int pool, int algo) {
+    if (!stito_conv3x3_supported(n, H, W, cin, cout, pool, algo) || cin % 8 != 0) return 0.0;
+    ConvShape c{n, H, W, cin, cout};
+    if (algo == STITO_CONV_WINOGRAD_F4) return wino43_issued_flops(c, pool != 0);
+    if (algo == STITO_CONV_WINOGRAD) {
+        WinoGeom g;
+        size_t lds;
+        int64_t blocks = 0;
+        const int ttw = wino_ttw(c, pool != 0);
+        const bool ok = pool ? (ttw == 8 ? wino_geometry<8, true>(c, g, lds, blocks) : ttw == 4 ? wino_geometry<4, true>(c, g, lds, blocks) : wino_geometry<2, true>(c, g, lds, blocks))
+                             : (ttw == 8 ? wino_geometry<8, false>(c, g, lds, blocks) : ttw == 4 ? wino_geometry<4, false>(c, g, lds, blocks) : wino_geometry<2, false>(c, g, lds, blocks));
+        return ok ? 2.0 * (double)blocks * 64.0 * 64.0 * 16.0 * cin : 0.0;
+    }
+    // direct: launch_conv's tiling -- (BM x BN) = (128 x 128) when cout % 128 == 0, else (256 x 64); TW by map width
+    const int BM = cout % 128 == 0 ? 128 : 256, BN = cout % 128 == 0 ? 128 : 64;
+    const int TW = W >= 16 ? 16 : (W >= 8 ? 8 : 4), TH = BM / TW;
+    const int Heff = pool ? 2 * (H / 2) : H;
+    const int64_t n_row_tiles = ((int64_t)n * Heff + TH - 1) / TH, n_col_tiles = (W + TW - 1) / TW;
+    return 2.0 * (double)(n_row_tiles * n_col_tiles) * (cout / BN) * BM * BN * 9.0 * cin;
+}
+
 extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                                      const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                                      int pool, int algo, void *stream) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ void glds16_m0(const float *sbase, unsigned voff, uns
 
 // conv_wino43.hip
 bool wino43_supported(const ConvShape &c, bool pool);
+double wino43_issued_flops(const ConvShape &c, bool pool);
 int launch_wino43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                   bool pool, long long *trace, hipStream_t st);
 int pack_wino43(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);

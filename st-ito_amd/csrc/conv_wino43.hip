@@ -18,7 +18,7 @@
 // share of the production into its own MFMA stream:
 //   MFMA   wave (g = w / 2, nh = w % 2): positions 9g .. 9g+8 x 32 tiles x channel half nh: 9 MFMA blocks = 144
 //          accumulator VGPRs, 18 MFMAs per chunk, operands of the next three blocks read while three run;
-//   U      [cin/4][36][cout][4] pre-transformed weights: 36 scalar-addressed 1 KB LDS-DMA copies per chunk, 4-5 per wave;
+//   U      [cin/4][36][pair][cout][2] pre-transformed weights: 36 scalar-addressed 1 KB LDS-DMA copies per chunk, 4-5 per wave;
 //   patch  raw halo patch (4 channels = 16 B per pixel): LDS-DMA too, lanes without a pixel masked off through EXEC (the
 //          two patch buffers are zero-filled once = the padding), issued first thing in the period BEFORE the one that
 //          transforms it;
@@ -52,9 +52,35 @@ struct Wino43Geom {
     int n_col_blocks;
     int Ho, Wo;        // output map (pooled when POOL)
     int PR;            // halo patch rows
-    int zoff;          // float offset of the zero pixels inside a patch buffer
-    int pfl;           // floats per patch buffer
     long long *trace;  // TRACE instantiation only
+};
+
+// LDS layout of a halo patch buffer (16-byte pixels = the 4 channels of the chunk).  A transform read fetches, for 16 tiles
+// at a time, the pixel (4 tr + k, 4 tc + l) of each tile: with the pixels stored row by row those addresses are 64 bytes
+// apart along a tile row, so 32 lanes fall on 4..8 bank groups (measured: the LDS, not the MFMA pipe, set the period).
+// The buffer is therefore split into 16 phase planes (pr % 4, pc % 4); inside a plane the pixel (pr / 4, pc / 4) of the 16
+// tiles of a read group are consecutive (or 8 / 4 / 2 apart) -- every LDS-DMA lane can fetch any pixel, so the permutation
+// is free:   slot(pr, pc) = ((pr % 4) * 4 + pc % 4) * PLANE + pos(pr / 4, pc / 4),
+//   TTW = 8: pos = (pr/4) * 9 + pc/4 (one 2-way conflict in 16 tiles);  TTW <= 4: pos = (pc/4) * RH + pr/4 with RH = 12, 24, 34
+//   (RH = 16 / TTW mod 16, so the TTW tile columns of a group interleave without collision).
+template <int TTW>
+struct W43Patch {
+    static constexpr bool ROWMAJOR = TTW == 8;
+    static constexpr int CW = 9;                                                // TTW == 8: positions per plane row
+    static constexpr int NR = 6;                                                // TTW == 8: plane rows (PR <= 24)
+    static constexpr int RH = TTW == 4 ? 12 : TTW == 2 ? 24 : 34;              // TTW <= 4: positions per plane column
+    static constexpr int PLANE = ROWMAJOR ? NR * CW : (TTW + 1) * RH;          // slots per plane
+    static constexpr int SLOTS = 16 * PLANE;
+    static constexpr int NPL = (SLOTS + W43_THREADS - 1) / W43_THREADS;        // LDS-DMA instructions per wave per chunk
+    static constexpr int PFL = SLOTS * W43_K;                                   // floats per patch buffer
+    static constexpr int MAXPR4 = ROWMAJOR ? NR : RH;                           // (PR + 3) / 4 must not exceed this
+    __host__ __device__ static constexpr int cstep() { return ROWMAJOR ? 1 : RH; }  // slots per tile column
+    __device__ static int slot(int pr, int pc) {
+        const int pos = ROWMAJOR ? (pr >> 2) * CW + (pc >> 2) : (pc >> 2) * RH + (pr >> 2);
+        return ((pr & 3) * 4 + (pc & 3)) * PLANE + pos;
+    }
+    // float offset of column l (0..5) of a tile relative to its column 0
+    __host__ __device__ static constexpr int coloff(int l) { return ((l & 3) * PLANE + (l >> 2) * cstep()) * W43_K; }
 };
 
 // -a as fma operand helper: (T3 - T1) etc. stay packed
@@ -85,7 +111,9 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
                                                               Wino43Geom g) {
     constexpr int TTH = 32 / TTW;
     constexpr int PWC = 4 * TTW + 2;  // patch columns
-    constexpr int NPL = 2;            // float4 of patch per thread per chunk (PR * PWC <= 1024, host check)
+    using PL = W43Patch<TTW>;
+    constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
+    constexpr int PFL = PL::PFL;      // floats per patch buffer
     constexpr int BUF = W43_BUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -110,28 +138,36 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     // ---- MFMA role ----------------------------------------------------------------------------------------
     const int half = lane >> 5, l31 = lane & 31;
     const int nh = wv & 1, pg = wv >> 1;
-    const int a_off = W43_U + (9 * pg) * 32 * W43_K + l31 * W43_K + half * 2;  // V[p][tile][4], this lane's channel pair
-    const int b_off = (9 * pg) * 64 * W43_K + (nh * 32 + l31) * W43_K + half * 2;  // U[p][cout][4]
+    // operands per channel pair (= lane half), 8 bytes per row so that a half-wave reads 256 contiguous bytes:
+    // V[p][cp][(tile + 16 cp) % 32][2] (the rotation keeps the transform's stores of both pairs on disjoint banks), U[p][cp][cout][2]
+    const int a_off = W43_U + (9 * pg) * 32 * W43_K + half * 64 + ((l31 + 16 * half) & 31) * 2;
+    const int b_off = (9 * pg) * 64 * W43_K + half * 128 + (nh * 32 + l31) * 2;
 
-    // ---- transform item: (row i of B^T d B, tile, channel pair); 48 items per wave so that all 8 waves carry the same load ----
-    int roff[4];   // float offsets (inside a patch buffer) of the four input rows the lane's row i combines
-    f32x2 cab, ccd;  // their coefficients (a, b), (c, d)
+    // ---- transform item: (row i of B^T d B, tile, channel pair).  Twelve units (row i, tile half) of 16 tiles x 2 pairs:
+    // lanes 0..31 of wave w carry unit w, lanes 32..47 a quarter of unit 8 + w/2, lanes 48..63 mirror lanes 32..47 (same reads,
+    // same values, same addresses written: no divergent branch in the loop, and every wave carries the same 48 items).
+    int roff[4];     // float offsets (inside a patch buffer) of the four input rows the lane's row i combines, at tile column 0
+    f32x2 cab, ccd;  // their coefficients (a, b), (c, d); 0 for rows outside the map / stream
     int vdst;
     {
-        // lanes 48..63 mirror lanes 32..47 (same reads, same values, same addresses written): no divergent branch in the loop
-        const int it = wv * 48 + (lane < 48 ? lane : lane - 16);
-        const int cp = it & 1, tile = (it >> 1) & 31, ti = it >> 6;
+        int ti, tile, cp;
+        if (lane < 32) {
+            ti = wv >> 1; tile = (wv & 1) * 16 + (lane & 15); cp = lane >> 4;
+        } else {
+            const int u = 8 + (wv >> 1), l = lane & 15;
+            ti = u >> 1; tile = (u & 1) * 16 + (wv & 1) * 8 + (l & 7); cp = l >> 3;
+        }
         // B^T (Lavin & Gray):  row 0: 4 d0 - 5 d2 + d4        row 1: -4 d1 - 4 d2 + d3 + d4   row 2: 4 d1 - 4 d2 - d3 + d4
         //                      row 3: -2 d1 - d2 + 2 d3 + d4  row 4: 2 d1 - d2 - 2 d3 + d4     row 5: 4 d1 - 5 d3 + d5
         int kr[4];
         float cf[4];
         switch (ti) {
-            case 0: kr[0] = 0; kr[1] = 2; kr[2] = 4; kr[3] = -1; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
+            case 0: kr[0] = 0; kr[1] = 2; kr[2] = 4; kr[3] = 4; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
             case 1: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -4.f; cf[1] = -4.f; cf[2] = 1.f; cf[3] = 1.f; break;
             case 2: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 4.f; cf[1] = -4.f; cf[2] = -1.f; cf[3] = 1.f; break;
             case 3: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -2.f; cf[1] = -1.f; cf[2] = 2.f; cf[3] = 1.f; break;
             case 4: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 2.f; cf[1] = -1.f; cf[2] = -2.f; cf[3] = 1.f; break;
-            default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = -1; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
+            default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = 5; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
         }
         const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
         const int s_ = vtr / g.TR, tr = vtr % g.TR;
@@ -139,34 +175,40 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int hh = 4 * tr - 1 + kr[x];
-            const bool ok = kr[x] >= 0 && vtr < g.VTR && hh >= 0 && hh < g.H;  // rows outside the map / stream: the zero pixels
-            roff[x] = (ok ? ((pc0 + kr[x]) * PWC + 4 * tcl) * W43_K : g.zoff) + cp * 2;
+            // rows outside the map / stream contribute nothing: coefficient 0 on a row that exists in the patch (finite data)
+            const bool ok = vtr < g.VTR && hh >= 0 && hh < g.H;
+            if (!ok) cf[x] = 0.f;
+            const int prow = ok ? pc0 + kr[x] : 0;
+            roff[x] = PL::slot(prow, 4 * tcl) * W43_K + cp * 2;
         }
         cab = (f32x2){cf[0], cf[1]};
         ccd = (f32x2){cf[2], cf[3]};
-        vdst = W43_U + (ti * 6) * 32 * W43_K + tile * W43_K + cp * 2;  // V[6 ti + j][tile][cp]
+        vdst = W43_U + (ti * 6) * 32 * W43_K + cp * 64 + ((tile + 16 * cp) & 31) * 2;  // V[6 ti + j][cp][(tile + 16 cp) % 32]
     }
 
     // ---- U slab copies: position ii = wv + 8 j, 1 KB each --------------------------------------------------
-    const float *u_base = upk + (int64_t)n0 * W43_K;
+    // packed weights [cin/4][36][2 pairs][cout][2]: lanes 0..31 fetch this block's 64 channels of pair 0, lanes 32..63 of pair 1
+    const float *u_base = upk + (int64_t)n0 * 2;
     const int64_t u_pos_stride = (int64_t)g.Cout * W43_K, u_chunk_stride = 36 * u_pos_stride;  // floats
+    const unsigned u_voff = (unsigned)((lane & 31) * 16 + (lane >> 5) * g.Cout * 8);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
 
-    // ---- halo patch staging: pixel q = tid + 512 j, 16 B (4 channels) each, by LDS-DMA ------------------------------
+    // ---- halo patch staging by LDS-DMA: slot q = tid + 512 j of the permuted layout (W43Patch) holds pixel (pr, pc) ------
     const int s_first = (iv_lo < 0 ? 0 : iv_lo) / g.H;
     const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W);
     const int64_t plane8 = (int64_t)g.H * g.W * 8;  // floats per 8-channel plane of one stream
     unsigned p_off[NPL];                             // per-lane byte offset from the chunk's base
     uint64_t p_mask[NPL];                            // lanes of this wave that have a pixel (wave-uniform)
     {
-        const int npix = g.PR * PWC;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int q = tid + W43_THREADS * j;
-            const int pr = q / PWC, pc = q % PWC;
+            const int plane = q / PL::PLANE, pos = q % PL::PLANE;
+            const int pr4 = PL::ROWMAJOR ? pos / PL::CW : pos % PL::RH, pc4 = PL::ROWMAJOR ? pos % PL::CW : pos / PL::RH;
+            const int pr = 4 * pr4 + (plane >> 2), pc = 4 * pc4 + (plane & 3);
             const int iv = iv_lo + pr;
             const int w = 4 * tc0 - 1 + pc;
-            const bool ok = q < npix && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
+            const bool ok = q < PL::SLOTS && pr < g.PR && pc < PWC && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
             const int s_ = ok ? iv / g.H : s_first, h_ = ok ? iv % g.H : 0, w_ = ok ? w : 0;
             p_off[j] = (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
             p_mask[j] = __builtin_amdgcn_ballot_w64(ok);
@@ -177,7 +219,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 #define W43_COPY_U1(CH, BOFF, J_) /* callers guarantee CH < n_chunks */                                  \
     {                                                                                                    \
         const int ii = wv + 8 * (J_) < 36 ? wv + 8 * (J_) : wv + 8 * (J_) - 8;                           \
-        glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + ii * u_pos_stride, (unsigned)lane * 16u,     \
+        glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + ii * u_pos_stride, u_voff,                   \
                   lds0 + (unsigned)((BOFF) + ii * 64 * W43_K) * 4u);                                     \
     }
 // patch(CH) -> patch buffer PB (0, 1): two masked LDS-DMA instructions per wave (pixels wv*64 + 512 j + lane)
@@ -190,7 +232,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"  \
                          "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                          \
                          : "=&s"(keep_)                                                                  \
-                         : "v"(p_off[j]), "s"(pb_), "s"(lds_patch + (unsigned)((PB) * g.pfl + (wv * 64 + W43_THREADS * j) * W43_K) * 4u), \
+                         : "v"(p_off[j]), "s"(pb_), "s"(lds_patch + (unsigned)((PB) * PFL + (wv * 64 + W43_THREADS * j) * W43_K) * 4u), \
                            "s"(p_mask[j])                                                                \
                          : "memory");                                                                    \
         }                                                                                                \
@@ -198,10 +240,10 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 // transform: row combination of column L (4 reads), T[L] = ((ca da + cb db) + cc dc) + cd dd
 #define W43_T_RD(PBUF, L, R)                                                                            \
     {                                                                                                   \
-        R[0] = *(const f32x2 *)((PBUF) + roff[0] + (L) * W43_K);                                         \
-        R[1] = *(const f32x2 *)((PBUF) + roff[1] + (L) * W43_K);                                         \
-        R[2] = *(const f32x2 *)((PBUF) + roff[2] + (L) * W43_K);                                         \
-        R[3] = *(const f32x2 *)((PBUF) + roff[3] + (L) * W43_K);                                         \
+        R[0] = *(const f32x2 *)((PBUF) + roff[0] + PL::coloff(L));                                       \
+        R[1] = *(const f32x2 *)((PBUF) + roff[1] + PL::coloff(L));                                       \
+        R[2] = *(const f32x2 *)((PBUF) + roff[2] + PL::coloff(L));                                       \
+        R[3] = *(const f32x2 *)((PBUF) + roff[3] + PL::coloff(L));                                       \
     }
 #define W43_T_ROW(L, R) tT[L] = pk_fma_hi(R[3], ccd, pk_fma_lo(R[2], ccd, pk_fma_hi(R[1], cab, pk_mul_lo(R[0], cab))));
 // column combination (the same B^T along the columns) and stores: V[6 i + j] for j = 0..5
@@ -245,12 +287,19 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     f32x2 tT[6], rX[4], rY[4];
     f32x2 xa[3], xb[3], ya[3], yb[3];
 
-    // ---- prologue: zero the patch buffers (= the padding), then patch(0), patch(1), U(0) by LDS-DMA; V(0) from patch(0) ------
-    for (int i = tid * 4; i < 2 * g.pfl; i += W43_THREADS * 4) *(f32x4 *)(patch0 + i) = (f32x4)(0.0f);
-    W43_BARRIER()  // no copy may land under the zero fill
+    // ---- prologue: patch(0), patch(1), U(0) by LDS-DMA, issued first; meanwhile every thread zeroes the slots of both patch
+    // buffers that ITS copy lane never writes (= the padding: no overlap with any copy, so no barrier in between); V(0) from patch(0)
     W43_COPY_P(0, 0)
     W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4)
     W43_COPY_P(1, 1)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int q = tid + W43_THREADS * j;
+        if (q < PL::SLOTS && !((p_mask[j] >> lane) & 1)) {
+            *(f32x4 *)(patch0 + q * W43_K) = (f32x4)(0.0f);
+            *(f32x4 *)(patch0 + PFL + q * W43_K) = (f32x4)(0.0f);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
     W43_T_RD(patch0, 0, rX) W43_T_RD(patch0, 1, rY)
@@ -272,7 +321,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     {                                                                                                   \
         const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
         const float *sb = smem + cur;                                                                    \
-        const float *pb_r = patch0 + ((k + 1) & 1) * g.pfl; /* patch(k+1); patch(k+2) goes where patch(k) was */ \
+        const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
         if (!(FIRST)) {                                                                                  \
             W43_GAP(S0, 2, 0, 0, if (MORE) W43_COPY_P(k + 2, k & 1))                                     \
             W43_GAP(S0, 2, 1, 0, W43_LOAD_OPS(S1, sb, 0) if (MORE) W43_COPY_U1(k + 1, nxt, 0))           \
@@ -417,7 +466,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     W43_STAMP(3)
 }
 
-// Winograd F(4x4,3x3) weight transform U = G g G^T (float64, rounded once), packed [cin/4][36][cout][4].
+// Winograd F(4x4,3x3) weight transform U = G g G^T (float64, rounded once), packed [cin/4][36][channel pair][cout][2].
 // G (Lavin & Gray) = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1].
 __global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ o) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,7 +483,7 @@ __global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, fl
     for (int a = 0; a < 6; ++a)
         for (int b = 0; b < 6; ++b) {
             const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
-            o[(((int64_t)chunk * 36 + a * 6 + b) * Cout + co) * W43_K + c4] = (float)u;
+            o[((((int64_t)chunk * 36 + a * 6 + b) * 2 + (c4 >> 1)) * Cout + co) * 2 + (c4 & 1)] = (float)u;
         }
 }
 
@@ -445,7 +494,7 @@ static int w43_ttw(const ConvShape &c, bool pool) {
 
 template <int TTW>
 static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &lds, int64_t &blocks) {
-    constexpr int TTH = 32 / TTW, PWC = 4 * TTW + 2;
+    constexpr int TTH = 32 / TTW;
     g = Wino43Geom{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
     g.Ho = pool ? c.H / 2 : c.H;
@@ -462,13 +511,10 @@ static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &l
     // patch rows: 4 per tile row + 2 halo, plus the input rows skipped at every stream boundary a block can straddle
     const int skip = g.H - 4 * g.TR > 0 ? g.H - 4 * g.TR : 0;
     g.PR = 4 * TTH + 2 + ((TTH - 1) / g.TR + 1) * skip;
-    const int npix = g.PR * PWC;
-    if (npix > 2 * W43_THREADS) return false;
-    g.zoff = (npix * W43_K + 255) / 256 * 256;
-    g.pfl = g.zoff + 64;  // + 16 zero pixels (a transform row reads 6 of them)
-    // 32-bit byte offsets of the patch loads relative to the block's first stream
+    if ((g.PR + 3) / 4 > W43Patch<TTW>::MAXPR4) return false;  // patch rows the permuted LDS layout has planes for
+    // 32-bit byte offsets of the patch copies relative to the block's first stream
     if ((int64_t)((TTH - 1) / g.TR + 2) * (g.Cin / 8) * g.H * g.W * 32 >= (1ll << 32)) return false;
-    lds = ((size_t)2 * W43_BUF + 2 * g.pfl) * sizeof(float);
+    lds = ((size_t)2 * W43_BUF + 2 * W43Patch<TTW>::PFL) * sizeof(float);
     return lds <= 160 * 1024 && (size_t)12 * 32 * W43_XT <= (size_t)2 * W43_BUF;
 }
 
@@ -484,6 +530,21 @@ bool wino43_supported(const ConvShape &c, bool pool) {
         case 2: return w43_geometry<2>(c, pool, g, lds, blocks);
         default: return w43_geometry<1>(c, pool, g, lds, blocks);
     }
+}
+
+// MFMA work the kernel issues for this shape (tile padding included): workgroups x 32 tiles x 64 channels x 36 positions x cin MACs
+double wino43_issued_flops(const ConvShape &c, bool pool) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks = 0;
+    bool ok;
+    switch (w43_ttw(c, pool)) {
+        case 8: ok = w43_geometry<8>(c, pool, g, lds, blocks); break;
+        case 4: ok = w43_geometry<4>(c, pool, g, lds, blocks); break;
+        case 2: ok = w43_geometry<2>(c, pool, g, lds, blocks); break;
+        default: ok = w43_geometry<1>(c, pool, g, lds, blocks); break;
+    }
+    return ok ? 2.0 * (double)blocks * 32.0 * 64.0 * 36.0 * c.Cin : 0.0;
 }
 
 template <int TTW, bool POOL>

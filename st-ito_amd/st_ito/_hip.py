@@ -82,6 +82,7 @@ SIGNATURES = {
     "stito_debug_wino_trace": (c_int, [c_void_p]),
     "stito_conv_timing_enable": (c_int, [c_int]),
     "stito_conv_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
+    "stito_conv3x3_issued_flops": (c_double, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),
