@@ -1007,28 +1007,29 @@ __global__ __launch_bounds__(WINO8_THREADS) void k_conv_wino8(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_block1.conv1: one input channel (the log-mel image) -> 64 channels.  K = 9: no matrix
-// shape to speak of; direct, output-bandwidth bound (writes S*T*M*64 floats).
-// thread = (pixel slot, 4 output channels); output in the channel-blocked layout (32 B per pixel per block).
+// conv_block1.conv1: one input channel (the log-mel image) -> 64 channels.  K = 9: no matrix shape to speak of; direct,
+// bound by the write of its output (S*T*M*64 floats = 7.9 GB at 512 streams).  thread = (channel octet, pixel): the 8
+// channels of a pixel are the 32 contiguous bytes of the channel-blocked layout, a wave (64 consecutive pixels of one
+// octet) stores 2 KB contiguous -- the first version (thread = 4 channels, the 16 quads of a pixel side by side) scattered
+// every wave store over 32 separate 32-byte pieces and reached 3.2 TB/s.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in, const float *__restrict__ w /*[cout][9]*/,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      float *__restrict__ out, int H, int W, int Cout, int64_t n_pix_per_stream) {
     const int s = blockIdx.y;
-    const int cg = threadIdx.x % (Cout / 4), ps = threadIdx.x / (Cout / 4);
-    const int pix_per_iter = 256 / (Cout / 4);
-    float wr[4][9], sc[4], sh[4];
+    const int oct = blockIdx.z;  // channels 8 oct .. 8 oct + 7
+    float wr[8][9], sc[8], sh[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 8; ++c) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wr[c][t] = w[(cg * 4 + c) * 9 + t];
-        sc[c] = scale[cg * 4 + c];
-        sh[c] = shift[cg * 4 + c];
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(oct * 8 + c) * 9 + t];  // wave-uniform: scalar loads
+        sc[c] = scale[oct * 8 + c];
+        sh[c] = shift[oct * 8 + c];
     }
     const float *ip = in + (int64_t)s * n_pix_per_stream;
-    float *op = out + (int64_t)s * n_pix_per_stream * Cout + (int64_t)(cg >> 1) * n_pix_per_stream * 8 + (cg & 1) * 4;  // NC8HW8
+    float *op = out + (int64_t)s * n_pix_per_stream * Cout + (int64_t)oct * n_pix_per_stream * 8;  // NC8HW8 plane of this octet
     const int npix = (int)n_pix_per_stream;  // H * W of one stream: 32-bit (a 64-bit p / W costs more than the conv)
-    for (int p = blockIdx.x * pix_per_iter + ps; p < npix; p += gridDim.x * pix_per_iter) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
         const int h = p / W, x = p - h * W;
         float v[9];
 #pragma unroll
@@ -1036,17 +1037,19 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
             const int hh = h + t / 3 - 1, ww = x + t % 3 - 1;
             v[t] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? ip[(int64_t)hh * W + ww] : 0.0f;
         }
-        float4 o;
-        float r[4];
+        float r[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 8; ++c) {
             float a = 0.0f;
 #pragma unroll
             for (int t = 0; t < 9; ++t) a = fmaf(v[t], wr[c][t], a);
             r[c] = fmaxf(fmaf(a, sc[c], sh[c]), 0.0f);
         }
-        o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
-        *(float4 *)(op + (int64_t)p * 8) = o;
+        float4 o0, o1;
+        o0.x = r[0]; o0.y = r[1]; o0.z = r[2]; o0.w = r[3];
+        o1.x = r[4]; o1.y = r[5]; o1.z = r[6]; o1.w = r[7];
+        *(float4 *)(op + (int64_t)p * 8) = o0;
+        *(float4 *)(op + (int64_t)p * 8 + 4) = o1;
     }
 }
 
@@ -1397,14 +1400,14 @@ static int launch_wino_tw(const float *in, const float *upk, const float *scale,
 
 static int conv_first(const float *in, const float *w, const float *scale, const float *shift, float *out, int S, int H,
                       int W, int Cout, hipStream_t st) {
-    STITO_REQUIRE(Cout % 4 == 0 && 256 % (Cout / 4) == 0, STITO_E_UNSUPPORTED, "first conv: cout %d", Cout);
+    STITO_REQUIRE(Cout % 8 == 0 && Cout / 8 <= 65535, STITO_E_UNSUPPORTED, "first conv: cout %d", Cout);
     const int64_t npix = (int64_t)H * W;
     STITO_REQUIRE(npix < (1ll << 30), STITO_E_UNSUPPORTED, "first conv: %dx%d map too large", H, W);
-    const int ppi = 256 / (Cout / 4);
-    int64_t gx = (npix + ppi - 1) / ppi;
-    const int64_t cap = (256 * 32 + S - 1) / S;
+    STITO_REQUIRE(S <= 65535, STITO_E_UNSUPPORTED, "first conv: %d streams per launch", S);
+    int64_t gx = (npix + 255) / 256;
+    const int64_t cap = (256 * 64 + (int64_t)S * (Cout / 8) - 1) / ((int64_t)S * (Cout / 8));  // ~64 workgroups per CU in total
     gx = gx < cap ? gx : (cap < 1 ? 1 : cap);
-    hipLaunchKernelGGL(k_conv_first, dim3((unsigned)gx, S), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix);
+    hipLaunchKernelGGL(k_conv_first, dim3((unsigned)gx, S, Cout / 8), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
@@ -1459,7 +1462,7 @@ extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, i
     if (pool && (H < 2 || W < 2)) return 0;
     if (algo == STITO_CONV_WINOGRAD_F4) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD) return wino_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
-    if (cin == 1) return (!pool && 256 % (cout / 4) == 0) ? 1 : 0;
+    if (cin == 1) return (!pool && cout % 8 == 0) ? 1 : 0;
     return (cin % 8 == 0 && cout % 64 == 0) ? 1 : 0;  // channel-blocked activations: 8 channels per block
 }
 

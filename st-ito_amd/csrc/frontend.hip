@@ -45,8 +45,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int N = fe.n_fft, N2 = N >> 1;
     float2 *bufA = (float2 *)smem_raw;           // [C][N2]
-    float2 *bufB = bufA + C * N2;                // [C][N2]
-    float *pw = (float *)(bufB + C * N2);        // [C][N2 + 1]
+    float2 *bufB = bufA + C * N2;                // [C][N2]; after the FFT the idle one of the two holds the power spectrum
 
     const int cand = blockIdx.y;
     const int64_t t = blockIdx.x;
@@ -59,7 +58,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
         d1 = fmaxf(pk, 1e-8f);
         if (norm_passes > 1) d2 = fmaxf(pk / d1, 1e-8f);  // == 1 unless the candidate is (near) silent
     }
-    const bool second = norm_passes > 1 && d2 != 1.0f;    // x / 1.0f == x: skip the (IEEE, ~10 instruction) divisions
+    const bool second = norm_passes > 1 && d2 != 1.0f;    // x / 1.0f == x
+    // x / d as x * (1 / d): one IEEE division per thread instead of eight per sample pair (the ~10-instruction division
+    // was a quarter of this kernel's vector work); <= 1 ulp from the reference's division, 1e-7 against a 2e-5 bar
+    const float r1 = 1.0f / d1, r2 = 1.0f / d2;
     const float *xl = audio + (int64_t)cand * C * L;
     const float *xr = xl + L;
     // center=True: frame t covers [t*hop - n_fft/2, t*hop + n_fft/2) with reflection at the ends;
@@ -70,12 +72,12 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     for (int m = tid; m < N2; m += FE_THREADS) {
         const int64_t i0 = reflect_idx(base + 2 * m, L), i1 = reflect_idx(base + 2 * m + 1, L);
         const float w0 = fe.window[2 * m], w1 = fe.window[2 * m + 1];
-        float a0 = xl[i0] / d1, a1 = xl[i1] / d1;
-        if (second) { a0 = a0 / d2; a1 = a1 / d2; }
+        float a0 = xl[i0] * r1, a1 = xl[i1] * r1;
+        if (second) { a0 = a0 * r2; a1 = a1 * r2; }
         if (C == 2) {
-            float b0 = xr[i0] / d1, b1 = xr[i1] / d1;
-            if (second) { b0 = b0 / d2; b1 = b1 / d2; }
-            const float m0 = (a0 + b0) / 2, m1 = (a1 + b1) / 2, s0 = (a0 - b0) / 2, s1 = (a1 - b1) / 2;
+            float b0 = xr[i0] * r1, b1 = xr[i1] * r1;
+            if (second) { b0 = b0 * r2; b1 = b1 * r2; }
+            const float m0 = (a0 + b0) * 0.5f, m1 = (a1 + b1) * 0.5f, s0 = (a0 - b0) * 0.5f, s1 = (a1 - b1) * 0.5f;  // / 2 is exact
             bufA[m] = make_float2(m0 * w0, m1 * w1);
             bufA[N2 + m] = make_float2(s0 * w0, s1 * w1);
         } else {
@@ -107,15 +109,15 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     for (; p < N2; p <<= 2, sh -= 2) {
         // butterfly i: inputs s[i + q N2/4], twiddles w^q with w = exp(-2 pi i k / (4p)) = table[k << (sh - 1)],
         // outputs d[4 (i - k) + k + q p]
-        for (int c = 0; c < C; ++c) {
-            const float2 *s = src + c * N2;
-            float2 *d = dst + c * N2;
-            for (int i = tid; i < quarter; i += FE_THREADS) {
-                const int k = i & (p - 1);
-                const int j = ((i - k) << 2) + k;
-                const int ti = k << (sh - 1);
-                const float2 w1 = fe.twiddle[ti], w2 = fe.twiddle[2 * ti];
-                const float2 w3 = cmul(w1, w2);
+        for (int i = tid; i < quarter; i += FE_THREADS) {
+            const int k = i & (p - 1);
+            const int j = ((i - k) << 2) + k;
+            const int ti = k << (sh - 1);
+            const float2 w1 = fe.twiddle[ti], w2 = fe.twiddle[2 * ti];  // shared by the mid and side streams
+            const float2 w3 = cmul(w1, w2);
+            for (int c = 0; c < C; ++c) {
+                const float2 *s = src + c * N2;
+                float2 *d = dst + c * N2;
                 const float2 a0 = s[i];
                 const float2 a1 = cmul(s[i + quarter], w1);
                 const float2 a2 = cmul(s[i + 2 * quarter], w2);
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     }
 
     // ---- unpack the real transform: X[k] = E[k] + W^k O[k], power spectrum ---------------------
+    float *pw = (float *)dst;  // [C][N2 + 1] in the FFT's idle buffer (C (N2 + 1) floats <= C N2 float2): 32 KB of LDS per
+                               // workgroup instead of 41, one more workgroup per CU
     for (int c = 0; c < C; ++c) {
         const float2 *Z = src + c * N2;
         for (int k = tid; k <= N2; k += FE_THREADS) {
@@ -199,7 +203,7 @@ extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, co
     d.bn_scale = fe->bn0_scale_dev; d.bn_shift = fe->bn0_shift_dev;
     STITO_REQUIRE(fe->norm_mode != STITO_NORM_BATCHNORM || (d.bn_scale && d.bn_shift), STITO_E_INVALID, "batchnorm input norm needs bn0 scale/shift");
     const int64_t T = fe->no_center ? stito_num_frames_nocenter(n_samples, N, fe->hop) : stito_num_frames(n_samples, fe->hop);
-    const size_t lds = (size_t)channels * (N / 2) * sizeof(float2) * 2 + (size_t)channels * (N / 2 + 1) * sizeof(float);
+    const size_t lds = (size_t)channels * (N / 2) * sizeof(float2) * 2;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_logmel, dim3((unsigned)T, pop), dim3(FE_THREADS), lds, st, d, audio_dev, peaks_dev, norm_passes,
                        channels, n_samples, T, logmel_dev);
