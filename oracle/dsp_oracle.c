@@ -100,6 +100,23 @@ void oracle_parametric_eq(const float *x, float *y, int64_t n, double sample_rat
     free(buf);
 }
 
+/* ---- sensitivity switches for two JUCE details that the default restatement leaves out ------
+ * snap_block > 0: pedalboard feeds JUCE blocks of that many samples (8192) and juce::dsp::BallisticsFilter::snapToZero()
+ *                 runs after each block: envelope state with |y| < 1e-8 becomes 0.
+ * undenormalise:  JUCE_UNDENORMALISE(x) = { x += 0.1f; x -= 0.1f; } (JUCE_INTEL builds) on the comb filters' `last` and
+ *                 `temp` and the all-pass `temp` of juce::Reverb -- a quantisation of those states to multiples of 2^-27.
+ * tests/test_oracle_golden.py measures what they change; the product kernels follow the default (both off). */
+static int g_snap_block = 0, g_undenormalise = 0;
+void oracle_set_juce_quirks(int snap_block, int undenormalise) { g_snap_block = snap_block; g_undenormalise = undenormalise; }
+static inline float undenorm(float x)
+{
+    if (!g_undenormalise) return x;
+    volatile float t = x;
+    t += 0.1f;
+    t -= 0.1f;
+    return t;
+}
+
 /* ---- juce::Decibels::decibelsToGain<float> ------------------------------------------ */
 static float db_to_gain_f32(float db, float minus_inf_db)
 {
@@ -128,6 +145,7 @@ void oracle_compressor(const float *x, float *y, int64_t n, double sample_rate,
         yold = env;
         float g = (env < thr) ? 1.0f : powf(env * thr_inv, ratio_inv - 1.0f);
         y[i] = g * in;
+        if (g_snap_block > 0 && (i + 1) % g_snap_block == 0 && !(yold < -1.0e-8f || yold > 1.0e-8f)) yold = 0.0f;
     }
 }
 
@@ -240,8 +258,8 @@ void oracle_freeverb(const float *l, const float *r, float *yl, float *yr, int64
             for (int c = 0; c < 2; ++c) {
                 int k = c * 8 + j;
                 float output = cbuf[k][cidx[k]];
-                clast[k] = (output * (1.0f - damp)) + (clast[k] * damp);
-                float temp = input + (clast[k] * feedbck);
+                clast[k] = undenorm((output * (1.0f - damp)) + (clast[k] * damp));
+                float temp = undenorm(input + (clast[k] * feedbck));
                 cbuf[k][cidx[k]] = temp;
                 cidx[k] = (cidx[k] + 1) % csz[k];
                 out[c] += output;
@@ -251,7 +269,7 @@ void oracle_freeverb(const float *l, const float *r, float *yl, float *yr, int64
             for (int c = 0; c < 2; ++c) {
                 int k = c * 4 + j;
                 float bv = abuf[k][aidx[k]];
-                float temp = out[c] + (bv * 0.5f);
+                float temp = undenorm(out[c] + (bv * 0.5f));
                 abuf[k][aidx[k]] = temp;
                 aidx[k] = (aidx[k] + 1) % asz[k];
                 out[c] = bv - out[c];

@@ -34,19 +34,27 @@ for b in range(6):
             layers.append((f"{H}x{W} {cin}->{cout}{' pool' if pool else ''}", alg, 2.0 * 9 * cin * cout * H * W * S))
     if b < 5:
         H, W = H // 2, W // 2
-print(f"{'layer':26s} {'fetch_GB(x2)':>12s} {'write_GB':>9s} {'traffic_GB':>10s} {'algorithmic_GB':>14s} {'ratio':>6s} {'FLOP/B':>7s}")
+print(f"{'layer':34s} {'fetch_GB(x2)':>12s} {'write_GB':>9s} {'traffic_GB':>10s} {'algorithmic_GB':>14s} {'ratio':>6s} {'FLOP/B':>7s}")
 tf = tw = ta = 0.0
 for i, (name, alg, fl) in enumerate(layers):
     fe = f[2 * i + 1][1] * 1024 * 2 / 1e9
     wr = w[2 * i + 1][1] * 1024 / 1e9
-    kern = "wino" if "wino" in f[2 * i + 1][0] else "direct"
+    kn = f[2 * i + 1][0]
+    kern = "F(4x4,3x3)" if "wino43" in kn else ("F(2x2,3x3)" if "wino" in kn else "direct")
     name = f"{name} [{kern}]"
-    print(f"{name:26s} {fe:12.3f} {wr:9.3f} {fe + wr:10.3f} {alg / 1e9:14.3f} {(fe + wr) / (alg / 1e9):6.2f} {fl / ((fe + wr) * 1e9):7.0f}")
+    print(f"{name:34s} {fe:12.3f} {wr:9.3f} {fe + wr:10.3f} {alg / 1e9:14.3f} {(fe + wr) / (alg / 1e9):6.2f} {fl / ((fe + wr) * 1e9):7.0f}")
     tf += fe; tw += wr; ta += alg / 1e9
-print(f"{'total (11 launches)':26s} {tf:12.3f} {tw:9.3f} {tf + tw:10.3f} {ta:14.3f} {(tf + tw) / ta:6.2f}")
+print(f"{'total (11 launches)':34s} {tf:12.3f} {tw:9.3f} {tf + tw:10.3f} {ta:14.3f} {(tf + tw) / ta:6.2f}")
 print(f"per launch average: traffic {1e3 * (tf + tw) / 11:.1f} MB, algorithmic {1e3 * ta / 11:.1f} MB  (n_streams = {S})")
 if len(sys.argv) > 4:
     import json
-    json.dump({"n_streams": S, "launches": 11, "fetch_GB_x2": tf, "write_GB": tw, "traffic_GB": tf + tw, "algorithmic_GB": ta,
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernel_source_hash
+    json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (each with --kernel-trace only) on "
+                           "`python tools/conv_bench.py --streams 512 --reps 1 --modes 2`; counters are KiB; FETCH_SIZE doubled per "
+                           "MI355X_MICROARCH.md section HBM (gfx950 counts 128-B requests at 64 B); WRITE_SIZE as is.  bench.py quotes "
+                           "traffic_bytes_per_launch only while kernel_source_hash matches the tree it runs from.",
+               "kernel_source_hash": kernel_source_hash(), "n_streams": S, "launches": 11, "fetch_GB_x2": tf, "write_GB": tw, "traffic_GB": tf + tw, "algorithmic_GB": ta,
                "traffic_bytes_per_launch": (tf + tw) * 1e9 / 11, "algorithmic_bytes_per_launch": ta * 1e9 / 11},
               open(sys.argv[4], "w"), indent=1)

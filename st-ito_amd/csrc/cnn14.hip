@@ -266,26 +266,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3(const float *__restric
 
 
 // ------------------------------------------------------------------------------------------------
-// k_conv_wino: the same 3x3 conv + BN + ReLU (+ 2x2 avg-pool) by Winograd F(2x2, 3x3)
-// (Lavin & Gray 2016): Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 4x4 input tile d.  The 16
-// element-wise products become 16 independent GEMMs  M_p[tile, cout] = V_p[tile, cin] U_p[cin, cout],
-// 16 MACs per 2x2 output tile instead of 36: 2.25x fewer MFMA cycles at float32 accuracy
-// comparable to the direct form (all transform coefficients are 0, +-1, +-1/2).
-//
-// Workgroup = 64 tiles x 64 output channels x 16 positions, 12 waves with two roles:
-//   * 8 consumer waves: wave w owns one ROW of the 4 x 4 Winograd domain (positions 4 xi + nu, xi = w / 2)
-//     for all 64 tiles and half (w % 2) of the 64 channels (4 x 2 MFMA 32x32 blocks = 128 accumulator
-//     VGPRs); per 8-channel chunk it issues 12 ds_read_b128 and 32 MFMAs and nothing else, so the
-//     matrix pipes never wait for VALU work;
-//   * 4 producer waves: copy U (pre-transformed weights, [cin/8][16][cout][8]) by LDS-DMA, load
-//     each tile's 4x4 patch straight from the channel-blocked activations (bounds-checked = zero
-//     padding, stream boundaries included), form B^T d B for half of the tiles and write V for the
-//     NEXT chunk (double buffered); consumer waves 0-3 transform the other half after their MFMAs.
-//   One barrier per chunk; 3 waves per SIMD (2 consumers + 1 producer), 128 KB LDS.
-// The 16 positions of one output meet only in the epilogue: a wave reduces its row over nu in registers
-// (column half of A^T M A), the 4 x 2 partial results per (tile, channel) are exchanged through LDS
-// in one pass, then the row half, BN, ReLU and the 2x2 average pool (one Winograd tile == one pooling
-// window) are applied per (tile, channel).
+// Winograd F(2x2, 3x3) (Lavin & Gray 2016): Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 4x4 input tile d.  The 16
+// element-wise products become 16 independent GEMMs  M_p[tile, cout] = V_p[tile, cin] U_p[cin, cout], 16 MACs per 2x2
+// output tile instead of 36: 2.25x fewer MFMA cycles at float32 accuracy comparable to the direct form (all transform
+// coefficients are 0, +-1, +-1/2).  Workgroup = 64 tiles x 64 output channels x 16 positions, 8-channel chunks:
+//   U  pre-transformed weights [cin/8][16][cout][8], copied by scalar-addressed LDS-DMA;
+//   V  B^T d B of each tile's 4x4 patch, read from the channel-blocked activations (bounds-checked = zero padding,
+//      stream boundaries included), double buffered in LDS as [pos][(tile + pos/4) % 64][8];
+//   the 16 positions of one output meet only in the epilogue: a wave reduces its row over nu in registers (column half
+//   of A^T M A), the 4 x 2 partial results per (tile, channel) are exchanged through LDS in one pass, then the row half,
+//   BN, ReLU and the 2x2 average pool (one Winograd tile == one pooling window) are applied per (tile, channel).
+// The first-round kernel (k_conv_wino: 8 consumer + 4 producer waves, 83 ms per trunk pass) is gone; what its LDS-stamp
+// traces showed -- producers only run once the consumers sit at the barrier -- is explained and fixed in k_conv_wino8 below.
 // ------------------------------------------------------------------------------------------------
 struct WinoGeom {
     int S, H, W, Cin, Cout;
@@ -293,378 +285,10 @@ struct WinoGeom {
     int64_t VTR;       // S * TR
     int n_col_blocks, n_m_blocks;
     int Ho, Wo;
-    int PR, pa_i;      // halo patch rows; patch LDS-DMA wave-instructions per chunk
-    long long *trace;  // TRACE instantiation only: s_memtime stamps of workgroup 100 (tools/wino_timeline.py)
+    int PR, pa_i;      // halo patch rows; patch float4 count / 64 (patch buffer size)
+    long long *trace;  // TRACE instantiation only: s_memtime stamps (tools/wino_timeline.py)
 };
-// phase stamp: [chunk - 8][wave][slot] for chunks 8..23 of workgroup 100.  Stamps go to a spare 6 KB of
-// LDS and are copied out at the end (a global store per stamp queues behind the LDS-DMA copies).
-// What the trace shows (tools/wino_timeline.py, 58x16 512->512): the consumers finish issuing MFMAs at
-// ~4600 cycles and reach the barrier at ~4850; a producer wave issues its copies by ~600, but the first
-// instruction after them that needs a memory counter completes ~4100 cycles later -- LDS-DMA copies sit
-// in the issuing wave's queue like LDS instructions, so its transform cannot start before they land --
-// and the transform then takes ~950 cycles in the MFMA-free tail: arrival ~5850.  Neither fewer patch
-// loads nor fewer transform instructions (packed subtractions: 89 -> 77 vector instructions per
-// iteration) move these numbers: the producers' vector instructions only get issued once the two
-// consumer waves of their SIMD have stopped issuing MFMAs (~4600), whatever their priority, so a chunk
-// costs the MFMA phase plus a serial producer tail.  Pacing the consumers (s_nop / s_sleep after every
-// MFMA) does unblock the producers -- patch loads issue at ~750 instead of ~4650, and with 256 idle
-// cycles per MFMA a producer is completely done at ~2000 -- but every pacing that leaves the matrix pipe
-// fed (s_nop 3 ... 15) stretches the MFMA phase by more than the tail it removes (88.6-89.8 ms against
-// 83.2).  Issuing the transform's 16 ds_read_b128 right after the barrier shortens the tail (1000 -> 640
-// cycles) but the reads collide with the consumers' operand reads and the MFMA phase grows by as much
-// (84.6 ms).  Double-buffered MFMA operand registers (reads of group nu+1 ahead of the MFMAs of group nu,
-// pinned with sched_group_barrier) do not shorten the MFMA phase either: with two consumer waves per SIMD
-// the matrix pipe is already fed (64 MFMAs x 64 cycles = 4096 of the ~4550).  Variants measured and
-// rejected: a dedicated copy wave + 3 transform waves (copies land by ~2600, but the transform, now
-// concurrent with the MFMA stream, gets about one issue slot per MFMA: 4900 cycles for 3 items; 87.2 ms
-// against 83.3); transform before the patch loads (no change); n-tile persistent workgroups with the
-// prologue hidden behind the previous epilogue (epilogue in half the LDS: 90.8 ms).
-#define WINO_T(slot)                                                                       \
-    if (TRACE && blockIdx.x == 100 && chunk >= 8 && chunk < 24 && lane == 0)               \
-        tr_lds[((chunk - 8) * 12 + wv) * 8 + (slot)] = (unsigned)__builtin_readcyclecounter();
-
 static constexpr int WK = 8;           // input channels per chunk
-static constexpr int WINO_THREADS = 768;
-
-template <int TTW, bool POOL, bool TRACE = false>
-__global__ __launch_bounds__(WINO_THREADS) void k_conv_wino(const float *__restrict__ in, const float *__restrict__ upk,
-                                                             const float *__restrict__ scale,
-                                                             const float *__restrict__ shift, float *__restrict__ out,
-                                                             WinoGeom g) {
-    constexpr int TTH = 64 / TTW;
-    constexpr int U_FLOATS = 16 * 64 * WK;  // [pos][cout][8]
-    constexpr int V_FLOATS = 16 * 64 * WK;  // [pos][(tile + pos%4) % 64][8]
-    constexpr int BUF = U_FLOATS + V_FLOATS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // channel tile fastest: the Cout/64 workgroups that share one halo patch run side by side, so
-    // the patch is fetched from HBM once and the concurrently streamed U slabs stay L2-resident
-    const int n_tiles = g.Cout / 64;
-    const int m_blk = blockIdx.x / n_tiles;
-    const int n0 = (blockIdx.x % n_tiles) * 64;
-    const int cb = m_blk % g.n_col_blocks;
-    const int rb = m_blk / g.n_col_blocks;
-    const int vtr0 = rb * TTH;  // virtual tile row; S*TR and S*H fit 31 bits (host check): 32-bit divisions only
-    const int tc0 = cb * TTW;
-    const int n_chunks = g.Cin / WK;
-
-    // LDS map (floats): [0, 2*BUF) U/V double buffer | patch[2] (raw halo patch, LDS-DMA) | zero row
-    constexpr int PWC = 2 * TTW + 2;                 // patch columns
-    const int pfl = g.pa_i * 256 + 512;              // floats per patch buffer: pixels + a row of zeros + trash row
-    float *patch0 = smem + 2 * BUF;                  // (the zero row is what out-of-stream rows read)
-    unsigned *tr_lds = (unsigned *)(patch0 + 2 * pfl);  // TRACE only: 16 chunks x 12 waves x 8 slots
-    // input virtual row (s*H + h) of patch row 0: one above the first tile row's centre rows
-    const int iv_lo = (vtr0 / g.TR) * g.H + 2 * (vtr0 % g.TR) - 1;
-
-    if (wv >= 8) {
-        // =============================== producer waves ===============================
-        // Producers are the youngest waves of the workgroup: at equal priority the SIMD's issue
-        // arbiter serves the two (older) MFMA waves first and the producer only gets leftover slots,
-        // which stretches its ~150 instructions per chunk over more than a chunk period.
-        __builtin_amdgcn_s_setprio(3);
-        const int ptid = tid - 512;
-
-        // ---- staging -----------------------------------------------------------------------------
-        // U slab (16 positions x 64 channels x 8 floats per chunk, 2 KB contiguous per position):
-        // LDS-DMA, 32 wave-instructions per chunk, 8 per producer wave, addressed from the scalar unit.
-        // Halo patch: HBM -> registers -> LDS (two register sets, loaded two periods ahead); pixels
-        // outside the map are never written: both patch buffers are zero-filled once.
-        constexpr int NU = 8;   // U wave-copies per producer wave per chunk
-        // float4 of patch per producer thread per chunk: 2 * PR * PWC float4 over 256 threads; PR <= 2 TTH + 4
-        // (geometry check): TTW 8: 2*20*18 = 720, TTW 4: 2*36*10 = 720, TTW 2: 2*68*6 = 816
-        constexpr int NPL = TTW == 2 ? 4 : 3;
-        const int pw = wv - 8;
-        const float *u_base = upk + (int64_t)n0 * WK;                       // wave-uniform
-        const int64_t u_pos_stride = (int64_t)g.Cout * WK, u_chunk_stride = 16 * u_pos_stride;  // floats
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;  // LDS byte address of smem
-        const int npix2 = g.PR * PWC * 2;
-        const int64_t plane_f4 = (int64_t)g.H * g.W * 2;  // float4 per 8-channel plane of one stream
-        const f32x4 *p_src[NPL];
-        bool p_val[NPL];
-        int p_dst[NPL];  // float offset in a patch buffer; lanes without a pixel write the trash row
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int q = ptid + 256 * j, pix = q >> 1;
-            const int pr = pix / PWC, pc = pix % PWC;
-            const int iv = iv_lo + pr;
-            const int w = 2 * tc0 - 1 + pc;
-            p_val[j] = q < npix2 && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
-            p_src[j] = (const f32x4 *)(in + (p_val[j] ? act_off(iv / g.H, 0, (int)(iv % g.H), w, g.Cin, g.H, g.W) : 0) + (q & 1) * 4);
-            p_dst[j] = p_val[j] ? q * 4 : g.pa_i * 256 + 256 + lane * 4;
-        }
-        // two register sets, each loaded two chunk periods before it is written to LDS (HBM latency under
-        // this load is ~2.5 us, longer than one period); native vectors: HIP's float4 struct arrays
-        // are not promoted out of scratch across barriers
-        f32x4 rpA[NPL], rpB[NPL];
-#define WINO_COPY_U(CH, BOFF)                                                                       \
-    if ((CH) < n_chunks) {                                                                           \
-        _Pragma("unroll") for (int k = 0; k < NU; ++k) {                                             \
-            const int ii = pw * NU + k; /* wave-uniform: position ii/2, half ii%2 of its 2 KB */     \
-            glds16_s(u_base + (int64_t)(CH) * u_chunk_stride + (ii >> 1) * u_pos_stride + (ii & 1) * 256, \
-                     (unsigned)lane * 16u, lds0 + (unsigned)((BOFF) + (ii >> 1) * 64 * WK + (ii & 1) * 256) * 4u); \
-        }                                                                                            \
-    }
-#define WINO_LOAD_P(rp, CH)                                                                         \
-    {                                                                                               \
-        const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                       \
-        _Pragma("unroll") for (int j = 0; j < NPL; ++j) rp[j] = p_src[j][cc_ * plane_f4];            \
-    }
-#define WINO_WRITE_P(rp, PBUF)                                                                      \
-    {                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < NPL; ++j) *(f32x4 *)((PBUF) + p_dst[j]) = rp[j];       \
-    }
-// one producer iteration: write the patch set loaded two periods ago (patch(chunk+2)), start the
-// U(chunk+1) copy, refill the set with patch(chunk+4), then transform patch(chunk+1) -> V(chunk+1).
-// The LDS-DMA copies are inline asm the compiler does not count, so any vmcnt(n) it inserts after
-// them is too small by their number and drains them (a full L2 round trip in the middle of every
-// chunk).  It inserts such waits before a ds_write of loaded registers and before reloading
-// registers whose previous load it has not seen waited for -- which is why the patch writes are
-// unconditional (lanes without a pixel write a trash slot): every load is consumed before the copies
-// are issued, nothing after them waits, and at the top of the next iteration the NPL patch loads
-// issued after the copies may stay in flight: vmcnt(NPL).
-#define WINO_PRODUCE(rp)                                                                            \
-    {                                                                                               \
-        const int cur = (chunk & 1) * BUF;                                                           \
-        WINO_T(0)                                                                                    \
-        if (NPL == 4) {                                                                              \
-            if (chunk == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* U(0) landed (2 sets younger) */ \
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            /* U(chunk) landed */   \
-        } else {                                                                                     \
-            if (chunk == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                    \
-        }                                                                                            \
-        __syncthreads(); /* X: V(chunk), U(chunk), patch(chunk+1) complete; `nxt` buffers free */    \
-        WINO_T(1)                                                                                    \
-        if (chunk + 1 < n_chunks) {                                                                  \
-            WINO_WRITE_P(rp, patch0 + (chunk & 1) * pfl)                                             \
-            WINO_COPY_U(chunk + 1, BUF - cur)                                                        \
-            WINO_T(2)                                                                                \
-            WINO_LOAD_P(rp, chunk + 4)                                                               \
-            WINO_T(3)                                                                                \
-            transform_store(patch0 + ((chunk + 1) & 1) * pfl, BUF - cur);                            \
-            WINO_T(4)                                                                                \
-        }                                                                                            \
-    }
-    static_assert(NPL == 3 || NPL == 4, "the vmcnt immediates of WINO_PRODUCE are written for 3 or 4 patch loads per set");
-
-        // ---- transform items: thread = (tile, channel quad, row xi of B^T d B), two tiles per thread ----
-        const int xi = ptid & 3, p_quad = (ptid >> 2) & 1;
-        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
-        const float sgn = xi == 1 ? 1.0f : -1.0f;   // T[xi] = d[ra] + sgn * d[rb]
-        // tiles 0..31 here (one item per producer thread); tiles 32..63 are transformed by four of the consumer
-        // waves once they have issued their MFMAs: two waves per SIMD then share the serial tail of a chunk
-        constexpr int NIT = 1;
-        int rowA[NIT], rowB[NIT], vdst[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int tile = (ptid >> 3) + 32 * it;
-            const int vtr = vtr0 + tile / TTW;
-            const int tcl = tile % TTW;
-            const int s_ = vtr / g.TR;
-            const int tr = vtr % g.TR;
-            const int pc0 = s_ * g.H + 2 * tr - 1 - iv_lo;  // patch row of this tile's row rr = 0
-            const int ha = 2 * tr - 1 + ra, hb = 2 * tr - 1 + rb;
-            const int zoff = g.pa_i * 256;
-            rowA[it] = ((vtr < g.VTR && ha >= 0 && ha < g.H) ? ((pc0 + ra) * PWC + 2 * tcl) * 8 : zoff) + p_quad * 4;
-            rowB[it] = ((vtr < g.VTR && hb >= 0 && hb < g.H) ? ((pc0 + rb) * PWC + 2 * tcl) * 8 : zoff) + p_quad * 4;
-            // V plane p = 4*xi + nu keeps tile t at slot (t + xi) % 64: the 4 lanes of a tile that
-            // write the same nu then hit 4 different 32-B slots instead of one bank group
-            vdst[it] = U_FLOATS + (xi * 4) * 64 * WK + ((tile + xi) & 63) * WK + p_quad * 4;
-        }
-        auto transform_store = [&](const float *pbuf, int v_boff) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                f32x4 T[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)  // native vector arithmetic -> v_pk_fma_f32 / v_pk_add_f32
-                    T[j] = *(const f32x4 *)(pbuf + rowA[it] + j * 8) + sgn * *(const f32x4 *)(pbuf + rowB[it] + j * 8);
-                float *vb = smem + v_boff + vdst[it];
-                // differences as fma(b, -1, a): hipcc has no packed subtract and would split a - b into four
-                // v_sub_f32; a * 1 + (-b) is exact, so the results are bit-identical
-                const f32x4 m1 = (f32x4)(-1.0f);
-                *(f32x4 *)(vb + 0 * 64 * WK) = __builtin_elementwise_fma(T[2], m1, T[0]);
-                *(f32x4 *)(vb + 1 * 64 * WK) = T[1] + T[2];
-                *(f32x4 *)(vb + 2 * 64 * WK) = __builtin_elementwise_fma(T[1], m1, T[2]);
-                *(f32x4 *)(vb + 3 * 64 * WK) = __builtin_elementwise_fma(T[3], m1, T[1]);
-            }
-        };
-
-        // patch(k) lives in patch buffer k & 1; U(k), V(k) in U/V buffer k & 1.
-        WINO_COPY_U(0, 0)                    // oldest in the queue: the waits below cover it without over-waiting
-        WINO_LOAD_P(rpA, 0)
-        WINO_LOAD_P(rpB, 1)
-        for (int i = ptid; i < 2 * pfl; i += 256) patch0[i] = 0.0f;  // patch buffers + their zero rows, under the loads
-        __syncthreads();                     // B0: zero fill of the patch buffers complete
-        WINO_WRITE_P(rpA, patch0)
-        WINO_WRITE_P(rpB, patch0 + pfl)
-        WINO_LOAD_P(rpA, 2)                  // set A: patch(2) -> written at chunk 0
-        WINO_LOAD_P(rpB, 3)                  // set B: patch(3) -> written at chunk 1
-        __syncthreads();                     // B1: patch(0) visible to every producer wave
-        transform_store(patch0, 0);          // V(0)
-        for (int chunk = 0; chunk < n_chunks; chunk += 2) {
-            WINO_PRODUCE(rpA)
-            if (chunk + 1 < n_chunks) {
-                ++chunk;
-                WINO_PRODUCE(rpB)
-                --chunk;
-            }
-        }
-#undef WINO_PRODUCE
-#undef WINO_COPY_U
-#undef WINO_LOAD_P
-#undef WINO_WRITE_P
-        // keep the barrier count of the consumers' epilogue
-        __syncthreads();
-        __syncthreads();
-        return;
-    }
-
-    // =============================== consumer waves ===============================
-    // wave w owns one ROW of the Winograd domain, positions p = 4 xi + nu (xi = w / 2, nu = 0..3), for
-    // all 64 tiles and one half (w % 2) of the 64 output channels: 4 x 2 MFMA 32x32 blocks = 128
-    // accumulator VGPRs.  Holding a complete row lets the wave apply the column half of A^T M A in
-    // registers, so only 2 instead of 4 values per (row, tile, channel) go through the LDS exchange.
-    const int half = lane >> 5, l31 = lane & 31;
-    const int xi = wv >> 1, nh = wv & 1;
-    int a_off[4][2], b_off[4];  // [nu][mb], [nu]
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-        const int p = 4 * xi + nu;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a_off[nu][q] = U_FLOATS + p * 64 * WK + ((q * 32 + l31 + xi) & 63) * WK + half * 4;
-        b_off[nu] = p * 64 * WK + (nh * 32 + l31) * WK + half * 4;
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.0f;
-    // helper role of consumer waves 0-3: B^T d B of tiles 32..63 for the next chunk (same item layout as the
-    // producers: row hx of the transform, channel quad, tile), done after the wave's own MFMAs (these waves
-    // finish issuing at ~2600 cycles of a chunk; waves 4-7 as helpers were slower: 84.1 against 81.8 ms).  While the two consumer waves of a SIMD stream MFMAs no other wave gets vector
-    // instructions issued at a useful rate (measured, whatever its priority or age), so the transform is a serial
-    // tail after the MFMA phase; sharing it between the producer and a consumer wave of each SIMD halves it.
-    const bool helper = wv < 4;
-    int h_rowA = 0, h_rowB = 0, h_vdst = 0;
-    float h_sgn = 0.0f;
-    {
-        const int hx = tid & 3, hq = (tid >> 2) & 1, tile = ((tid >> 3) & 31) + 32;
-        const int ra = hx == 0 ? 0 : (hx == 2 ? 2 : 1), rb = hx == 3 ? 3 : (hx == 2 ? 1 : 2);
-        h_sgn = hx == 1 ? 1.0f : -1.0f;
-        const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
-        const int s_ = vtr / g.TR, tr = vtr % g.TR;
-        const int pc0 = s_ * g.H + 2 * tr - 1 - iv_lo;
-        const int ha = 2 * tr - 1 + ra, hb = 2 * tr - 1 + rb;
-        const int zoff = g.pa_i * 256;
-        h_rowA = ((vtr < g.VTR && ha >= 0 && ha < g.H) ? ((pc0 + ra) * PWC + 2 * tcl) * 8 : zoff) + hq * 4;
-        h_rowB = ((vtr < g.VTR && hb >= 0 && hb < g.H) ? ((pc0 + rb) * PWC + 2 * tcl) * 8 : zoff) + hq * 4;
-        h_vdst = U_FLOATS + (hx * 4) * 64 * WK + ((tile + hx) & 63) * WK + hq * 4;
-    }
-// one transform item, streamed so that at most T0, T2 and one column pair are live next to the accumulators
-#define WINO_HELP(PBUF, VBOFF)                                                                      \
-    {                                                                                               \
-        const float *pb_ = (PBUF);                                                                   \
-        float *vb_ = smem + (VBOFF) + h_vdst;                                                        \
-        const f32x4 sg_ = (f32x4)(h_sgn), m1_ = (f32x4)(-1.0f);                                      \
-        const f32x4 T0 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB), sg_, *(const f32x4 *)(pb_ + h_rowA)); \
-        const f32x4 T2 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB + 16), sg_, *(const f32x4 *)(pb_ + h_rowA + 16)); \
-        *(f32x4 *)(vb_ + 0 * 64 * WK) = __builtin_elementwise_fma(T2, m1_, T0);                      \
-        const f32x4 T1 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB + 8), sg_, *(const f32x4 *)(pb_ + h_rowA + 8)); \
-        *(f32x4 *)(vb_ + 1 * 64 * WK) = T1 + T2;                                                     \
-        *(f32x4 *)(vb_ + 2 * 64 * WK) = __builtin_elementwise_fma(T1, m1_, T2);                      \
-        const f32x4 T3 = __builtin_elementwise_fma(*(const f32x4 *)(pb_ + h_rowB + 24), sg_, *(const f32x4 *)(pb_ + h_rowA + 24)); \
-        *(f32x4 *)(vb_ + 3 * 64 * WK) = __builtin_elementwise_fma(T3, m1_, T1);                      \
-    }
-
-    __syncthreads();  // B0 (producers: zero fill)
-    __syncthreads();  // B1 (producers: first patch landed)
-    if (helper) WINO_HELP(patch0, 0)  // this wave's share of V(0); visible after the first chunk barrier
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const float *sb = smem + (chunk & 1) * BUF;
-        WINO_T(0)
-        __syncthreads();
-        WINO_T(1)
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            const float4 av0 = *(const float4 *)(sb + a_off[nu][0]);
-            const float4 av1 = *(const float4 *)(sb + a_off[nu][1]);
-            const float4 bv = *(const float4 *)(sb + b_off[nu]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float a0 = kk == 0 ? av0.x : kk == 1 ? av0.y : kk == 2 ? av0.z : av0.w;
-                const float a1 = kk == 0 ? av1.x : kk == 1 ? av1.y : kk == 2 ? av1.z : av1.w;
-                const float b0 = kk == 0 ? bv.x : kk == 1 ? bv.y : kk == 2 ? bv.z : bv.w;
-                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[nu][0], 0, 0, 0);
-                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[nu][1], 0, 0, 0);
-            }
-        }
-        WINO_T(2)
-        if (helper && chunk + 1 < n_chunks) WINO_HELP(patch0 + ((chunk + 1) & 1) * pfl, BUF - (chunk & 1) * BUF)
-    }
-#undef WINO_HELP
-
-    // ---- epilogue: Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1].  Column half in registers:
-    // c0 = m0 + m1 + m2, c1 = m1 - m2 - m3 over nu; exchange xch[2 xi + j][tile 0..63][channel 0..63]
-    // (8 planes over the U/V double buffer and the first 16 KB of the patch buffers, all idle now);
-    // row half, BN + ReLU (+ pool) per (tile, channel).  Tile stride XT = 72 floats: the two half-waves of
-    // an accumulator register sit 4 tiles apart, 4 * 72 = 32 mod 64 banks -> conflict-free writes.
-    constexpr int XT = 72, XP = 64 * XT;
-    float *xch = smem;
-    __syncthreads();  // main loop done with the LDS
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        float *xp = xch + (2 * xi) * XP + mb * 32 * XT + nh * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float m0 = acc[0][mb][r], m1 = acc[1][mb][r], m2 = acc[2][mb][r], m3 = acc[3][mb][r];
-            xp[row * XT] = (m0 + m1) + m2;
-            xp[XP + row * XT] = (m1 - m2) - m3;
-        }
-    }
-    __syncthreads();
-    const int e_co = tid & 63, e_t0 = tid >> 6;  // thread -> channel, tiles e_t0 + 8*k
-    const int co = n0 + e_co;
-    const float sc = scale[co], sh = shift[co];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int tl = e_t0 + 8 * it;  // tile within the block
-        float c0[4], c1[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            c0[x] = xch[(2 * x) * XP + tl * XT + e_co];
-            c1[x] = xch[(2 * x + 1) * XP + tl * XT + e_co];
-        }
-        float y[4];
-        y[0] = (c0[0] + c0[1]) + c0[2];
-        y[1] = (c1[0] + c1[1]) + c1[2];
-        y[2] = (c0[1] - c0[2]) - c0[3];
-        y[3] = (c1[1] - c1[2]) - c1[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(y[e], sc, sh), 0.0f);
-        const int vtr = vtr0 + tl / TTW;
-        const int tc = tc0 + tl % TTW;
-        if (vtr < g.VTR && tc < g.TC) {
-            const int s = vtr / g.TR;
-            const int tr = vtr % g.TR;
-            if (POOL) {
-                out[act_off(s, co, tr, tc, g.Cout, g.Ho, g.Wo)] = (((y[0] + y[1]) + y[2]) + y[3]) * 0.25f;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int hh = 2 * tr + (e >> 1), ww = 2 * tc + (e & 1);
-                    if (hh < g.H && ww < g.W) out[act_off(s, co, hh, ww, g.Cout, g.H, g.W)] = y[e];
-                }
-            }
-        }
-    }
-    if (TRACE && blockIdx.x == 100)
-        for (int i = tid; i < 16 * 12 * 8; i += 512) g.trace[i] = tr_lds[i];
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_conv_wino8: the same Winograd F(2x2,3x3) tile (64 tiles x 64 output channels x 16 positions, 8-channel
@@ -1337,13 +961,8 @@ static bool wino_geometry(const ConvShape &c, WinoGeom &g, size_t &lds, int64_t 
     g.pa_i = (g.PR * (2 * TTW + 2) * 2 + 63) / 64;
     lds = ((size_t)2 * (16 * 64 * WK * 2) + 2 * (g.pa_i * 256 + 512)) * sizeof(float);
     // pa_i >= 8: the epilogue's exchange (8 planes x 64 tiles x 72 floats) spills 16 KB into the patch buffers
-    if (g.PR * (2 * TTW + 2) * 2 > (TTW == 2 ? 4 : 3) * 256) return false;  // NPL patch float4 per producer thread
+    if (g.PR * (2 * TTW + 2) * 2 > 2 * WINO8_THREADS) return false;  // two patch float4 per thread per chunk
     return g.pa_i >= 8 && g.pa_i <= 16 && (2 * TTW + 2) * 8 <= 256 && lds <= 160 * 1024;
-}
-
-static int wino_variant() {  // STITO_WINO=12: the first-round 12-wave producer/consumer kernel (kept for A/B runs)
-    static const int v = [] { const char *e = getenv("STITO_WINO"); return e ? atoi(e) : 8; }();
-    return v;
 }
 
 template <int TTW, bool POOL>
@@ -1354,22 +973,10 @@ static int launch_wino(const float *in, const float *upk, const float *scale, co
     int64_t blocks;
     STITO_REQUIRE((wino_geometry<TTW, POOL>(c, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd): %dx%d map does not fit the LDS-resident halo patch", c.H, c.W);
-    if (wino_variant() == 8) {
-        g.trace = g_wino_trace;
-        auto kern8 = g_wino_trace ? k_conv_wino8<TTW, POOL, true> : k_conv_wino8<TTW, POOL, false>;
-        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern8, dim3((unsigned)blocks), dim3(WINO8_THREADS), lds, st, in, upk, scale, shift, out, g);
-        STITO_LAUNCH_CHECK();
-        return STITO_OK;
-    }
     g.trace = g_wino_trace;
-    if (g_wino_trace) {
-        lds += 16 * 12 * 8 * sizeof(unsigned);
-        STITO_REQUIRE(lds <= 160 * 1024, STITO_E_UNSUPPORTED, "wino trace: no spare LDS for the stamps at this shape");
-    }
-    auto kern = g_wino_trace ? k_conv_wino<TTW, POOL, true> : k_conv_wino<TTW, POOL, false>;
-    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WINO_THREADS), lds, st, in, upk, scale, shift, out, g);
+    auto kern8 = g_wino_trace ? k_conv_wino8<TTW, POOL, true> : k_conv_wino8<TTW, POOL, false>;
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern8, dim3((unsigned)blocks), dim3(WINO8_THREADS), lds, st, in, upk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
