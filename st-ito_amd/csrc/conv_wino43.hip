@@ -38,6 +38,9 @@
 
 namespace stito {
 
+#ifndef W43_ABL
+#define W43_ABL 0  // timing-experiment bit mask (1 no transform, 2 no U copies, 4 no patch copies, 8 no operand reads); 0 in every build that ships
+#endif
 static constexpr int W43_THREADS = 512;
 static constexpr int W43_K = 4;                          // input channels per chunk
 static constexpr int W43_U = 36 * 64 * W43_K;            // floats: [pos][cout][4]
@@ -323,31 +326,31 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         const float *sb = smem + cur;                                                                    \
         const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
         if (!(FIRST)) {                                                                                  \
-            W43_GAP(S0, 2, 0, 0, if (MORE) W43_COPY_P(k + 2, k & 1))                                     \
-            W43_GAP(S0, 2, 1, 0, W43_LOAD_OPS(S1, sb, 0) if (MORE) W43_COPY_U1(k + 1, nxt, 0))           \
-            W43_GAP(S0, 2, 2, 0, if (MORE) W43_COPY_U1(k + 1, nxt, 1))                                   \
-            W43_GAP(S0, 2, 0, 1, if (MORE) W43_COPY_U1(k + 1, nxt, 2))                                   \
-            W43_GAP(S0, 2, 1, 1, if (MORE) W43_COPY_U1(k + 1, nxt, 3))                                   \
-            W43_GAP(S0, 2, 2, 1, if (MORE) W43_COPY_U1(k + 1, nxt, 4))                                   \
+            W43_GAP(S0, 2, 0, 0, if (MORE && !(W43_ABL & 4)) W43_COPY_P(k + 2, k & 1))                                     \
+            W43_GAP(S0, 2, 1, 0, if (!(W43_ABL & 8)) W43_LOAD_OPS(S1, sb, 0) if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 0))           \
+            W43_GAP(S0, 2, 2, 0, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 1))                                   \
+            W43_GAP(S0, 2, 0, 1, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 2))                                   \
+            W43_GAP(S0, 2, 1, 1, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 3))                                   \
+            W43_GAP(S0, 2, 2, 1, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 4))                                   \
         } else {                                                                                         \
             W43_COPY_P(k + 2, k & 1)                                                                     \
-            W43_LOAD_OPS(S1, sb, 0)                                                                      \
+            if (!(W43_ABL & 8)) W43_LOAD_OPS(S1, sb, 0)                                                                      \
             W43_COPY_U1(k + 1, nxt, 0) W43_COPY_U1(k + 1, nxt, 1) W43_COPY_U1(k + 1, nxt, 2)             \
             W43_COPY_U1(k + 1, nxt, 3) W43_COPY_U1(k + 1, nxt, 4)                                        \
             W43_FENCE()                                                                                  \
         }                                                                                                \
-        W43_GAP(S1, 0, 0, 0, W43_LOAD_OPS(S0, sb, 1))                                                    \
-        W43_GAP(S1, 0, 1, 0, if (MORE) { W43_T_RD(pb_r, 0, rX) W43_T_RD(pb_r, 1, rY) })                  \
+        W43_GAP(S1, 0, 0, 0, if (!(W43_ABL & 8)) W43_LOAD_OPS(S0, sb, 1))                                                    \
+        W43_GAP(S1, 0, 1, 0, if (MORE && !(W43_ABL & 1)) { W43_T_RD(pb_r, 0, rX) W43_T_RD(pb_r, 1, rY) })                  \
         W43_GAP(S1, 0, 2, 0, )                                                                           \
-        W43_GAP(S1, 0, 0, 1, if (MORE) { W43_T_ROW(0, rX) W43_T_RD(pb_r, 2, rX) })                       \
-        W43_GAP(S1, 0, 1, 1, if (MORE) { W43_T_ROW(1, rY) W43_T_RD(pb_r, 3, rY) })                       \
-        W43_GAP(S1, 0, 2, 1, if (MORE) { W43_T_ROW(2, rX) W43_T_RD(pb_r, 4, rX) })                       \
-        W43_GAP(S0, 1, 0, 0, W43_LOAD_OPS(S1, sb, 2))                                                    \
-        W43_GAP(S0, 1, 1, 0, if (MORE) { W43_T_ROW(3, rY) W43_T_RD(pb_r, 5, rY) })                       \
-        W43_GAP(S0, 1, 2, 0, if (MORE) W43_T_ROW(4, rX))                                                 \
-        W43_GAP(S0, 1, 0, 1, if (MORE) W43_T_ROW(5, rY))                                                 \
-        W43_GAP(S0, 1, 1, 1, if (MORE) W43_T_COLS_A(nxt))                                                \
-        W43_GAP(S0, 1, 2, 1, if (MORE) W43_T_COLS_B(nxt))                                                \
+        W43_GAP(S1, 0, 0, 1, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(0, rX) W43_T_RD(pb_r, 2, rX) })                       \
+        W43_GAP(S1, 0, 1, 1, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(1, rY) W43_T_RD(pb_r, 3, rY) })                       \
+        W43_GAP(S1, 0, 2, 1, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(2, rX) W43_T_RD(pb_r, 4, rX) })                       \
+        W43_GAP(S0, 1, 0, 0, if (!(W43_ABL & 8)) W43_LOAD_OPS(S1, sb, 2))                                                    \
+        W43_GAP(S0, 1, 1, 0, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(3, rY) W43_T_RD(pb_r, 5, rY) })                       \
+        W43_GAP(S0, 1, 2, 0, if (MORE && !(W43_ABL & 1)) W43_T_ROW(4, rX))                                                 \
+        W43_GAP(S0, 1, 0, 1, if (MORE && !(W43_ABL & 1)) W43_T_ROW(5, rY))                                                 \
+        W43_GAP(S0, 1, 1, 1, if (MORE && !(W43_ABL & 1)) W43_T_COLS_A(nxt))                                                \
+        W43_GAP(S0, 1, 2, 1, if (MORE && !(W43_ABL & 1)) W43_T_COLS_B(nxt))                                                \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* U(k+1), patch(k+2) landed (no partial waits: see the header) */ \
         W43_BARRIER()                                     /* B(k) */                                     \
         if (TRACE && k < 12) { W43_STAMP(4 + k) }                                                        \
