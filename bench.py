@@ -116,9 +116,32 @@ def conv_layer_times(model, n_streams, T, reps=3):
     layers = []
     cur = x
     issued_total = 0.0
+    fused = bool(W.conv1_fused_w_dev) and bool(W.conv_wino_dev[1]) and W.conv_wino_algo[1] == 2 and \
+        L.stito_conv_block1_fused_supported(n_streams, rows[0]["H"], rows[0]["W"], rows[0]["cout"], rows[1]["cout"], 1)
     for i, r in enumerate(rows):
         Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
+        if fused and i == 0:
+            continue  # conv_block1 is one launch: reported with its second conv
         out = torch.empty((n_streams, r["cout"] // 8, Ho, Wo, 8), device=dev)
+        if fused and i == 1:
+            args = (_hip.ptr(x), W.conv1_fused_w_dev, W.bn_shift_dev[0], W.conv_wino_dev[1], W.bn_scale_dev[1], W.bn_shift_dev[1],
+                    _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], 1, st)
+            _hip.check(L.stito_conv_block1_fused(*args))
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in ev:
+                a.record()
+                _hip.check(L.stito_conv_block1_fused(*args))
+                b.record()
+            torch.cuda.synchronize()
+            ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            fl = (r["flops"] + rows[0]["flops"]) * n_streams
+            issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 2)
+            issued_total += issued
+            layers.append(dict(layer="conv_block1 (conv1 fused into conv2's patch staging)", algo=ALGO_NAMES[2], H=r["H"], W=r["W"], cin=1,
+                               cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2),
+                               mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)))
+            cur = out
+            continue
         walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2) else 1
         wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], walgo)
         algo = walgo if wino else 0
@@ -316,7 +339,7 @@ def main():
             issued_timed = issued_pass * passes_per_step * args.steps      # FLOPs the timed launches issued (full passes)
             achieved = issued_timed / conv_ms.value / 1e9                  # TFLOP/s of MFMA work over the timed region's conv launches
             traffic, traffic_note = pmc_traffic_per_launch(streams_per_launch)
-            algos = sorted({l["algo"] for l in layers if l["cin"] % 8 == 0})
+            algos = sorted({l["algo"] for l in layers if "mfma_frac" in l})
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": "the 11 f32-MFMA 3x3-conv launches of a trunk pass (" + ", ".join(algos) + "; v_mfma_f32_32x32x2_f32). achieved = "

@@ -187,6 +187,8 @@ typedef struct {
     const float *fc_mid_b_dev;   /* (embed_dim) */
     const float *fc_side_wt_dev; /* (2048, embed_dim) */
     const float *fc_side_b_dev;  /* (embed_dim) */
+    const float *conv1_fused_w_dev; /* stito_cnn14_pack_conv1_fused, or NULL.  With it and an F(4x4,3x3) packing of conv index 1
+                                       the forward runs conv_block1 as ONE launch (stito_conv_block1_fused) */
 } stito_cnn14_weights;
 
 /* Number of floats of a packed conv weight for (cout, cin) and algorithm. */
@@ -216,6 +218,17 @@ int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, i
  * the 1-channel input of the first conv is (n, H, W).
  * in (n, cin/8, H, W, 8) -> out (n, cout/8, H', W', 8), y = relu(conv3x3(x) * scale + shift),
  * pool != 0: 2x2 average pooling (floor). */
+/* conv_block1 fused (panns.py:250, ConvBlock 65-80): y = pool?(relu(bn2(conv3x3(relu(bn1(conv3x3(x))))))) for a 1-channel
+ * input x (n, H, W) -- the log-mel image -- in one launch: the first conv (c1 channels) is evaluated per 4-channel chunk
+ * while the Winograd F(4x4,3x3) kernel stages its input patch, so the c1-channel full-resolution map never goes to HBM.
+ *   fused_w1_dev  stito_cnn14_pack_conv1_fused(w1 (c1,1,3,3), bn1 scale): [c1/4][9][4], scale folded;  shift1_dev (c1)
+ *   packed_w2_dev STITO_CONV_WINOGRAD_F4 packing of w2 (cout, c1, 3, 3);  scale2_dev / shift2_dev (cout)
+ *   out_dev       (n, cout/8, H', W', 8).   Needs c1 % 8 == 0, cout % 64 == 0, W >= 32 (pooled) / W >= 29 (not pooled). */
+int stito_cnn14_pack_conv1_fused(const float *w_oihw_dev, const float *scale_dev, int c1, float *packed_dev, void *stream);
+int stito_conv_block1_fused_supported(int n, int H, int W, int c1, int cout, int pool);
+int stito_conv_block1_fused(const float *x_dev, const float *fused_w1_dev, const float *shift1_dev, const float *packed_w2_dev,
+                            const float *scale2_dev, const float *shift2_dev, float *out_dev, int n, int H, int W, int c1,
+                            int cout, int pool, void *stream);
 /* Profiling aid: with buf_dev != NULL the Winograd launches use an instrumented instantiation whose
  * workgroup 100 records s_memtime stamps of 32 chunks x 12 waves x 8 phases (int64) into buf_dev;
  * NULL (default) restores the plain kernel.  Thread-local.  See tools/wino_timeline.py. */

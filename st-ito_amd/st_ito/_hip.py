@@ -47,6 +47,7 @@ class Cnn14Weights(Structure):
         ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
         ("fc_mid_wt_dev", c_void_p), ("fc_mid_b_dev", c_void_p),
         ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
+        ("conv1_fused_w_dev", c_void_p),
     ]
 
 
@@ -82,6 +83,10 @@ SIGNATURES = {
     "stito_debug_wino_trace": (c_int, [c_void_p]),
     "stito_conv_timing_enable": (c_int, [c_int]),
     "stito_conv_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
+    "stito_cnn14_pack_conv1_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "stito_conv_block1_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "stito_conv_block1_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_void_p]),
     "stito_conv3x3_issued_flops": (c_double, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
