@@ -9,9 +9,9 @@
 //   parametric EQ  : 12th-order LTI cascade, float64 like scipy.lfilter (effects.py:465-512).
 //                    One workgroup per stream, 256 time-chunks per stream; zero-state pass,
 //                    12x12 state-transition power + chunk scan in LDS, corrected pass.
-//   compressor     : envelope is a non-linear one-pole (switching attack/release) -> one lane
-//                    per stream, serial in time, LDS-transposed tiles for coalescing; the
-//                    gain computer (pow) runs fully parallel afterwards.
+//   compressor     : the switching one-pole envelope composes over (max, +): 15-sample block functions in
+//                    parallel, a short serial scan over block boundaries, envelope + VCA in parallel
+//                    (compressor.hip).
 //   Freeverb       : one workgroup per candidate, all delay lines resident in LDS (~112 KB);
 //                    time advances in tiles shorter than the shortest delay line, so comb /
 //                    all-pass updates inside a tile are independent; the comb damping one-pole
@@ -21,7 +21,6 @@
 //   distortion/gain: element-wise.
 #include "common.h"
 #include "dsp_view.h"
-#include "comp_env_serial.inc"
 
 namespace stito {
 
@@ -126,8 +125,11 @@ __global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, 
         o[0] = thr;
         o[1] = 1.0f / thr;
         o[2] = 1.0f / (float)v[1] - 1.0f;
-        o[3] = at < 1.0e-3f ? 0.0f : expf(expf_ / at);
-        o[4] = rl < 1.0e-3f ? 0.0f : expf(expf_ / rl);
+        // the one-pole coefficients sit next to 1 and the envelope only sees 1 - c: one ulp of c is up to 3e-5 of
+        // (1 - c).  exp in double of the float32 argument, rounded once, is the correctly rounded expf the host libm
+        // returns (ocml's expf is allowed 1 ulp)
+        o[3] = at < 1.0e-3f ? 0.0f : (float)exp((double)(expf_ / at));
+        o[4] = rl < 1.0e-3f ? 0.0f : (float)exp((double)(expf_ / rl));
     } else if (kind == STITO_FX_DISTORTION) {
         o[0] = db_to_gain((float)v[0], -100.0f);
         o[1] = db_to_gain((float)v[1], -100.0f);
@@ -320,234 +322,6 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
             for (int w = 1; w < EQ_NC / 64; ++w) m = fmaxf(m, pk_red[w]);
             atomicMax((unsigned int *)&post.peaks[cand], __float_as_uint(m));
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Compressor: juce::dsp::Compressor<float> (peak ballistics + VCA), effects.py:891-897
-// ------------------------------------------------------------------------------------------------
-static constexpr int CE_T = 64;            // samples per tile (comp_env_serial.inc is generated for 64)
-static constexpr int CE_LD = 2 * CE_T + 4; // LDS row stride in floats: CE_T (a, r) pairs (16-B aligned rows,
-                                           // conflict-free b128 column walks)
-static constexpr int CE_THREADS = 768;     // wave 0: recurrence; waves 1-11: global <-> LDS movers (3 mover waves
-                                           // could not keep up with the 3-instruction-per-sample serial wave)
-static constexpr int CE_MOVERS = CE_THREADS - 64;
-static constexpr int CE_SLOTS = 3;         // LDS ring: tile being stored / computed / filled
-static constexpr int CE_COLS = CE_T / 4;   // float4 columns of a tile row
-static constexpr int CE_RSTEP = CE_MOVERS / CE_COLS;             // rows between a mover's items (44)
-static constexpr int CE_NIT = (64 + CE_RSTEP - 1) / CE_RSTEP;    // float4 items per mover per tile (2)
-
-typedef float ce_f2 __attribute__((ext_vector_type(2)));
-typedef float ce_f4 __attribute__((ext_vector_type(4)));
-
-// One step of the switching one-pole in "max of two affine maps" form.  The reference form is
-//     y' = v + c (y - v),  c = (v > y) ? c_att : c_rel,  v = |x|                       (effects.py:891-897)
-// Both candidates are affine in y and differ by (c_att - c_rel)(y - v), so for c_att <= c_rel the
-// selected one is the larger: y' = max(c_att y + (1-c_att) v, c_rel y + (1-c_rel) v); for
-// c_att > c_rel it is the smaller, which is the same max applied to z = -y.  With
-// (a, r) = s ((1-c_att) v, (1-c_rel) v), s = +-1, precomputed off the critical path the serial wave
-// issues one v_pk_fma_f32 and one v_max_f32 per sample (a single wave issues a VALU instruction
-// every ~7 cycles whether or not it depends on the previous one -- tools/ubench/env_chain.hip --
-// so the instruction count, not the dependency depth, sets the time per sample).  env = |z|.
-__device__ __forceinline__ float env_step(ce_f2 c2, float z, ce_f2 ar) {
-    const ce_f2 t = __builtin_elementwise_fma(c2, (ce_f2){z, z}, ar);
-    return fmaxf(t.x, t.y);
-}
-
-// The recurrence is serial in time (a switching one-pole is not associative), so the time axis
-// cannot be split; what can be done is to make the serial wave do nothing but the recurrence and
-// to keep HBM latency off its critical path.  One workgroup = 64 streams: lane l of wave 0 owns
-// stream l and walks its row of an LDS tile ((a, r) pairs in, z out over the already-consumed head
-// of the same row, 4 samples per pair of ds_read_b128); waves 1-3 are movers: tile j+3 is in flight
-// HBM -> registers (two register sets), tile j+1 is being expanded to (a, r) pairs in the ring,
-// tile j-1 is being stored as |z| -- one barrier per 64 samples.  (Applying the VCA in the movers
-// as well was measured: 8.0 ms fused against 6.5 + 1.1 ms separate -- the gain computer is
-// throughput work for 256 CUs, this kernel only occupies S / 64 of them.)
-template <bool VEC>
-__global__ __launch_bounds__(CE_THREADS) void k_comp_env(InView in, float *__restrict__ env, int64_t cand_stride,
-                                                          int C, int64_t L, int S, const double *__restrict__ coef) {
-    extern __shared__ __attribute__((aligned(16))) float ce_smem[];
-    float *ring = ce_smem;                                                       // [CE_SLOTS][64][CE_LD]
-    const float **row_in = (const float **)(ce_smem + CE_SLOTS * 64 * CE_LD);   // [64]
-    float **row_out = (float **)(row_in + 64);                                   // [64]
-    float *row_sa = (float *)(row_out + 64), *row_sr = row_sa + 64;              // [64] each
-
-    const int tid = threadIdx.x;
-    const int s0 = blockIdx.x * 64;
-    const int nrows = min(64, S - s0);
-    ce_f2 c2 = {0.f, 0.f};
-    if (tid < 64) {
-        const int s = s0 + (tid < nrows ? tid : 0);
-        const int cand = s / C, ch = s % C;
-        row_in[tid] = in_ptr(in, cand, ch);
-        row_out[tid] = env + (int64_t)cand * cand_stride + (int64_t)ch * L;
-        const double *cf = coef + (int64_t)cand * COEF_STRIDE;
-        const float cat = (float)cf[3], crl = (float)cf[4];
-        const float sg = cat <= crl ? 1.0f : -1.0f;
-        c2 = (ce_f2){cat, crl};
-        row_sa[tid] = sg * (1.0f - cat);
-        row_sr[tid] = sg * (1.0f - crl);
-    }
-    __syncthreads();
-    const int64_t ntiles = (L + CE_T - 1) / CE_T;
-    const int m = tid - 64;  // mover index
-    float z = 0.0f;
-
-    if (!VEC) {  // unaligned fallback: synchronous scalar tiles (any L / base alignment), same arithmetic
-        for (int64_t k = 0; k < ntiles; ++k) {
-            const int64_t t0 = k * CE_T;
-            for (int i = tid; i < 64 * CE_T; i += CE_THREADS) {
-                const int r = i / CE_T, j = i % CE_T;
-                const float v = (r < nrows && t0 + j < L) ? fabsf(row_in[r][t0 + j]) : 0.0f;
-                *(ce_f2 *)(ring + r * CE_LD + 2 * j) = (ce_f2){row_sa[r] * v, row_sr[r] * v};
-            }
-            __syncthreads();
-            if (tid < 64)
-                for (int j = 0; j < CE_T; ++j) {
-                    z = env_step(c2, z, *(const ce_f2 *)(ring + tid * CE_LD + 2 * j));
-                    ring[tid * CE_LD + j] = z;  // slot j <= 2j: already consumed
-                }
-            __syncthreads();
-            for (int i = tid; i < 64 * CE_T; i += CE_THREADS) {
-                const int r = i / CE_T, j = i % CE_T;
-                if (r < nrows && t0 + j < L) row_out[r][t0 + j] = fabsf(ring[r * CE_LD + j]);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-
-    // every mover thread serves the same (row, float4 column) items in every tile: column
-    // q = m % 16, rows m / 16 + CE_RSTEP u (CE_MOVERS = CE_RSTEP * 16).  Pointers are kept in registers as
-    // global-address-space pointers (the row tables in LDS hold generic pointers).
-    typedef ce_f4 f4;
-    typedef const __attribute__((address_space(1))) f4 *gsrc_t;
-    typedef __attribute__((address_space(1))) f4 *gdst_t;
-    gsrc_t gsrc[CE_NIT];
-    gdst_t gdst[CE_NIT];
-    float sa[CE_NIT], sr[CE_NIT];
-    bool ok[CE_NIT], inr[CE_NIT];
-    const int mq = 4 * (m & (CE_COLS - 1)), mr0 = m / CE_COLS;
-    const int lbase = mr0 * CE_LD;  // + u * CE_RSTEP * CE_LD; pairs at + 2 mq, results at + mq
-#pragma unroll
-    for (int u = 0; u < CE_NIT; ++u) {
-        const int r = mr0 + CE_RSTEP * u;
-        inr[u] = tid >= 64 && r < 64;
-        ok[u] = inr[u] && r < nrows;
-        gsrc[u] = (gsrc_t)(row_in[r & 63]);
-        gdst[u] = (gdst_t)(row_out[r & 63]);
-        sa[u] = row_sa[r & 63];
-        sr[u] = row_sr[r & 63];
-    }
-    f4 setA[CE_NIT], setB[CE_NIT], vst[CE_NIT];
-
-    // loads are unconditional (addresses clamped into the stream) and masked only when they are
-    // written to LDS two iterations later: a branch around a load, or any use of its result, would
-    // make the compiler wait for it on the spot
-#define CE_GLOAD(SET, K)                                                                      \
-    {                                                                                         \
-        const int64_t t0_ = (int64_t)(K) * CE_T + mq;                                          \
-        const int64_t tc_ = (t0_ < L - 4 ? t0_ : L - 4) >> 2;                                  \
-        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u) SET[u] = gsrc[u][tc_];              \
-    }
-#define CE_LWRITE(SET, K)                                                                     \
-    {                                                                                         \
-        float *dst_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase + 2 * mq;              \
-        const bool in_ = (int64_t)(K) * CE_T + mq + 3 < L; /* masked here, not at load time */ \
-        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u) if (inr[u]) {                       \
-            const f4 x_ = (ok[u] && in_) ? SET[u] : (f4)(0.0f);                                \
-            const f4 v_ = {fabsf(x_.x), fabsf(x_.y), fabsf(x_.z), fabsf(x_.w)};                \
-            float *d_ = dst_ + u * CE_RSTEP * CE_LD;                                           \
-            *(f4 *)d_ = (f4){sa[u] * v_.x, sr[u] * v_.x, sa[u] * v_.y, sr[u] * v_.y};          \
-            *(f4 *)(d_ + 4) = (f4){sa[u] * v_.z, sr[u] * v_.z, sa[u] * v_.w, sr[u] * v_.w};    \
-        }                                                                                     \
-    }
-#define CE_GSTORE(K)                                                                          \
-    {                                                                                         \
-        const float *src_ = ring + (int)((K) % CE_SLOTS) * 64 * CE_LD + lbase + mq;            \
-        const int64_t t0_ = (int64_t)(K) * CE_T + mq;                                          \
-        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            vst[u] = *(const f4 *)(src_ + (inr[u] ? u * CE_RSTEP * CE_LD : 0));                \
-        _Pragma("unroll") for (int u = 0; u < CE_NIT; ++u)                                     \
-            if (ok[u] && t0_ + 3 < L)                                                          \
-                gdst[u][t0_ >> 2] = (f4){fabsf(vst[u].x), fabsf(vst[u].y), fabsf(vst[u].z), fabsf(vst[u].w)}; \
-    }
-    // the serial wave's tile: generated inline asm (tools/gen/gen_env_asm.py), 3.1 instructions per
-    // sample instead of the 4.25 hipcc needs for the same arithmetic (see comp_env_serial.inc)
-    auto serial_tile = [&](int64_t k) {
-        float *row = ring + (int)(k % CE_SLOTS) * 64 * CE_LD + tid * CE_LD;
-        const unsigned row_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)row;
-        STITO_COMP_ENV_SERIAL_TILE(z, c2, row_addr);
-    };
-
-    if (tid >= 64) {  // prologue: tiles 0, 1 -> registers; tile 0 -> ring; tile 2 -> registers
-        CE_GLOAD(setA, 0);
-        CE_GLOAD(setB, 1);
-        CE_LWRITE(setA, 0);
-        CE_GLOAD(setA, 2);
-    } else {
-        __builtin_amdgcn_s_setprio(3);
-    }
-    __syncthreads();
-    // iteration j: wave 0 computes tile j in place; movers write tile j+1 (loaded two iterations
-    // ago), refill that register set with tile j+3 and store tile j-1.
-    for (int64_t j = 0; j < ntiles; j += 2) {
-        if (tid >= 64) {
-            if (j + 1 < ntiles) CE_LWRITE(setB, j + 1);
-            CE_GLOAD(setB, j + 3);
-            if (j > 0) CE_GSTORE(j - 1);
-        } else {
-            serial_tile(j);
-        }
-        __syncthreads();
-        if (j + 1 >= ntiles) break;
-        if (tid >= 64) {
-            if (j + 2 < ntiles) CE_LWRITE(setA, j + 2);
-            CE_GLOAD(setA, j + 4);
-            CE_GSTORE(j);
-        } else {
-            serial_tile(j + 1);
-        }
-        __syncthreads();
-    }
-    if (tid >= 64) CE_GSTORE(ntiles - 1);
-#undef CE_GLOAD
-#undef CE_LWRITE
-#undef CE_GSTORE
-}
-
-// VCA: gain = env < thr ? 1 : pow(env/thr, 1/ratio - 1); y = gain * x.  The power goes through
-// v_log_f32 / v_exp_f32 (1 ulp each; base >= 1, |exponent| < 1: relative error < 2e-6 against powf, inside
-// the 2e-5 parity bound of the effect): the kernel is then bound by its 12 bytes per sample of HBM traffic.
-__device__ __forceinline__ float vca_gain(float e, float thr, float thr_inv, float p) {
-    return e < thr ? 1.0f : __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(e * thr_inv));
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_comp_gain(InView in, float *__restrict__ out, const float *__restrict__ env,
-                                                    int64_t cand_stride, int C, int64_t L,
-                                                    const double *__restrict__ coef) {
-    const int s = blockIdx.y;
-    const int cand = s / C, ch = s % C;
-    const float *x = in_ptr(in, cand, ch);
-    const int64_t off = (int64_t)cand * cand_stride + (int64_t)ch * L;
-    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
-    const float thr = (float)cf[0], thr_inv = (float)cf[1], p = (float)cf[2];
-    if (VEC) {
-        const float4 *x4 = (const float4 *)x, *e4 = (const float4 *)(env + off);
-        float4 *o4 = (float4 *)(out + off);
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L / 4; i += (int64_t)gridDim.x * blockDim.x) {
-            const float4 e = e4[i], v = x4[i];
-            float4 o;
-            o.x = vca_gain(e.x, thr, thr_inv, p) * v.x;
-            o.y = vca_gain(e.y, thr, thr_inv, p) * v.y;
-            o.z = vca_gain(e.z, thr, thr_inv, p) * v.z;
-            o.w = vca_gain(e.w, thr, thr_inv, p) * v.w;
-            o4[i] = o;
-        }
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x)
-            out[off + i] = vca_gain(env[off + i], thr, thr_inv, p) * x[i];
     }
 }
 
@@ -871,7 +645,7 @@ extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n
     size_t coef = align_up((size_t)(n_fx > 0 ? n_fx : 1) * pop * COEF_STRIDE * sizeof(double), 256);
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
-    size_t env = has_comp ? align_up((size_t)pop * cout * n_samples * sizeof(float), 256) : 0;
+    size_t env = has_comp ? compressor_workspace_bytes(pop * 2, n_samples) : 0;  // block functions + boundary states
     size_t cr = 0;  // convolution reverb: spectra of the input blocks and of every candidate's IR partitions
     for (int i = 0; i < n_fx; ++i)
         if (chain[i].kind == STITO_FX_NOISE_REVERB) {
@@ -946,7 +720,7 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
     float *envbuf = (float *)(ws + align_up((size_t)(n_fx > 0 ? n_fx : 1) * pop * COEF_STRIDE * sizeof(double), 256));
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
-    char *crbuf = (char *)envbuf + (has_comp ? align_up((size_t)pop * C_out * n_samples * sizeof(float), 256) : 0);
+    char *crbuf = (char *)envbuf + (has_comp ? compressor_workspace_bytes(pop * 2, n_samples) : 0);
     // per-stage peaks (normalize_stages) live in the last pop floats of the workspace
     float *stage_peaks = (float *)(ws + (need - 256 - align_up((size_t)pop * sizeof(float), 256)));
 
@@ -997,21 +771,11 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                 hipLaunchKernelGGL(k_eq, dim3(S), dim3(EQ_NC), 0, st, in, post, audio_dev, cand_stride, Cn, L, cf);
                 break;
             }
-            case STITO_FX_COMPRESSOR:
-            {
-                const size_t lds = (size_t)CE_SLOTS * 64 * CE_LD * sizeof(float) + 128 * sizeof(void *) + 128 * sizeof(float);
-                // float4 rows need 16-B aligned stream starts: every stream offset is a multiple of L
-                const bool vec = (L % 4 == 0) && (((uintptr_t)in.base & 15) == 0) && (((uintptr_t)envbuf & 15) == 0);
-                auto kern = vec ? k_comp_env<true> : k_comp_env<false>;
-                STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3((S + 63) / 64), dim3(CE_THREADS), lds, st, in, envbuf, cand_stride, Cn, L, S, cf);
-                STITO_LAUNCH_CHECK();
-            }
-                if ((L % 4 == 0) && (((uintptr_t)in.base | (uintptr_t)envbuf | (uintptr_t)audio_dev) & 15) == 0)
-                    hipLaunchKernelGGL(k_comp_gain<true>, dim3(grid_x_for(L / 4, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
-                else
-                    hipLaunchKernelGGL(k_comp_gain<false>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, envbuf, cand_stride, Cn, L, cf);
+            case STITO_FX_COMPRESSOR: {
+                const int rc = compressor_stage(in, audio_dev, cand_stride, pop, Cn, L, cf, envbuf, st);
+                if (rc) return rc;
                 break;
+            }
             case STITO_FX_DISTORTION:
                 hipLaunchKernelGGL(k_pointwise<STITO_FX_DISTORTION>, dim3(grid_x_for(L, S), S), dim3(256), 0, st, in, audio_dev, cand_stride, Cn, L, cf);
                 break;

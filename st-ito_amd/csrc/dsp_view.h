@@ -25,4 +25,9 @@ size_t conv_reverb_workspace_bytes(int n_streams, int64_t n_samples, int64_t n_t
 int conv_reverb_stage(const InView &in, float *audio_dev, int64_t cand_stride, int pop, int64_t n_samples,
                       const double *coef, const float *noise_bank, int64_t n_taps, void *workspace, hipStream_t st);
 
+// Compressor stage (compressor.hip): envelope by block composition + VCA, in place on audio_dev.
+size_t compressor_workspace_bytes(int n_streams, int64_t n_samples);
+int compressor_stage(const InView &in, float *audio_dev, int64_t cand_stride, int pop, int C, int64_t n_samples,
+                     const double *coef, void *workspace, hipStream_t st);
+
 }  // namespace stito

@@ -93,10 +93,10 @@ def test_single_effect_vs_oracle(dev, kind, chs, tol):
 def test_compressor_ballistics_corners(dev):
     """Heavy compression (threshold -40 dB, ratio 20) at the corners of the attack/release range,
     including attack slower than release (c_att > c_rel: the GPU envelope runs on z = -y there) and
-    an odd length (scalar fallback of k_comp_env).  The GPU evaluates the switching one-pole as
-    max(c_a y + (1-c_a) v, c_r y + (1-c_r) v); the oracle as v + c (y - v): the same real-number map
-    with different float32 rounding (measured here: <= 3e-7 of peak; bound 2e-5 like the other
-    compressor test)."""
+    an odd length.  The GPU evaluates the switching one-pole as max(c_a y + (1-c_a) v, c_r y + (1-c_r) v)
+    and crosses 15-sample blocks with their composed (max, +) block functions (compressor.hip); the oracle
+    walks v + c (y - v) sample by sample: the same real-number map with different float32 rounding
+    (measured here: <= 3e-7 of peak; bound 2e-5 like the other compressor test)."""
     op, pp = _plugins_pair(["Compressor"])
     raw = lambda v, lo, hi: (v - lo) / (hi - lo)
     rows = []
@@ -113,6 +113,33 @@ def test_compressor_ballistics_corners(dev):
             err = np.abs(got[p] - ref).max() / max(1.0, np.abs(ref).max())
             print(f"compressor att/rel corner {p} n={n}: err {err:.3e}")
             assert err < 2e-5
+
+
+@pytest.mark.parametrize("n", [1, 14, 15, 16, 29, 30, 31, 479, 480, 481, 495, 7681])
+def test_compressor_block_boundaries(dev, n):
+    """Lengths around the compressor's block structure: shorter than one 15-sample block (no block function at
+    all), exact multiples, one sample either side, one register ring of 32 blocks (480 samples) +- 1, one past
+    a 256-block apply tile + ring; 3 candidates x 1 channel = 3 streams (a partly idle quad group) and
+    9 x 2 = 18 streams (two serial waves, the second nearly idle).
+
+    Attack times are kept <= 10 ms here.  With a slow attack the first samples of the reference's own recurrence,
+    v + c (y - v) with c within 1e-3 of 1 and y << v, carry rounding noise of ulp(v) / y ~ 1e-5 relative, which
+    the gain computer passes on (measured 3.6e-5 of peak at n = 16, attack 67 ms): there the reference's output is
+    its own float32 noise and no other order of operations reproduces it.  The GPU walks the first block in the
+    reference's order (bit-identical) and starts every later block from the (max, +) boundary state;
+    test_compressor_ballistics_corners covers the slow-attack corners on full-length audio."""
+    op, pp = _plugins_pair(["Compressor"])
+    rng = np.random.default_rng(n)
+    for P, chs in ((3, 1), (9, 2)):
+        x = (0.7 * rng.standard_normal((chs, n))).astype(np.float32)
+        W = rng.random((P, 4))
+        W[:, 0] = rng.uniform(0.3, 0.6, P)  # thresholds -56 .. -32 dB: always compressing
+        W[:, 2] = rng.uniform(0.0, 0.099, P)  # attack 0.1 .. 10 ms
+        got, _ = _render_gpu(pp, x, W, dev, normalize=False)
+        for p in range(P):
+            ref = _oracle_chain_raw(op, x, W[p])
+            err = np.abs(got[p] - ref).max() / max(1.0, np.abs(ref).max())
+            assert got[p].shape == ref.shape and err < 2e-5, f"n={n} P={P} cand {p}: {err:.3e}"
 
 
 def _noise_reverb_pair(n_taps, taps=255):
