@@ -99,7 +99,7 @@ def pmc_traffic_per_launch(n_streams):
     return float(d["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(PMC_TRAFFIC_JSON)}"
 
 
-ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)"}
+ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)", 3: "winograd F(4x4,3x3), input transform hoisted (two kernels)"}
 
 
 def conv_layer_times(model, n_streams, T, reps=3):
@@ -142,16 +142,18 @@ def conv_layer_times(model, n_streams, T, reps=3):
                                mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)))
             cur = out
             continue
-        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2) else 1
+        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3) else 1
         wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], walgo)
         algo = walgo if wino else 0
+        wsb = L.stito_conv3x3_workspace_bytes(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         args = (_hip.ptr(cur), W.conv_wino_dev[i] if wino else W.conv_w_dev[i], W.bn_scale_dev[i], W.bn_shift_dev[i],
-                _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo, st)
-        _hip.check(L.stito_conv3x3_bn_relu(*args))  # warm
+                _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo, _hip.ptr(ws), wsb, st)
+        _hip.check(L.stito_conv3x3_bn_relu_ws(*args))  # warm
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in ev:
             a.record()
-            _hip.check(L.stito_conv3x3_bn_relu(*args))
+            _hip.check(L.stito_conv3x3_bn_relu_ws(*args))
             b.record()
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))

@@ -76,7 +76,8 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 3 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo). */
+/* ABI version: 4 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+ * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
@@ -168,7 +169,12 @@ int stito_logmel(const stito_frontend *fe, const float *audio_dev, const float *
  * Winograd F(4x4,3x3) (36 MACs per 4x4 outputs instead of 144: 4x fewer than direct, 1.78x fewer than F(2x2,3x3)).
  * Both Winograd forms need cin % 8 == 0, cout % 64 == 0 and a feature map whose halo patch fits LDS
  * (stito_conv3x3_supported). */
-enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 2 };
+enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 2,
+       /* F(4x4,3x3) with the input transform hoisted out of the convolution: one pass writes the transformed input tiles
+        * to a workspace, the convolution streams them like the weights.  Same packed weights as STITO_CONV_WINOGRAD_F4,
+        * same arithmetic and results; pays off when cout >= 512 (the workgroups that share a pixel block and differ only
+        * in their 64 output channels no longer repeat the transform).  Needs stito_conv3x3_bn_relu_ws (ABI version 4). */
+       STITO_CONV_WINOGRAD_F4_PRE = 3 };
 
 typedef struct {
     int32_t embed_dim;
@@ -180,7 +186,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD or STITO_CONV_WINOGRAD_F4 (ABI version 3) */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4 or _F4_PRE (the latter two share a packing) */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -248,6 +254,12 @@ int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, in
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
+/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE: the transformed input,
+ * stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
+size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo);
+int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
+                             const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
+                             int pool, int algo, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---- hand-crafted features: st_ito/features.py (alternative metrics of the evaluation harness) ---- */
 /* compute_rms_energy (features.py:235-245) and compute_crest_factor (248-264) of (n_items, channels, n) audio

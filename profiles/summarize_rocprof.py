@@ -13,10 +13,13 @@ for path in sys.argv[1:]:
     print(f"{'kernel':100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
     for r in rows:
         print(f"{r[0][:100]:100s} {r[1]:6d} {r[2]:10.3f} {r[3]:10.1f} {r[4]:10.1f} {r[5]:10.1f} {100 * r[2] / tot:6.2f}")
-    # The roofline kernel family as bench.py counts it: every MFMA 3x3-conv launch of a full-size trunk pass (all template
-    # instances together; the < 1 ms launches are the 2-stream target-embedding pass, not part of a step).
-    n, avg, total = cur.execute("select count(*), avg(end-start)/1e6, sum(end-start)/1e6 from kernels "
-                                "where name like '%k_conv_wino%' and (end-start) > 1e6").fetchone()
+    # The roofline kernel family as bench.py counts it: the 11 MFMA 3x3-conv layers of every full-size trunk pass.  A layer is
+    # one k_conv_wino* launch (> 1 ms at full size), plus -- where the F(4x4,3x3) input transform is hoisted -- its transform
+    # pass (template MODE 2, > 0.08 ms at full size; the 2-stream target-embedding pass is far below both thresholds).
+    n, total = cur.execute("select count(*), sum(end-start)/1e6 from kernels where name like '%k_conv_wino%' and (end-start) > 1e6").fetchone()
+    n2, total2 = cur.execute("select count(*), sum(end-start)/1e6 from kernels where name like '%k_conv_wino43%false, 2>%' "
+                             "and (end-start) > 8e4 and (end-start) <= 1e6").fetchone()
     if n:
-        print(f"# MFMA conv family (k_conv_wino*, launches > 1 ms): {n} launches, avg {avg:.4f} ms, total {total:.2f} ms"
-              f"   <- compare with roofline.avg_launch_ms of the bench line")
+        total += total2 or 0.0
+        print(f"# MFMA conv family (k_conv_wino*): {n} conv layers ({n2} of them with a separate transform pass), avg {total / n:.4f} ms per layer, "
+              f"total {total:.2f} ms   <- compare with roofline.avg_launch_ms of the bench line")

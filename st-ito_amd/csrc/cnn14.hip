@@ -1026,11 +1026,11 @@ using namespace stito;
 static bool wino_ok(int cout, int cin) { return cin % WK == 0 && cout % 64 == 0; }
 
 extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo) {
-    return (size_t)cout * cin * (algo == STITO_CONV_WINOGRAD_F4 ? 36 : algo == STITO_CONV_WINOGRAD ? 16 : 9);
+    return (size_t)cout * cin * ((algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) ? 36 : algo == STITO_CONV_WINOGRAD ? 16 : 9);
 }
 
 extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream) {
-    if (algo == STITO_CONV_WINOGRAD_F4) {
+    if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) {  // one packing for both
         STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
         return pack_wino43(w_oihw_dev, cout, cin, packed_dev, (hipStream_t)stream);
     }
@@ -1086,7 +1086,7 @@ extern "C" int stito_debug_wino_trace(long long *buf_dev) {
 extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo) {
     if (n <= 0 || H <= 0 || W <= 0 || cout % 4 != 0) return 0;
     if (pool && (H < 2 || W < 2)) return 0;
-    if (algo == STITO_CONV_WINOGRAD_F4) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
+    if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD) return wino_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (cin == 1) return (!pool && cout % 8 == 0) ? 1 : 0;
     return (cin % 8 == 0 && cout % 64 == 0) ? 1 : 0;  // channel-blocked activations: 8 channels per block
@@ -1097,7 +1097,7 @@ extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, i
 extern "C" double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int cout, int pool, int algo) {
     if (!stito_conv3x3_supported(n, H, W, cin, cout, pool, algo) || cin % 8 != 0) return 0.0;
     ConvShape c{n, H, W, cin, cout};
-    if (algo == STITO_CONV_WINOGRAD_F4) return wino43_issued_flops(c, pool != 0);
+    if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_issued_flops(c, pool != 0);
     if (algo == STITO_CONV_WINOGRAD) {
         WinoGeom g;
         size_t lds;
@@ -1120,6 +1120,7 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
                                      int pool, int algo, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
+    STITO_REQUIRE(algo != STITO_CONV_WINOGRAD_F4_PRE, STITO_E_WORKSPACE, "conv: STITO_CONV_WINOGRAD_F4_PRE needs stito_conv3x3_bn_relu_ws");
     if (cin % 8 != 0) {
         STITO_REQUIRE(cin == 1 && !pool, STITO_E_UNSUPPORTED, "conv: cin=%d (only 1 or a multiple of 8)", cin);
         return conv_first(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cout, st);
@@ -1144,10 +1145,40 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
                 : launch_conv_tw<4, 1, false>(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, g, st);
 }
 
+extern "C" size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo) {
+    if (algo != STITO_CONV_WINOGRAD_F4_PRE || !stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)) return 0;
+    return wino43_pre_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
+}
+
+extern "C" int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
+                                        const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
+                                        int pool, int algo, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (algo != STITO_CONV_WINOGRAD_F4_PRE)
+        return stito_conv3x3_bn_relu(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cin, cout, pool, algo, stream);
+    STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
+    STITO_REQUIRE(cin % 8 == 0 && cout % 64 == 0 && wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
+    STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
+    return launch_wino43_pre(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
+                             (float *)workspace_dev, workspace_bytes, (hipStream_t)stream);
+}
+
 static void cnn14_dims(int64_t T, int M, int H[7], int W[7]) {
     H[0] = (int)T; W[0] = M;
     for (int b = 1; b <= 5; ++b) { H[b] = H[b - 1] / 2; W[b] = W[b - 1] / 2; }
     H[6] = H[5]; W[6] = W[5];
+}
+
+// transformed-input workspace: the largest need among the layers that run STITO_CONV_WINOGRAD_F4_PRE
+static size_t cnn14_pre_bytes(const stito_cnn14_weights *w, int n_streams, const int H[7], const int W[7]) {
+    size_t v = 0;
+    for (int i = 0; i < STITO_CNN14_NUM_CONVS; ++i) {
+        if (w->conv_wino_dev[i] == nullptr || w->conv_wino_algo[i] != STITO_CONV_WINOGRAD_F4_PRE) continue;
+        const int blk = i / 2, j = i % 2;
+        const int ci = j == 0 ? w->channels[blk] : w->channels[blk + 1], pool = (j == 1 && blk < 5) ? 1 : 0;
+        const size_t need = stito_conv3x3_workspace_bytes(n_streams, H[blk], W[blk], ci, w->channels[blk + 1], pool, STITO_CONV_WINOGRAD_F4_PRE);
+        v = need > v ? need : v;
+    }
+    return align_up(v, 256);
 }
 
 extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int n_streams, int64_t n_frames) {
@@ -1161,7 +1192,7 @@ extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int 
         b = pooled > b ? pooled : b;
     }
     const size_t feat = (size_t)n_streams * w->channels[6];
-    return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + 256;
+    return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + cnn14_pre_bytes(w, n_streams, H, W) + 256;
 }
 
 // ---- optional launch timing for bench.py: HIP events on the launch stream around the MFMA convs ----
@@ -1218,6 +1249,8 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     float *actA = (float *)ws;
     float *actB = (float *)(ws + align_up(a * 4, 256));
     float *feat = (float *)(ws + align_up(a * 4, 256) + align_up(b * 4, 256));
+    const size_t vbytes = cnn14_pre_bytes(w, S, H, W);
+    void *vbuf = ws + align_up(a * 4, 256) + align_up(b * 4, 256) + align_up((size_t)S * w->channels[6] * 4, 256);
 
     const float *cur = logmel_dev;
     // conv_block1 as one launch when the fused first-conv weights and an F(4x4,3x3) packing of its second conv are there
@@ -1248,7 +1281,8 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             const int i = 2 * blk + j;
             const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
             // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
-            const int walgo = w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 ? STITO_CONV_WINOGRAD_F4 : STITO_CONV_WINOGRAD;
+            const int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE)
+                                  ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;
             const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
             const bool timed = g_conv_timing.on && ci % 8 == 0;
             if (timed) {
@@ -1260,9 +1294,9 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                 }
                 STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
             }
-            const int rc = stito_conv3x3_bn_relu(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
-                                                 w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
-                                                 wino ? walgo : STITO_CONV_DIRECT, stream);
+            const int rc = stito_conv3x3_bn_relu_ws(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
+                                                    w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
+                                                    wino ? walgo : STITO_CONV_DIRECT, vbuf, vbytes, stream);
             if (rc) return rc;
             if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
         }

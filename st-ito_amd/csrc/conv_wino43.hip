@@ -55,6 +55,7 @@ struct Wino43Geom {
     int n_col_blocks;
     int Ho, Wo;        // output map (pooled when POOL)
     int PR;            // halo patch rows
+    int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
     long long *trace;  // TRACE instantiation only
     // FUSE1 instantiation (conv_block1: the Cin = 1 first conv computed on the fly while staging the patch):
     const float *fw;   // first-conv weights, BN scale folded, packed [16 chunks][9 taps][4 channels]
@@ -122,7 +123,12 @@ __device__ __forceinline__ f32x2 pk_mul_lo(f32x2 x, f32x2 c) {
     return d;
 }
 
-template <int TTW, bool POOL, bool TRACE, bool FUSE1 = false>
+// MODE 0: the whole convolution (patch -> V in the workgroup).  The workgroups of one pixel block that differ only in their
+// 64 output channels all repeat the same input transform (8 .. 32 times for Cout >= 512), and it is paid in the same
+// ALUs the f32 MFMAs run on; for those layers the transform is hoisted: MODE 2 runs the production pipeline alone (one
+// workgroup per pixel block, no weights, no MFMAs) and writes every chunk's V slab -- in exactly the LDS layout -- to HBM,
+// MODE 1 is the convolution with `in` = those slabs: V(k) arrives by LDS-DMA like U(k), nothing is transformed.
+template <int TTW, bool POOL, bool TRACE, bool FUSE1 = false, int MODE = 0>
 __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__restrict__ in, const float *__restrict__ upk,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, float *__restrict__ out,
@@ -133,18 +139,23 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
     constexpr int PFL = PL::PFL;      // floats per patch buffer
     constexpr int BUF = W43_BUF;
+    constexpr bool PREV = MODE == 1, VOUT = MODE == 2;
+    static_assert(!(FUSE1 && MODE != 0), "the fused first conv only exists for MODE 0");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_tiles = g.Cout / 64;
+    const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
     const int m_blk = blockIdx.x / n_tiles;  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    const int n0 = (blockIdx.x % n_tiles) * 64;
+    const int n0 = VOUT ? 0 : (blockIdx.x % n_tiles) * 64;
     const int cb = m_blk % g.n_col_blocks;
     const int rb = m_blk / g.n_col_blocks;
     const int vtr0 = rb * TTH;  // first virtual tile row (s * TR + tr) of the block
     const int tc0 = cb * TTW;
-    const int n_chunks = g.Cin / W43_K;
+    // MODE 2: this workgroup transforms chunks c_base .. c_base + n_chunks - 1 of the pixel block (an even count >= 2)
+    const int n_chunks_all = g.Cin / W43_K;
+    const int n_chunks = VOUT ? n_chunks_all / g.n_cgroups : n_chunks_all;
+    const int c_base = VOUT ? (blockIdx.x % n_tiles) * n_chunks : 0;
     float *patch0 = smem + 2 * BUF;
     const int iv_lo = (vtr0 / g.TR) * g.H + 4 * (vtr0 % g.TR) - 1;  // input virtual row (s*H + h) of patch row 0
 
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     int roff[4];     // float offsets (inside a patch buffer) of the four input rows the lane's row i combines, at tile column 0
     f32x2 cab, ccd;  // their coefficients (a, b), (c, d); 0 for rows outside the map / stream
     int vdst;
-    {
+    if constexpr (!PREV) {
         int ti, tile, cp;
         if (lane < 32) {
             ti = wv >> 1; tile = (wv & 1) * 16 + (lane & 15); cp = lane >> 4;
@@ -210,15 +221,16 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     const int64_t u_pos_stride = (int64_t)g.Cout * W43_K, u_chunk_stride = 36 * u_pos_stride;  // floats
     const unsigned u_voff = (unsigned)((lane & 31) * 16 + (lane >> 5) * g.Cout * 8);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const float *v_base = in + (int64_t)m_blk * n_chunks_all * W43_V;  // PREV: this pixel block's V slabs
 
     // ---- halo patch staging by LDS-DMA: slot q = tid + 512 j of the permuted layout (W43Patch) holds pixel (pr, pc) ------
     const int s_first = (iv_lo < 0 ? 0 : iv_lo) / g.H;
-    const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W);
     const int64_t plane8 = (int64_t)g.H * g.W * 8;  // floats per 8-channel plane of one stream
+    const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W) + (int64_t)(c_base >> 1) * plane8;
     unsigned p_off[NPL];                             // per-lane byte offset from the chunk's base
     uint64_t p_mask[NPL];                            // lanes of this wave that have a pixel (wave-uniform)
     int f_win[NPL], f_dst[NPL];                      // FUSE1: window offset of the pixel's 3x3 neighbourhood, patch-buffer destination
-    {
+    if constexpr (!PREV) {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int q = tid + W43_THREADS * j;
@@ -267,6 +279,23 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         const int ii = wv + 8 * (J_) < 36 ? wv + 8 * (J_) : wv + 8 * (J_) - 8;                           \
         glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + ii * u_pos_stride, u_voff,                   \
                   lds0 + (unsigned)((BOFF) + ii * 64 * W43_K) * 4u);                                     \
+    }
+// PREV: V slab of chunk CH (18 KB, already in the LDS layout) -> V region of buffer BOFF: 18 copies of 1 KB, J = 0..2 per wave
+#define W43_COPY_V1(CH, BOFF, J_)                                                                        \
+    {                                                                                                    \
+        const int ii = wv + 8 * (J_) < 18 ? wv + 8 * (J_) : wv + 8 * (J_) - 8;                           \
+        glds16_m0(v_base + (int64_t)(CH) * W43_V + ii * 256, (unsigned)lane * 16u,                       \
+                  lds0 + (unsigned)((BOFF) + W43_U + ii * 256) * 4u);                                    \
+    }
+// VOUT: V(k) (complete in the current buffer since the last barrier) -> HBM
+#define W43_STORE_V(K_, CUR)                                                                             \
+    {                                                                                                    \
+        f32x4 *vo_ = (f32x4 *)(out + ((int64_t)m_blk * n_chunks_all + c_base + (K_)) * W43_V);                        \
+        const f32x4 *vs_ = (const f32x4 *)(smem + (CUR) + W43_U);                                        \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+            const int e_ = tid + W43_THREADS * j;                                                        \
+            if (e_ < W43_V / 4) vo_[e_] = vs_[e_];                                                       \
+        }                                                                                                \
     }
 // patch(CH) -> patch buffer PB (0, 1): two masked LDS-DMA instructions per wave (pixels wv*64 + 512 j + lane)
 #define W43_COPY_P(CH, PB)                                                                              \
@@ -319,8 +348,16 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             S##b[t_] = *(const f32x2 *)((SB) + b_off + (3 * (G) + t_) * 64 * W43_K);                     \
         }                                                                                                \
     }
+// The MFMA intrinsics have no side effects, so nothing ties them to the fences: with little else in a gap (MODE 1 has only
+// copies there) hipcc lets them drift and clumps them behind the waits -- measured: the hoisted transform then buys nothing.
+// An empty volatile asm that "touches" the accumulator before and after pins each one between the neighbouring pieces.
+// (The MFMA itself as inline asm gave wrong sums: hipcc does not apply its MFMA hazard handling to opaque asm.)
 #define W43_MFMA(S, G, T_, E_)                                                                          \
-    acc[3 * (G) + (T_)] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[T_][E_], S##b[T_][E_], acc[3 * (G) + (T_)], 0, 0, 0);
+    if constexpr (!VOUT) {                                                                              \
+        asm volatile("" : "+v"(acc[3 * (G) + (T_)]));                                                   \
+        acc[3 * (G) + (T_)] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[T_][E_], S##b[T_][E_], acc[3 * (G) + (T_)], 0, 0, 0); \
+        asm volatile("" : "+v"(acc[3 * (G) + (T_)]));                                                   \
+    }
 #define W43_FENCE() __builtin_amdgcn_sched_barrier(0);
 #define W43_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define W43_GAP(S, G, T_, E_, WORK) W43_MFMA(S, G, T_, E_) WORK W43_FENCE()
@@ -331,12 +368,17 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     f32x2 tT[6], rX[4], rY[4];
-    f32x2 xa[3], xb[3], ya[3], yb[3];
+    f32x2 xa[3], xb[3], ya[3], yb[3], za[3], zb[3];  // z: PREV only
 
     // ---- prologue: patch(0), patch(1), U(0) by LDS-DMA, issued first; meanwhile every thread zeroes the slots of both patch
     // buffers that ITS copy lane never writes (= the padding: no overlap with any copy, so no barrier in between); V(0) from patch(0)
+    if constexpr (PREV) {  // V(0), U(0) by LDS-DMA; nothing to transform
+        W43_COPY_V1(0, 0, 0) W43_COPY_V1(0, 0, 1) W43_COPY_V1(0, 0, 2)
+        W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     if (!FUSE1) W43_COPY_P(0, 0)
-    W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4)
+    if (!VOUT) { W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4) }
     if (!FUSE1) W43_COPY_P(1, 1)
     if (FUSE1) {
         // raw log-mel window (1 channel) of the block: rows in padded virtual-row space from pv0, columns from 4 tc0 - 2
@@ -372,6 +414,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     W43_T_ROW(4, rX) W43_T_ROW(5, rY)
     W43_T_COLS_A(0)
     W43_T_COLS_B(0)
+    }
     W43_BARRIER()  // B(-1): V(0), U(0) complete
     W43_STAMP(1)
 
@@ -379,55 +422,79 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 // S0 holds group 2 of the previous chunk on entry; the sets alternate S0, S1, S0 and the next period starts on S1.
 // MORE: chunk k+1 exists -- its production (U copies, transform) and the patch copy of chunk k+2 are spread over the first
 // MFMA gaps; patch(c) lives in buffer c % 2.
-#define W43_PERIOD(S0, S1, FIRST, MORE)                                                                 \
+#define W43_OPS(X) if (!VOUT && !(W43_ABL & 8)) { X }
+#define W43_UCP(X) if (!VOUT && MORE_ && !(W43_ABL & 2)) { X }
+#define W43_TRF(X) if (!PREV && MORE_ && !(W43_ABL & 1)) { X }
+#define W43_PERIOD4(P2, G0, G1, N2, FIRST, MORE)                                                                 \
     {                                                                                                   \
+        constexpr bool MORE_ = MORE;                                                                     \
         const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
         const float *sb = smem + cur;                                                                    \
         const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
+        if (VOUT) W43_STORE_V(k, cur)                                                                    \
         if (!(FIRST)) {                                                                                  \
-            W43_GAP(S0, 2, 0, 0, if (MORE && !(W43_ABL & 4)) { if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) } else W43_COPY_P(k + 2, k & 1) }) \
-            W43_GAP(S0, 2, 1, 0, if (!(W43_ABL & 8)) W43_LOAD_OPS(S1, sb, 0) if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 0))           \
-            W43_GAP(S0, 2, 2, 0, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 1))                                   \
-            W43_GAP(S0, 2, 0, 1, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 2))                                   \
-            W43_GAP(S0, 2, 1, 1, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 3))                                   \
-            W43_GAP(S0, 2, 2, 1, if (MORE && !(W43_ABL & 2)) W43_COPY_U1(k + 1, nxt, 4))                                   \
+            W43_GAP(P2, 2, 0, 0, if (MORE_ && !(W43_ABL & 4)) { if (PREV) { W43_COPY_V1(k + 1, nxt, 0) } else if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) } else W43_COPY_P(k + 2, k & 1) }) \
+            W43_GAP(P2, 2, 1, 0, W43_OPS(W43_LOAD_OPS(G0, sb, 0)) W43_UCP(W43_COPY_U1(k + 1, nxt, 0)))   \
+            W43_GAP(P2, 2, 2, 0, W43_UCP(W43_COPY_U1(k + 1, nxt, 1)))                                    \
+            W43_GAP(P2, 2, 0, 1, W43_UCP(W43_COPY_U1(k + 1, nxt, 2)))                                    \
+            W43_GAP(P2, 2, 1, 1, W43_UCP(W43_COPY_U1(k + 1, nxt, 3)))                                    \
+            W43_GAP(P2, 2, 2, 1, W43_UCP(W43_COPY_U1(k + 1, nxt, 4)))                                    \
         } else {                                                                                         \
-            if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) W43_MAKE_P1(k + 2, k & 1, 1) } else W43_COPY_P(k + 2, k & 1)          \
-            if (!(W43_ABL & 8)) W43_LOAD_OPS(S1, sb, 0)                                                                      \
-            W43_COPY_U1(k + 1, nxt, 0) W43_COPY_U1(k + 1, nxt, 1) W43_COPY_U1(k + 1, nxt, 2)             \
-            W43_COPY_U1(k + 1, nxt, 3) W43_COPY_U1(k + 1, nxt, 4)                                        \
+            if (PREV) { W43_COPY_V1(k + 1, nxt, 0) W43_COPY_V1(k + 1, nxt, 1) W43_COPY_V1(k + 1, nxt, 2) } \
+            else if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) W43_MAKE_P1(k + 2, k & 1, 1) } else W43_COPY_P(k + 2, k & 1) \
+            W43_OPS(W43_LOAD_OPS(G0, sb, 0))                                                             \
+            W43_UCP(W43_COPY_U1(k + 1, nxt, 0) W43_COPY_U1(k + 1, nxt, 1) W43_COPY_U1(k + 1, nxt, 2)     \
+                    W43_COPY_U1(k + 1, nxt, 3) W43_COPY_U1(k + 1, nxt, 4))                               \
             W43_FENCE()                                                                                  \
         }                                                                                                \
-        W43_GAP(S1, 0, 0, 0, if (!(W43_ABL & 8)) W43_LOAD_OPS(S0, sb, 1))                                                    \
-        W43_GAP(S1, 0, 1, 0, if (MORE && !(W43_ABL & 1)) { W43_T_RD(pb_r, 0, rX) W43_T_RD(pb_r, 1, rY) })                  \
-        W43_GAP(S1, 0, 2, 0, if (FUSE1 && MORE && !(FIRST)) W43_MAKE_P1(k + 2, k & 1, 1))               \
-        W43_GAP(S1, 0, 0, 1, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(0, rX) W43_T_RD(pb_r, 2, rX) })                       \
-        W43_GAP(S1, 0, 1, 1, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(1, rY) W43_T_RD(pb_r, 3, rY) })                       \
-        W43_GAP(S1, 0, 2, 1, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(2, rX) W43_T_RD(pb_r, 4, rX) })                       \
-        W43_GAP(S0, 1, 0, 0, if (!(W43_ABL & 8)) W43_LOAD_OPS(S1, sb, 2))                                                    \
-        W43_GAP(S0, 1, 1, 0, if (MORE && !(W43_ABL & 1)) { W43_T_ROW(3, rY) W43_T_RD(pb_r, 5, rY) })                       \
-        W43_GAP(S0, 1, 2, 0, if (MORE && !(W43_ABL & 1)) W43_T_ROW(4, rX))                                                 \
-        W43_GAP(S0, 1, 0, 1, if (MORE && !(W43_ABL & 1)) W43_T_ROW(5, rY))                                                 \
-        W43_GAP(S0, 1, 1, 1, if (MORE && !(W43_ABL & 1)) W43_T_COLS_A(nxt))                                                \
-        W43_GAP(S0, 1, 2, 1, if (MORE && !(W43_ABL & 1)) W43_T_COLS_B(nxt))                                                \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* U(k+1), patch(k+2) landed (no partial waits: see the header) */ \
+        W43_GAP(G0, 0, 0, 0, W43_OPS(W43_LOAD_OPS(G1, sb, 1)))                                           \
+        W43_GAP(G0, 0, 1, 0, W43_TRF(W43_T_RD(pb_r, 0, rX) W43_T_RD(pb_r, 1, rY)) if (PREV && MORE_ && !(FIRST)) W43_COPY_V1(k + 1, nxt, 1)) \
+        W43_GAP(G0, 0, 2, 0, if (FUSE1 && MORE_ && !(FIRST)) W43_MAKE_P1(k + 2, k & 1, 1) if (PREV && MORE_ && !(FIRST)) W43_COPY_V1(k + 1, nxt, 2)) \
+        W43_GAP(G0, 0, 0, 1, W43_TRF(W43_T_ROW(0, rX) W43_T_RD(pb_r, 2, rX)))                            \
+        W43_GAP(G0, 0, 1, 1, W43_TRF(W43_T_ROW(1, rY) W43_T_RD(pb_r, 3, rY)))                            \
+        W43_GAP(G0, 0, 2, 1, W43_TRF(W43_T_ROW(2, rX) W43_T_RD(pb_r, 4, rX)))                            \
+        W43_GAP(G1, 1, 0, 0, W43_OPS(W43_LOAD_OPS(N2, sb, 2)))                                           \
+        W43_GAP(G1, 1, 1, 0, W43_TRF(W43_T_ROW(3, rY) W43_T_RD(pb_r, 5, rY)))                            \
+        W43_GAP(G1, 1, 2, 0, W43_TRF(W43_T_ROW(4, rX)))                                                  \
+        W43_GAP(G1, 1, 0, 1, W43_TRF(W43_T_ROW(5, rY)))                                                  \
+        W43_GAP(G1, 1, 1, 1, W43_TRF(W43_T_COLS_A(nxt)))                                                 \
+        W43_GAP(G1, 1, 2, 1, W43_TRF(W43_T_COLS_B(nxt)))                                                 \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* U(k+1), patch(k+2) / V(k+1) landed (no partial waits: see the header) */ \
         W43_BARRIER()                                     /* B(k) */                                     \
         if (TRACE && k < 12) { W43_STAMP(4 + k) }                                                        \
     }
 
+// two operand sets alternate (MODE 0 / 2: register budget); group 2 of the chunk waits in S1 for the next period, which names it S0
+#define W43_PERIOD(S0, S1, FIRST, MORE) W43_PERIOD4(S0, S1, S0, S1, FIRST, MORE)
+
     {
         // n_chunks is even and >= 2 (Cin % 8 == 0).  Periods 0 .. n_chunks-2 produce the next chunk; the last one does not.
         int k = 0;
-        W43_PERIOD(x, y, true, true)  // leaves group 2 of chunk 0 in set y
-        for (k = 1; k + 2 < n_chunks; k += 2) {
-            W43_PERIOD(y, x, false, true)
-            ++k;
-            W43_PERIOD(x, y, false, true)
-            --k;
+        if constexpr (PREV) {
+            // one operand set per block group (there are registers to spare without the transform): every period is the same code
+            W43_PERIOD4(z, x, y, z, true, true)
+            for (k = 1; k + 2 < n_chunks; k += 2) {  // two periods per trip: the buffer parity is a compile-time constant
+                W43_PERIOD4(z, x, y, z, false, true)
+                ++k;
+                W43_PERIOD4(z, x, y, z, false, true)
+                --k;
+            }
+            W43_PERIOD4(z, x, y, z, false, false)  // k = n_chunks - 1
+            W43_MFMA(z, 2, 0, 0) W43_MFMA(z, 2, 1, 0) W43_MFMA(z, 2, 2, 0)
+            W43_MFMA(z, 2, 0, 1) W43_MFMA(z, 2, 1, 1) W43_MFMA(z, 2, 2, 1)
+        } else {
+            W43_PERIOD(x, y, true, true)  // leaves group 2 of chunk 0 in set y
+            for (k = 1; k + 2 < n_chunks; k += 2) {
+                W43_PERIOD(y, x, false, true)
+                ++k;
+                W43_PERIOD(x, y, false, true)
+                --k;
+            }
+            W43_PERIOD(y, x, false, false)  // k = n_chunks - 1
+            if constexpr (VOUT) return;  // every V slab is in HBM
+            W43_MFMA(x, 2, 0, 0) W43_MFMA(x, 2, 1, 0) W43_MFMA(x, 2, 2, 0)
+            W43_MFMA(x, 2, 0, 1) W43_MFMA(x, 2, 1, 1) W43_MFMA(x, 2, 2, 1)
         }
-        W43_PERIOD(y, x, false, false)  // k = n_chunks - 1
-        W43_MFMA(x, 2, 0, 0) W43_MFMA(x, 2, 1, 0) W43_MFMA(x, 2, 2, 0)
-        W43_MFMA(x, 2, 0, 1) W43_MFMA(x, 2, 1, 1) W43_MFMA(x, 2, 2, 1)
     }
     W43_STAMP(2)
 
@@ -559,6 +626,7 @@ static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &l
     constexpr int TTH = 32 / TTW;
     g = Wino43Geom{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
+    g.n_cgroups = 1;
     g.Ho = pool ? c.H / 2 : c.H;
     g.Wo = pool ? c.W / 2 : c.W;
     g.TR = pool ? (g.Ho + 1) / 2 : (c.H + 3) / 4;
@@ -680,6 +748,68 @@ int launch_wino43(const float *in, const float *upk, const float *scale, const f
         case 4: return pool ? launch_w43<4, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<4, false>(in, upk, scale, shift, out, c, trace, st);
         case 2: return pool ? launch_w43<2, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<2, false>(in, upk, scale, shift, out, c, trace, st);
         default: return pool ? launch_w43<1, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<1, false>(in, upk, scale, shift, out, c, trace, st);
+    }
+}
+
+// Hoisted input transform (MODE 2 then MODE 1): V slabs [pixel block][cin/4][36][pair][32][2] in `vbuf`.
+template <int TTW>
+static size_t w43_pre_bytes(const ConvShape &c, bool pool) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    if (!w43_geometry<TTW>(c, pool, g, lds, blocks)) return 0;
+    return (size_t)(blocks / (c.Cout / 64)) * (size_t)(c.Cin / W43_K) * W43_V * sizeof(float);
+}
+
+size_t wino43_pre_workspace_bytes(const ConvShape &c, bool pool) {
+    if (!wino43_supported(c, pool)) return 0;
+    switch (w43_ttw(c, pool)) {
+        case 8: return w43_pre_bytes<8>(c, pool);
+        case 4: return w43_pre_bytes<4>(c, pool);
+        case 2: return w43_pre_bytes<2>(c, pool);
+        default: return w43_pre_bytes<1>(c, pool);
+    }
+}
+
+template <int TTW, bool POOL>
+static int launch_w43_pre(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                          float *vbuf, hipStream_t st) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
+    {   // V slabs: the chunks of a pixel block split over as many workgroups as it takes to fill the chip a few times
+        Wino43Geom gv = g;
+        const int64_t m_blocks = blocks / (c.Cout / 64);
+        const int n_chunks = c.Cin / W43_K;
+        int ncg = 1;
+        while (m_blocks * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;  // even share, >= 4 chunks
+        gv.n_cgroups = ncg;
+        auto kern = k_conv_wino43<TTW, POOL, false, false, 2>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds, st, in, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, vbuf, gv);
+        STITO_LAUNCH_CHECK();
+    }
+    auto kern = k_conv_wino43<TTW, POOL, false, false, 1>;
+    const size_t lds1 = (size_t)2 * W43_BUF * sizeof(float);
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const float *)vbuf, upk, scale, shift, out, g);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+int launch_wino43_pre(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                      bool pool, float *vbuf, size_t vbuf_bytes, hipStream_t st) {
+    const size_t need = wino43_pre_workspace_bytes(c, pool);
+    STITO_REQUIRE(need > 0 && vbuf != nullptr && vbuf_bytes >= need, STITO_E_WORKSPACE,
+                  "conv (winograd F(4x4,3x3), hoisted input transform): workspace have %zu need %zu", vbuf_bytes, need);
+    switch (w43_ttw(c, pool)) {
+        case 8: return pool ? launch_w43_pre<8, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<8, false>(in, upk, scale, shift, out, c, vbuf, st);
+        case 4: return pool ? launch_w43_pre<4, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<4, false>(in, upk, scale, shift, out, c, vbuf, st);
+        case 2: return pool ? launch_w43_pre<2, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<2, false>(in, upk, scale, shift, out, c, vbuf, st);
+        default: return pool ? launch_w43_pre<1, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<1, false>(in, upk, scale, shift, out, c, vbuf, st);
     }
 }
 

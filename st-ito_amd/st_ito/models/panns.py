@@ -120,6 +120,9 @@ class Cnn14(nn.Module):
         # 3x3 conv algorithm of the trunk: "winograd_f4" (F(4x4,3x3), default), "winograd" (F(2x2,3x3)) or "direct"
         self.conv_algo = {"direct": _hip.CONV_DIRECT, "winograd": _hip.CONV_WINOGRAD, "winograd_f4": _hip.CONV_WINOGRAD_F4}[
             os.environ.get("STITO_CONV_ALGO", "winograd_f4")]
+        # F(4x4,3x3) layers with at least this many output channels run with the input transform hoisted into its own
+        # pass (CONV_WINOGRAD_F4_PRE): from 512 up the 8+ workgroups sharing a pixel block stop repeating it (0 = never)
+        self.conv_pre_min_cout = int(os.environ.get("STITO_CONV_PRE_MIN_COUT", "512"))
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -167,7 +170,8 @@ class Cnn14(nn.Module):
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, self.conv_algo), dtype=torch.float32, device=dev)
                     _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, self.conv_algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()
-                    W.conv_wino_algo[2 * b + j] = self.conv_algo
+                    pre = self.conv_algo == _hip.CONV_WINOGRAD_F4 and 0 < self.conv_pre_min_cout <= cout
+                    W.conv_wino_algo[2 * b + j] = _hip.CONV_WINOGRAD_F4_PRE if pre else self.conv_algo
                     keep.append(upk)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)

@@ -18,14 +18,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames", type=int, default=469)
-    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3)")
+    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 9 = production mix (3 for cout >= 512, else 2)")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     L = _hip.lib()
     dev = torch.device("cuda", 0)
     st = _hip.stream_ptr()
     rows = [r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 0]
+    # mode 9 = the production mix of st_ito/models/panns.py: algo 3 for cout >= 512, algo 2 below
     modes = [int(m) for m in a.modes.split(",")]
+    def algo_of(m, r):
+        return (3 if r["cout"] >= 512 else 2) if m == 9 else m
     res = {m: [] for m in modes}
     ref_out = {}
     for li, r in enumerate(rows):
@@ -35,24 +38,27 @@ def main():
         sc = (0.5 + torch.rand(r["cout"], generator=g)).to(dev)
         sh = (0.1 * torch.randn(r["cout"], generator=g)).to(dev)
         Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
-        for m in modes:
+        for mode in modes:
+            m = algo_of(mode, r)
             packed = torch.empty(L.stito_cnn14_packed_conv_floats(r["cout"], r["cin"], m), device=dev)
             _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), r["cout"], r["cin"], m, _hip.ptr(packed), st))
             out = torch.empty((a.streams, r["cout"] // 8, Ho, Wo, 8), device=dev)
+            wsb = L.stito_conv3x3_workspace_bytes(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
             args = (_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), a.streams, r["H"], r["W"],
-                    r["cin"], r["cout"], r["pool"], m, st)
-            _hip.check(L.stito_conv3x3_bn_relu(*args))
+                    r["cin"], r["cout"], r["pool"], m, _hip.ptr(ws), wsb, st)
+            _hip.check(L.stito_conv3x3_bn_relu_ws(*args))
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
             for s, e in ev:
-                s.record(); _hip.check(L.stito_conv3x3_bn_relu(*args)); e.record()
+                s.record(); _hip.check(L.stito_conv3x3_bn_relu_ws(*args)); e.record()
             torch.cuda.synchronize()
             ms = float(np.median([s.elapsed_time(e) for s, e in ev]))
-            res[m].append((ms, r["flops"] * a.streams / ms / 1e9))
-            if m == modes[0]:
+            res[mode].append((ms, r["flops"] * a.streams / ms / 1e9))
+            if mode == modes[0]:
                 ref_out[li] = out.clone()
             else:
                 err = (out - ref_out[li]).abs().max().item()
-                assert err < 1e-4 * max(1.0, ref_out[li].abs().max().item()), f"layer {li}: algo {m} differs from algo {modes[0]} by {err}"
+                assert err < 1e-4 * max(1.0, ref_out[li].abs().max().item()), f"layer {li}: mode {mode} differs from mode {modes[0]} by {err}"
     print(f"{'layer':28s}" + "".join(f"  algo{m}: ms   TF/s" for m in modes))
     for li, r in enumerate(rows):
         name = f"{r['H']}x{r['W']} {r['cin']}->{r['cout']}{' pool' if r['pool'] else ''}"

@@ -33,8 +33,10 @@ for li, r in enumerate(r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 
         _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), r["cout"], r["cin"], m, _hip.ptr(packed), st))
         for rep in range(1 if m == 0 else a.reps):
             out = torch.full((a.streams, r["cout"] // 8, Ho, Wo, 8), float("nan"), device=dev)
-            _hip.check(L.stito_conv3x3_bn_relu(_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), a.streams,
-                                               r["H"], r["W"], r["cin"], r["cout"], r["pool"], m, st))
+            wsb = L.stito_conv3x3_workspace_bytes(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+            _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), a.streams,
+                                                  r["H"], r["W"], r["cin"], r["cout"], r["pool"], m, _hip.ptr(ws), wsb, st))
             if m == 0:
                 ref = out
                 continue

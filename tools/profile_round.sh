@@ -12,8 +12,8 @@ python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/r2p/bench.json 2> $R/gp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2p/prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/r2p/bench_prof.json 2> $R/gpurun_out/r2p/prof.log
 python $R/profiles/summarize_rocprof.py $R/gpurun_out/r2p/prof/*/*_results.db > $R/gpurun_out/r2p/kernel_stats.txt
 # 3. PMC passes (separate), conv launches only
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/r2p/pmc_fetch -- python $R/tools/conv_bench.py --streams 512 --reps 1 --modes 2 > $R/gpurun_out/r2p/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/r2p/pmc_write -- python $R/tools/conv_bench.py --streams 512 --reps 1 --modes 2 > $R/gpurun_out/r2p/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/r2p/pmc_fetch -- python $R/tools/conv_bench.py --streams 512 --reps 1 --modes 9 > $R/gpurun_out/r2p/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/r2p/pmc_write -- python $R/tools/conv_bench.py --streams 512 --reps 1 --modes 9 > $R/gpurun_out/r2p/pmc_write.log 2>&1
 cd $R
 python profiles/summarize_pmc.py gpurun_out/r2p/pmc_fetch/*/*_results.db gpurun_out/r2p/pmc_write/*/*_results.db 512 gpurun_out/r2p/conv_pmc_traffic.json > gpurun_out/r2p/conv_pmc_traffic.txt 2>&1
 cat gpurun_out/r2p/conv_pmc_traffic.txt
