@@ -33,15 +33,21 @@ class BoundTransform:
         lb, ub, al, au = self.lb, self.ub, self.al, self.au
         y = np.array(y, dtype=np.float64, copy=True)
         lo, hi = lb - al, ub + au
-        period = 2.0 * (hi - lo)
-        # shift into [lo, lo + period), then mirror the upper half
-        y = lo + np.mod(y - lo, period)
-        y = np.where(y > hi, 2.0 * hi - y, y)
+        # pycma's shift_or_mirror_into_invertible: values inside [lo, hi] -- every sample of a run that behaves -- are left
+        # bit for bit as they are; only the others are shifted by whole periods into [lo, lo + period) and the upper half
+        # mirrored back
+        out = (y < lo) | (y > hi)
+        if out.any():
+            period = 2.0 * (hi - lo)
+            v = lo + np.mod(y[out] - lo, period)
+            y[out] = np.where(v > hi, 2.0 * hi - v, v)
         x = y.copy()
         low = y < lb + al
-        x[low] = lb + (y[low] - (lb - al)) ** 2 / (4.0 * al)
+        if low.any():
+            x[low] = lb + (y[low] - (lb - al)) ** 2 / (4.0 * al)
         up = y > ub - au
-        x[up] = ub - (y[up] - (ub + au)) ** 2 / (4.0 * au)
+        if up.any():
+            x[up] = ub - (y[up] - (ub + au)) ** 2 / (4.0 * au)
         return x
 
     def inverse(self, x: np.ndarray) -> np.ndarray:
@@ -130,8 +136,8 @@ class CMAEvolutionStrategy:
         z = self.rng.standard_normal((self.lam, self.N))
         y = z * self.D[None, :] @ self.B.T
         self._geno = self.mean[None, :] + self.sigma * y
-        ph = self._geno if self.boundary is None else self.boundary(self._geno)
-        return [ph[i].copy() for i in range(self.lam)]
+        ph = self._geno.copy() if self.boundary is None else self.boundary(self._geno)
+        return list(ph)  # rows of a fresh array (boundary() copies; without bounds _geno is not handed out: see below)
 
     def tell(self, solutions: Sequence[np.ndarray], function_values: Sequence[float]):
         f = np.asarray(function_values, dtype=np.float64)
