@@ -172,49 +172,10 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     const int a_off = W43_U + (9 * pg) * 32 * W43_K + half * 64 + ((l31 + 16 * half) & 31) * 2;
     const int b_off = (9 * pg) * 64 * W43_K + half * 128 + (nh * 32 + l31) * 2;
 
-    // ---- transform item: (row i of B^T d B, tile, channel pair).  Twelve units (row i, tile half) of 16 tiles x 2 pairs:
-    // lanes 0..31 of wave w carry unit w, lanes 32..47 a quarter of unit 8 + w/2, lanes 48..63 mirror lanes 32..47 (same reads,
-    // same values, same addresses written: no divergent branch in the loop, and every wave carries the same 48 items).
+    // transform-item registers (set up AFTER the first copies are in flight: the index arithmetic hides behind their latency)
     int roff[4];     // float offsets (inside a patch buffer) of the four input rows the lane's row i combines, at tile column 0
     f32x2 cab, ccd;  // their coefficients (a, b), (c, d); 0 for rows outside the map / stream
     int vdst;
-    if constexpr (!PREV) {
-        int ti, tile, cp;
-        if (lane < 32) {
-            ti = wv >> 1; tile = (wv & 1) * 16 + (lane & 15); cp = lane >> 4;
-        } else {
-            const int u = 8 + (wv >> 1), l = lane & 15;
-            ti = u >> 1; tile = (u & 1) * 16 + (wv & 1) * 8 + (l & 7); cp = l >> 3;
-        }
-        // B^T (Lavin & Gray):  row 0: 4 d0 - 5 d2 + d4        row 1: -4 d1 - 4 d2 + d3 + d4   row 2: 4 d1 - 4 d2 - d3 + d4
-        //                      row 3: -2 d1 - d2 + 2 d3 + d4  row 4: 2 d1 - d2 - 2 d3 + d4     row 5: 4 d1 - 5 d3 + d5
-        int kr[4];
-        float cf[4];
-        switch (ti) {
-            case 0: kr[0] = 0; kr[1] = 2; kr[2] = 4; kr[3] = 4; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
-            case 1: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -4.f; cf[1] = -4.f; cf[2] = 1.f; cf[3] = 1.f; break;
-            case 2: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 4.f; cf[1] = -4.f; cf[2] = -1.f; cf[3] = 1.f; break;
-            case 3: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -2.f; cf[1] = -1.f; cf[2] = 2.f; cf[3] = 1.f; break;
-            case 4: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 2.f; cf[1] = -1.f; cf[2] = -2.f; cf[3] = 1.f; break;
-            default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = 5; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
-        }
-        const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
-        const int s_ = vtr / g.TR, tr = vtr % g.TR;
-        const int pc0 = s_ * g.H + 4 * tr - 1 - iv_lo;  // patch row of this tile's first input row
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int hh = 4 * tr - 1 + kr[x];
-            // rows outside the map / stream contribute nothing: coefficient 0 on a row that exists in the patch (finite data)
-            const bool ok = vtr < g.VTR && hh >= 0 && hh < g.H;
-            if (!ok) cf[x] = 0.f;
-            const int prow = ok ? pc0 + kr[x] : 0;
-            roff[x] = PL::slot(prow, 4 * tcl) * W43_K + cp * 2;
-        }
-        cab = (f32x2){cf[0], cf[1]};
-        ccd = (f32x2){cf[2], cf[3]};
-        vdst = W43_U + (ti * 6) * 32 * W43_K + cp * 64 + ((tile + 16 * cp) & 31) * 2;  // V[6 ti + j][cp][(tile + 16 cp) % 32]
-    }
-
     // ---- U slab copies: position ii = wv + 8 j, 1 KB each --------------------------------------------------
     // packed weights [cin/4][36][2 pairs][cout][2]: lanes 0..31 fetch this block's 64 channels of pair 0, lanes 32..63 of pair 1
     const float *u_base = upk + (int64_t)n0 * 2;
@@ -398,6 +359,45 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             *(f32x4 *)(patch0 + q * W43_K) = (f32x4)(0.0f);
             *(f32x4 *)(patch0 + PFL + q * W43_K) = (f32x4)(0.0f);
         }
+    }
+    // ---- transform item: (row i of B^T d B, tile, channel pair).  Twelve units (row i, tile half) of 16 tiles x 2 pairs:
+    // lanes 0..31 of wave w carry unit w, lanes 32..47 a quarter of unit 8 + w/2, lanes 48..63 mirror lanes 32..47 (same reads,
+    // same values, same addresses written: no divergent branch in the loop, and every wave carries the same 48 items).
+    if constexpr (!PREV) {
+        int ti, tile, cp;
+        if (lane < 32) {
+            ti = wv >> 1; tile = (wv & 1) * 16 + (lane & 15); cp = lane >> 4;
+        } else {
+            const int u = 8 + (wv >> 1), l = lane & 15;
+            ti = u >> 1; tile = (u & 1) * 16 + (wv & 1) * 8 + (l & 7); cp = l >> 3;
+        }
+        // B^T (Lavin & Gray):  row 0: 4 d0 - 5 d2 + d4        row 1: -4 d1 - 4 d2 + d3 + d4   row 2: 4 d1 - 4 d2 - d3 + d4
+        //                      row 3: -2 d1 - d2 + 2 d3 + d4  row 4: 2 d1 - d2 - 2 d3 + d4     row 5: 4 d1 - 5 d3 + d5
+        int kr[4];
+        float cf[4];
+        switch (ti) {
+            case 0: kr[0] = 0; kr[1] = 2; kr[2] = 4; kr[3] = 4; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
+            case 1: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -4.f; cf[1] = -4.f; cf[2] = 1.f; cf[3] = 1.f; break;
+            case 2: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 4.f; cf[1] = -4.f; cf[2] = -1.f; cf[3] = 1.f; break;
+            case 3: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -2.f; cf[1] = -1.f; cf[2] = 2.f; cf[3] = 1.f; break;
+            case 4: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 2.f; cf[1] = -1.f; cf[2] = -2.f; cf[3] = 1.f; break;
+            default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = 5; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
+        }
+        const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
+        const int s_ = vtr / g.TR, tr = vtr % g.TR;
+        const int pc0 = s_ * g.H + 4 * tr - 1 - iv_lo;  // patch row of this tile's first input row
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int hh = 4 * tr - 1 + kr[x];
+            // rows outside the map / stream contribute nothing: coefficient 0 on a row that exists in the patch (finite data)
+            const bool ok = vtr < g.VTR && hh >= 0 && hh < g.H;
+            if (!ok) cf[x] = 0.f;
+            const int prow = ok ? pc0 + kr[x] : 0;
+            roff[x] = PL::slot(prow, 4 * tcl) * W43_K + cp * 2;
+        }
+        cab = (f32x2){cf[0], cf[1]};
+        ccd = (f32x2){cf[2], cf[3]};
+        vdst = W43_U + (ti * 6) * 32 * W43_K + cp * 64 + ((tile + 16 * cp) & 31) * 2;  // V[6 ti + j][cp][(tile + 16 cp) % 32]
     }
     if (FUSE1) {
         W43_BARRIER()  // window complete
