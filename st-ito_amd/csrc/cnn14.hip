@@ -1086,6 +1086,7 @@ extern "C" int stito_debug_wino_trace(long long *buf_dev) {
 extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo) {
     if (n <= 0 || H <= 0 || W <= 0 || cout % 4 != 0) return 0;
     if (pool && (H < 2 || W < 2)) return 0;
+    if (algo == STITO_CONV_WINOGRAD_F4_PRE && cout % 256 != 0) return 0;  // its workgroup order deals channel tiles in fours
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD) return wino_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (cin == 1) return (!pool && cout % 8 == 0) ? 1 : 0;
@@ -1281,8 +1282,10 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             const int i = 2 * blk + j;
             const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
             // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
-            const int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE)
-                                  ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;
+            int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE)
+                            ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;
+            if (walgo == STITO_CONV_WINOGRAD_F4_PRE && !stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo))
+                walgo = STITO_CONV_WINOGRAD_F4;  // same packing
             const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
             const bool timed = g_conv_timing.on && ci % 8 == 0;
             if (timed) {

@@ -56,6 +56,8 @@ struct Wino43Geom {
     int Ho, Wo;        // output map (pooled when POOL)
     int PR;            // halo patch rows
     int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
+    int n_mblocks;     // pixel blocks (MODE 1: the grid is padded to whole XCD rounds)
+    int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
     long long *trace;  // TRACE instantiation only
     // FUSE1 instantiation (conv_block1: the Cin = 1 first conv computed on the fly while staging the patch):
     const float *fw;   // first-conv weights, BN scale folded, packed [16 chunks][9 taps][4 channels]
@@ -146,8 +148,21 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
-    const int m_blk = blockIdx.x / n_tiles;  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    const int n0 = VOUT ? 0 : (blockIdx.x % n_tiles) * 64;
+    int m_blk = blockIdx.x / n_tiles;  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    int n0 = VOUT ? 0 : (blockIdx.x % n_tiles) * 64;
+    if constexpr (PREV) {
+        // MODE 1 streams 18 KB of V and 36 KB of U per period through L2, and workgroup b runs on XCD b % 8 (own L2 each).
+        // With the channel tile fastest the 8+ sharers of a V slab sit on 8 different XCDs: every slab is fetched 8 times
+        // (PMC: 22.8 GB for conv_block4.conv2 against 9.2 GB for MODE 0).  Here the 32 workgroups an XCD runs at a time are
+        // 8 pixel blocks x 4 channel tiles: 8 V streams + 4 U streams = 288 KB per period per XCD, the minimum of 18 a + 36 b
+        // over a b = 32 (612 KB before).  Pixel blocks are dealt round-robin to the XCDs; padding workgroups leave at once.
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3, r = j & 31, gi = j >> 5;
+        const int a = g.ct_group, n_ctg = n_tiles / a;          // a channel tiles x 32 / a pixel blocks per XCD round
+        const int ct = (gi % n_ctg) * a + (r % a);
+        m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+        n0 = ct * 64;
+        if (m_blk >= g.n_mblocks) return;
+    }
     const int cb = m_blk % g.n_col_blocks;
     const int rb = m_blk / g.n_col_blocks;
     const int vtr0 = rb * TTH;  // first virtual tile row (s * TR + tr) of the block
@@ -627,6 +642,8 @@ static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &l
     g = Wino43Geom{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
     g.n_cgroups = 1;
+    g.n_mblocks = 0;
+    g.ct_group = 4;
     g.Ho = pool ? c.H / 2 : c.H;
     g.Wo = pool ? c.W / 2 : c.W;
     g.TR = pool ? (g.Ho + 1) / 2 : (c.H + 3) / 4;
@@ -795,6 +812,19 @@ static int launch_w43_pre(const float *in, const float *upk, const float *scale,
     auto kern = k_conv_wino43<TTW, POOL, false, false, 1>;
     const size_t lds1 = (size_t)2 * W43_BUF * sizeof(float);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    // grid in whole XCD rounds: 8 XCDs x (groups of 8 pixel blocks) x (groups of 4 channel tiles) x 32 workgroups
+    const int64_t m_blocks = blocks / (c.Cout / 64);
+    g.n_mblocks = (int)m_blocks;
+    // channel tiles side by side on an XCD: swept 1..32 at 512 streams (tools/conv_bench.py --modes 9): 4 is best for 8 tiles
+    // (conv_block4: 3.17 / 5.69 ms against 3.63 / 6.59 for 1), 8 from 16 tiles up (1-4 % over 4), 32 loses 15 % at 32 tiles
+    const int n_tiles = c.Cout / 64;
+    const int a = n_tiles >= 16 ? 8 : 4;
+    STITO_REQUIRE(n_tiles % a == 0, STITO_E_UNSUPPORTED, "conv (hoisted input transform): cout %d", c.Cout);
+    g.ct_group = a;
+    const int bm = 32 / a;
+    const int64_t m_groups = ((m_blocks + 7) / 8 + bm - 1) / bm;
+    blocks = 8 * m_groups * (n_tiles / a) * 32;
+    STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv (hoisted input transform): grid");
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const float *)vbuf, upk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
