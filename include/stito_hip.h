@@ -140,14 +140,15 @@ typedef struct {
     const float *twiddle_dev;     /* (n_fft/2, 2) cos/sin of exp(-2 pi i k / n_fft) */
     const int32_t *mel_start_dev; /* (n_mels) first FFT bin of each band */
     const int32_t *mel_len_dev;   /* (n_mels) number of consecutive bins */
-    const int32_t *mel_off_dev;   /* (n_mels) offset of the band's weights in mel_w_dev */
-    const float *mel_w_dev;       /* packed non-zero runs of melW[:, m] */
+    const int32_t *mel_off_dev;   /* (n_mels) offset of the band's first weight in mel_w_dev */
+    const float *mel_w_dev;       /* the non-zero run of melW[:, m]: weight i of band m at mel_off[m] + i * mel_w_stride */
     const float *bn0_scale_dev;   /* (n_mels) gamma/sqrt(var+eps)        (BATCHNORM only) */
     const float *bn0_shift_dev;   /* (n_mels) beta - mean*scale          (BATCHNORM only) */
     int32_t no_center;    /* 0: frames centred with reflect padding (torchlibrosa, panns.py:147-155);
                              1: frame t starts at t*hop, no padding (torchaudio MelSpectrogram(center=False),
                              utils.py:104-113) */
-    int32_t reserved;
+    int32_t mel_w_stride; /* 0 / 1: runs packed back to back; n_mels with mel_off[m] = m: table (max run length, n_mels),
+                             zero padded -- the lanes of a wave then read consecutive floats (ABI version 4; was `reserved`) */
 } stito_frontend;
 
 /* T = n_samples / hop + 1 frames (center=True, reflect padding). */

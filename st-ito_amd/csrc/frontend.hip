@@ -19,7 +19,7 @@
 namespace stito {
 
 struct FrontendDev {
-    int n_fft, hop, n_mels, norm_mode, log2_n2, no_center;
+    int n_fft, hop, n_mels, norm_mode, log2_n2, no_center, mel_stride;
     const float *window;
     const float2 *twiddle;  // exp(-2 pi i k / n_fft), k < n_fft/2
     const int *mel_start, *mel_len, *mel_off;
@@ -69,13 +69,26 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     const int64_t base = fe.no_center ? t * fe.hop : t * fe.hop - N2;
 
     // ---- load, normalise, mid/side, window, pack even/odd samples as complex ------------------
+    // Interior frames whose first sample is 8-byte aligned (every frame but the reflected ends when hop and the stream
+    // offsets are even) fetch sample pairs as one 8-byte load: half the load instructions and index arithmetic of the
+    // general path (measured by ablation: this stage was 1.0 of the kernel's 2.3 ms).  Same values, same operations.
+    const bool fast = base >= 0 && base + N <= L && (((uintptr_t)(xl + base) | (uintptr_t)(xr + base) | (uintptr_t)fe.window) & 7) == 0;
     for (int m = tid; m < N2; m += FE_THREADS) {
-        const int64_t i0 = reflect_idx(base + 2 * m, L), i1 = reflect_idx(base + 2 * m + 1, L);
-        const float w0 = fe.window[2 * m], w1 = fe.window[2 * m + 1];
-        float a0 = xl[i0] * r1, a1 = xl[i1] * r1;
+        float a0, a1, b0 = 0.0f, b1 = 0.0f, w0, w1;
+        if (fast) {
+            const float2 a = ((const float2 *)(xl + base))[m], w = ((const float2 *)fe.window)[m];
+            a0 = a.x; a1 = a.y; w0 = w.x; w1 = w.y;
+            if (C == 2) { const float2 b = ((const float2 *)(xr + base))[m]; b0 = b.x; b1 = b.y; }
+        } else {
+            const int64_t i0 = reflect_idx(base + 2 * m, L), i1 = reflect_idx(base + 2 * m + 1, L);
+            w0 = fe.window[2 * m]; w1 = fe.window[2 * m + 1];
+            a0 = xl[i0]; a1 = xl[i1];
+            if (C == 2) { b0 = xr[i0]; b1 = xr[i1]; }
+        }
+        a0 = a0 * r1; a1 = a1 * r1;
         if (second) { a0 = a0 * r2; a1 = a1 * r2; }
         if (C == 2) {
-            float b0 = xr[i0] * r1, b1 = xr[i1] * r1;
+            b0 = b0 * r1; b1 = b1 * r1;
             if (second) { b0 = b0 * r2; b1 = b1 * r2; }
             const float m0 = (a0 + b0) * 0.5f, m1 = (a1 + b1) * 0.5f, s0 = (a0 - b0) * 0.5f, s1 = (a1 - b1) * 0.5f;  // / 2 is exact
             bufA[m] = make_float2(m0 * w0, m1 * w1);
@@ -157,10 +170,14 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     for (int q = tid; q < C * M; q += FE_THREADS) {
         const int c = q / M, m = q - c * M;
         const int st = fe.mel_start[m], ln = fe.mel_len[m];
+        // weights at w[i * mel_stride]: with the interleaved table (stride = n_mels, offset = m) the lanes of a wave read
+        // consecutive floats per step; with packed runs (stride 1) every lane is on its own cache line -- 64 lines per
+        // load instruction, which made this loop 0.85 of the kernel's 2.3 ms
         const float *w = fe.mel_w + fe.mel_off[m];
+        const int ws = fe.mel_stride;
         const float *p = pw + c * (N2 + 1) + st;
         float acc = 0.0f;
-        for (int i = 0; i < ln; ++i) acc = fmaf(p[i], w[i], acc);
+        for (int i = 0; i < ln; ++i) acc = fmaf(p[i], w[i * ws], acc);
         float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
         if (fe.norm_mode == STITO_NORM_MINMAX) {
             v = fminf(fmaxf(v, -80.0f), 40.0f);
@@ -200,6 +217,7 @@ extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, co
     d.log2_n2 = l2;
     d.window = fe->window_dev; d.twiddle = (const float2 *)fe->twiddle_dev;
     d.mel_start = fe->mel_start_dev; d.mel_len = fe->mel_len_dev; d.mel_off = fe->mel_off_dev; d.mel_w = fe->mel_w_dev;
+    d.mel_stride = fe->mel_w_stride > 1 ? fe->mel_w_stride : 1;
     d.bn_scale = fe->bn0_scale_dev; d.bn_shift = fe->bn0_shift_dev;
     STITO_REQUIRE(fe->norm_mode != STITO_NORM_BATCHNORM || (d.bn_scale && d.bn_shift), STITO_E_INVALID, "batchnorm input norm needs bn0 scale/shift");
     const int64_t T = fe->no_center ? stito_num_frames_nocenter(n_samples, N, fe->hop) : stito_num_frames(n_samples, fe->hop);

@@ -36,7 +36,7 @@ class Frontend(Structure):
         ("window_dev", c_void_p), ("twiddle_dev", c_void_p), ("mel_start_dev", c_void_p),
         ("mel_len_dev", c_void_p), ("mel_off_dev", c_void_p), ("mel_w_dev", c_void_p),
         ("bn0_scale_dev", c_void_p), ("bn0_shift_dev", c_void_p),
-        ("no_center", c_int32), ("reserved", c_int32),
+        ("no_center", c_int32), ("mel_w_stride", c_int32),
     ]
 
 
@@ -152,3 +152,24 @@ def ptr(t):
 
 def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def mel_tables(melW, dev):
+    """Device tables of a (n_bins, n_mels) mel filterbank for stito_frontend: every band is one run of consecutive
+    non-zero bins.  -> (mel_start, mel_len, mel_off, mel_w, mel_w_stride) in the interleaved layout: weight i of band m
+    at mel_w[i * n_mels + m] (zero padded to the longest run), so that the lanes of a wave -- one band each -- read
+    consecutive floats per step."""
+    import numpy as np
+    import torch
+    melW = np.asarray(melW, dtype=np.float32)
+    n_mels = melW.shape[1]
+    starts, lens = [], []
+    for m in range(n_mels):
+        nz = np.nonzero(melW[:, m])[0]
+        s, e = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 0)
+        starts.append(s); lens.append(e - s)
+    table = np.zeros((max(max(lens), 1), n_mels), np.float32)
+    for m in range(n_mels):
+        table[: lens[m], m] = melW[starts[m]: starts[m] + lens[m], m]
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)  # noqa: E731
+    return i32(starts), i32(lens), i32(list(range(n_mels))), torch.from_numpy(table).to(dev).contiguous(), n_mels

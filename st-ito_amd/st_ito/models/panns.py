@@ -222,15 +222,7 @@ class Cnn14(nn.Module):
         tw = np.stack([np.cos(-2 * np.pi * kk / n_fft), np.sin(-2 * np.pi * kk / n_fft)], 1).astype(np.float32)
         tw_t = torch.from_numpy(tw).to(dev).contiguous()
         melW = self.logmel_extractor.melW.detach().cpu().numpy()  # (n_bins, n_mels)
-        starts, lens, offs, packed_w = [], [], [], []
-        for m in range(self.mel_bins):
-            nz = np.nonzero(melW[:, m])[0]
-            s, e = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 0)
-            starts.append(s); lens.append(e - s); offs.append(sum(len(a) for a in packed_w))
-            packed_w.append(melW[s:e, m].astype(np.float32))
-        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)  # noqa: E731
-        ms, ml, mo = i32(starts), i32(lens), i32(offs)
-        mw = torch.from_numpy(np.concatenate(packed_w + [np.zeros(1, np.float32)])).to(dev)
+        ms, ml, mo, mw, FE.mel_w_stride = _hip.mel_tables(melW, dev)
         FE.window_dev, FE.twiddle_dev = win_t.data_ptr(), tw_t.data_ptr()
         FE.mel_start_dev, FE.mel_len_dev, FE.mel_off_dev, FE.mel_w_dev = ms.data_ptr(), ml.data_ptr(), mo.data_ptr(), mw.data_ptr()
         keep += [win_t, tw_t, ms, ml, mo, mw]

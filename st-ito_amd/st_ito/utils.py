@@ -207,13 +207,7 @@ class MFCCExtractor:
         m_pts = torch.linspace(0.0, m_max, n_mels + 2)
         f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
         fb = _create_triangular_filterbank_from(all_freqs, f_pts).numpy()
-        starts, lens, offs, packed = [], [], [], []
-        for m in range(n_mels):
-            nz = np.nonzero(fb[:, m])[0]
-            s0, e0 = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 0)
-            starts.append(s0); lens.append(e0 - s0); offs.append(sum(len(a) for a in packed))
-            packed.append(fb[s0:e0, m].astype(np.float32))
-        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)  # noqa: E731
+        m_start, m_len, m_off, m_w, m_stride = _hip.mel_tables(fb, dev)
         kk = np.arange(n_fft // 2)
         tw = np.stack([np.cos(-2 * np.pi * kk / n_fft), np.sin(-2 * np.pi * kk / n_fft)], 1).astype(np.float32)
         # orthonormal DCT-II (n_mels, n_mfcc): torchaudio.functional.create_dct(n_mfcc, n_mels, "ortho")
@@ -222,11 +216,12 @@ class MFCCExtractor:
         dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
         dct[0] *= 1.0 / math.sqrt(2.0)
         dct *= math.sqrt(2.0 / float(n_mels))
-        self._keep = [torch.hann_window(n_fft, periodic=True).to(dev), torch.from_numpy(tw).to(dev).contiguous(), i32(starts), i32(lens),
-                      i32(offs), torch.from_numpy(np.concatenate(packed + [np.zeros(1, np.float32)])).to(dev), dct.t().contiguous().to(dev)]
+        self._keep = [torch.hann_window(n_fft, periodic=True).to(dev), torch.from_numpy(tw).to(dev).contiguous(), m_start, m_len,
+                      m_off, m_w, dct.t().contiguous().to(dev)]
         FE = _hip.Frontend()
         FE.n_fft, FE.hop, FE.n_mels, FE.norm_mode, FE.no_center = n_fft, hop_length, n_mels, _hip.NORM_NONE, 1
         FE.window_dev, FE.twiddle_dev, FE.mel_start_dev, FE.mel_len_dev, FE.mel_off_dev, FE.mel_w_dev = (t.data_ptr() for t in self._keep[:6])
+        FE.mel_w_stride = m_stride
         self.FE, self.dct = FE, self._keep[6]
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

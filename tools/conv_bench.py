@@ -28,7 +28,11 @@ def main():
     # mode 9 = the production mix of st_ito/models/panns.py: algo 3 for cout >= 512, algo 2 below
     modes = [int(m) for m in a.modes.split(",")]
     def algo_of(m, r):
-        return (3 if r["cout"] >= 512 else 2) if m == 9 else m
+        if m == 9:
+            return 3 if r["cout"] >= 512 else 2
+        if m == 3 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 3):
+            return 2  # the hoisted transform needs cout % 256 == 0
+        return m
     res = {m: [] for m in modes}
     ref_out = {}
     for li, r in enumerate(rows):
