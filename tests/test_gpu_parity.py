@@ -449,6 +449,32 @@ def test_model_vs_golden_reference(dev, golden_dir, norm):
         assert np.abs(e[key].numpy() - ref).max() / np.abs(ref).max() < 1e-4
 
 
+def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
+    """The model's default (F(4x4,3x3) with the input transform hoisted into its own pass from 512 output channels up:
+    conv_block4-6, STITO_CONV_WINOGRAD_F4_PRE) against the same trunk with every layer transforming in-kernel
+    (conv_pre_min_cout = 0): same arithmetic in the same order, so the embeddings are identical bit for bit -- on a
+    bench-shaped input (10 s: the 469 x 128 map, all tile widths 8 / 4 / 2 / 1) and on a short one (ragged tiles)."""
+    from st_ito import _hip
+    from st_ito.models.panns import Cnn14
+    om = O.fill_deterministic(O.Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "batchnorm"), 0).eval()
+    outs = {}
+    for pre in (512, 0):
+        pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "batchnorm")
+        pm.load_state_dict(om.state_dict())
+        pm.eval().to(dev)
+        pm.conv_pre_min_cout = pre
+        W, _, _ = pm._ensure()
+        algos = [int(W.conv_wino_algo[i]) for i in range(12)]
+        assert algos[1:6] == [_hip.CONV_WINOGRAD_F4] * 5
+        assert algos[6:] == [_hip.CONV_WINOGRAD_F4_PRE if pre else _hip.CONV_WINOGRAD_F4] * 6
+        for n in (480000, 40001):
+            x = torch.stack([O.synth_audio(70 + i, 2, n) for i in range(3)])
+            outs[(pre, n)] = [t.clone() for t in pm(x.to(dev))]
+    for n in (480000, 40001):
+        for a, b in zip(outs[(512, n)], outs[(0, n)]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tag", ["stereo", "mono"])
 def test_evaluate_losses_golden(dev, golden_dir, tag):
     """run_es.evaluate end to end (pad to 262144, render, embed, cosine) against the losses the
