@@ -383,7 +383,19 @@ __global__ __launch_bounds__(256) void k_delay(InView in, float *__restrict__ ou
 // Freeverb: juce::Reverb::processStereo, effects.py:952-959
 // ------------------------------------------------------------------------------------------------
 static constexpr int RV_TT = 192;       // tile length; must be <= the shortest delay line (244 @ 48 kHz)
-static constexpr int RV_THREADS = 1024; // 16 waves = 16 comb filters
+static constexpr int RV_RUN = 6;        // consecutive samples of a comb per lane: a comb's tile is 32 lanes, two combs per wave
+static constexpr int RV_COMB_WAVES = 8;
+static constexpr int RV_AP_WAVES = 2 * RV_TT / 64;   // one all-pass / mix thread per (channel, sample)
+static constexpr int RV_STAGE_WAVES = 2;             // input staging: thread v < RV_TT / 2 moves samples 2v, 2v + 1 of both channels
+static constexpr int RV_THREADS = (RV_COMB_WAVES + RV_AP_WAVES + RV_STAGE_WAVES) * 64;
+static constexpr int RV_PD = 4;         // input tiles in flight per staging thread (register ring)
+static constexpr int RV_PAD = 32;       // floats: half the LDS banks
+static constexpr int RV_XB = 2 * RV_TT + RV_PAD;    // floats per dry-input buffer
+static constexpr int RV_CB = 16 * RV_TT + RV_PAD;   // floats per comb-output buffer
+static constexpr int RV_TILE_FLOATS = 2 * RV_TT + 3 * RV_XB + 2 * RV_CB;  // s_in + s_x + s_comb
+static_assert(RV_RUN * 32 == RV_TT && RV_THREADS <= 1024, "a comb's tile is 32 lanes x RV_RUN samples");
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct ReverbGeom {
     int comb_size[16];  // [ch*8 + j]
@@ -400,13 +412,31 @@ __device__ __forceinline__ float rv_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
 }
 
+// One workgroup per candidate, every delay line in LDS, ONE barrier per 192-sample tile, three roles on separate waves
+// working on three consecutive tiles at once.  The tile time is set by LATENCY, not by instruction count or bandwidth
+// (measured with s_memtime stamps and by switching roles off: round 1's kernel spent 2 200 cycles per tile, of which per
+// tile: two vector loads of the all-pass geometry from the kernel-argument struct + vmcnt(0), two 64-bit modulos, an
+// all-pass chain that read each line only after the previous stage's write, a wait for the input on the heels of the
+// output store -- vmcnt is one in-order counter -- and 3 samples per lane behind a 6-step wave scan).  Hence:
+//   staging waves  only loads in their vmcnt: the input of tile k + 1 comes out of a register ring filled RV_PD tiles ahead
+//                  (branch-free, so hipcc counts the waits instead of draining);
+//   all-pass waves only stores: comb sums, all four all-pass reads and the dry sample are fetched together, then the chain
+//                  runs on registers;
+//   comb waves     a comb's tile is 32 lanes x 6 consecutive samples: the damping one-pole runs serially inside the lane
+//                  (5 + 6 dependent FMAs) and a 5-step scan of affine maps crosses the lanes on the DPP network.
+// (An LDS-only barrier -- s_waitcnt lgkmcnt(0); s_barrier, without __syncthreads()'s vmcnt(0) -- was measured too: 2.16
+// against 2.06 ms on the same box; hipcc then drains vmcnt in front of the LDS writes instead.)
+#define RV_BARRIER() __syncthreads()
+
 __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restrict__ out, int64_t cand_stride,
                                                         int64_t L, const double *__restrict__ coef, ReverbGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *state = smem;                          // comb + all-pass delay lines
     float *s_in = smem + g.state_floats;          // [2 buffers][RV_TT] (L+R)*gain
-    float *s_x = s_in + 2 * RV_TT;                // [3 buffers][2][RV_TT] dry input
-    float *s_comb = s_x + 6 * RV_TT;              // [2 buffers][16][RV_TT] comb outputs
+    // channel 1 sits 32 banks behind channel 0 in s_x and s_comb: an all-pass wave's lanes alternate channels on the same
+    // sample, and without the pad both channels of a sample fall on one bank in every comb-sum read
+    float *s_x = s_in + 2 * RV_TT;                // [3 buffers][2][RV_TT (+ RV_PAD for channel 1)] dry input
+    float *s_comb = s_x + 3 * RV_XB;              // [2 buffers][16][RV_TT] (+ RV_PAD in front of combs 8..15) comb outputs
 
     const int cand = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -417,115 +447,174 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
     float *yl = out + (int64_t)cand * cand_stride, *yr = yl + L;
 
     for (int i = tid; i < g.state_floats; i += RV_THREADS) state[i] = 0.0f;
+    const int ntiles = (int)((L + RV_TT - 1) / RV_TT);
 
-    // comb j == this wave; lane handles samples 3*lane .. 3*lane+2 of the tile
-    const int csz = g.comb_size[wv];
-    float *cbuf = state + g.comb_off[wv];
-    int cpos = 0;
-    float last_in = 0.0f;  // filterStore entering the tile
-    const float d3 = damp * damp * damp;
-    float apow[6];
-    {
-        float a = d3;
+    if (wv < RV_COMB_WAVES) {
+        // ---- comb role: lanes 0..31 of wave w are comb 2 w, lanes 32..63 comb 2 w + 1; lane l of a comb owns samples 6 l .. 6 l + 5
+        const int cidx = 2 * wv + (lane >> 5), cl = lane & 31;
+        const int csz = g.comb_size[cidx];
+        float *cbuf = state + g.comb_off[cidx];
+        int cpos = 0;
+        float last_in = 0.0f;  // filterStore entering the tile (meaningful in lane 0 of the comb)
+        float apw[4];          // damp^6, ^12, ^24, ^48: the affine maps' slopes at scan distances 1, 2, 4, 8
+        {
+            float a = damp * damp * damp;
+            a = a * a;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { apow[k] = a; a *= a; }
-    }
-    const float dlane = powf(d3, (float)lane);  // damp^(3*lane)
-    const float m15 = powf(d3, (float)((lane & 15) + 1));            // from lane 15 of the previous row
-    const float m31 = lane >= 32 ? powf(d3, (float)(lane - 31)) : 0.0f;  // from lane 31
-    // all-pass role: thread u < 2 RV_TT = (channel u & 1, sample u >> 1): the two channels of a sample sit in
-    // adjacent lanes, so the width mix and the (L+R) input sum are one __shfl_xor away -- no exchange through LDS
-    int appos[4] = {0, 0, 0, 0};
-    const int c2 = tid & 1, t2 = tid >> 1;
-    const float *xc_g = c2 == 0 ? xl : xr;
-    float *yc_g = c2 == 0 ? yl : yr;
-    const bool ap = tid < 2 * RV_TT;
-
-    // ONE barrier per tile, two tiles in flight: in step k the 16 waves run the combs of tile k while the first
-    // 2 RV_TT threads also run comb sums + all-passes + wet/dry mix + store of tile k-1 (comb outputs double-
-    // buffered) and stage the input of tile k+1 (s_in double-, s_x triple-buffered).  Both are chains of LDS round
-    // trips; in one instruction stream their latencies overlap.  The input of tile k+2 is already on its way from
-    // HBM into registers.
-    float px = (ap && t2 < L) ? xc_g[t2] : 0.0f;
-    if (ap) {  // stage tile 0, fetch tile 1
-        const float po = __shfl_xor(px, 1);
-        s_x[c2 * RV_TT + t2] = px;
-        if (c2 == 0) s_in[t2] = (px + po) * 0.015f;
-        const int64_t tn = (int64_t)RV_TT + t2;
-        px = tn < L ? xc_g[tn] : 0.0f;
-    }
-    const int64_t ntiles = (L + RV_TT - 1) / RV_TT;
-    for (int64_t k = 0; k <= ntiles; ++k) {
-        __syncthreads();  // combs of tile k-1, all-passes of tile k-2 and the staging of tile k are complete
-        if (ap && k >= 1) {  // ---- tile k-1: comb sum + 4 series all-passes, mix, store ----
-            const int64_t t0 = (k - 1) * RV_TT;
-            const float *cmb = s_comb + ((k - 1) & 1) * 16 * RV_TT;
-            float acc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc += cmb[(c2 * 8 + j) * RV_TT + t2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sz = g.ap_size[c2 * 4 + j];
-                float *ab = state + g.ap_off[c2 * 4 + j];
-                int p = appos[j] + t2;
-                p = p >= sz ? p - sz : p;
-                const float bv = ab[p];
-                ab[p] = acc + (bv * 0.5f);
-                acc = bv - acc;
-                appos[j] += RV_TT;
-                appos[j] = appos[j] >= sz ? appos[j] - sz : appos[j];
-            }
-            const float other = rv_dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the other channel of this sample
-            if (t0 + t2 < L) yc_g[t0 + t2] = acc * wet1 + other * wet2 + s_x[(int)((k - 1) % 3) * 2 * RV_TT + c2 * RV_TT + t2] * dry;
+            for (int k = 0; k < 4; ++k) { apw[k] = a; a *= a; }
         }
-        if (ap && k + 1 < ntiles) {  // ---- stage tile k+1, fetch tile k+2 ----
-            const float po = __shfl_xor(px, 1);
-            s_x[(int)((k + 1) % 3) * 2 * RV_TT + c2 * RV_TT + t2] = px;
-            if (c2 == 0) s_in[((k + 1) & 1) * RV_TT + t2] = (px + po) * 0.015f;
-            const int64_t tn = (k + 2) * RV_TT + t2;
-            px = tn < L ? xc_g[tn] : 0.0f;
-        }
-        if (k < ntiles) {   // ---- tile k: 16 comb filters, one per wave ----
-            const float *in_c = s_in + (k & 1) * RV_TT;
-            float *cmb = s_comb + (k & 1) * 16 * RV_TT;
-            float o[3], w[3];
-            int idx[3];
+        const float m15 = (cl & 16) ? powf(apw[0], (float)((cl & 15) + 1)) : 0.0f;  // from lane 15 of the comb's first row
+        // the line's values for tile k + 1 are read at the end of tile k: they were written a whole delay (>= 2 tiles) ago, so
+        // the LDS round trip is off the tile's dependent chain (read -> 5 FMAs -> scan -> 6 FMAs -> write)
+        int base = RV_RUN * cl;  // cpos = 0, and csz > RV_TT: the first run is straight
+        bool straight = true;
+        float o[RV_RUN];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                int p = cpos + 3 * lane + i;
-                p = p >= csz ? p - csz : p;
-                idx[i] = p;
-                o[i] = cbuf[p];
-            }
-            // lane-local affine map of 3 damping steps: last_out = d3*last_in + b
-            float b = o[0] * omd;
-            b = o[1] * omd + b * damp;
-            b = o[2] * omd + b * damp;
-            // inclusive wave scan of the affine maps on the DPP network (a ds_bpermute shuffle costs an LDS round
-            // trip per step): shifts 1, 2, 4, 8 inside the 16-lane rows (lanes shifted in from outside read 0),
-            // then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3, each with the power of
-            // d3 that belongs to the lane's distance
-            b = fmaf(apow[0], rv_dpp<0x111>(b), b);
-            b = fmaf(apow[1], rv_dpp<0x112>(b), b);
-            b = fmaf(apow[2], rv_dpp<0x114>(b), b);
-            b = fmaf(apow[3], rv_dpp<0x118>(b), b);
+        for (int i = 0; i < RV_RUN; ++i) o[i] = 0.0f;  // the lines start empty
+        for (int k = 0; k <= ntiles; ++k) {
+            RV_BARRIER();
+            if (k == ntiles) break;
+            const float *in_c = s_in + (k & 1) * RV_TT + RV_RUN * cl;
+            float *cmb = s_comb + (k & 1) * RV_CB + cidx * RV_TT + (cidx >= 8 ? RV_PAD : 0) + RV_RUN * cl;
+            float pq[RV_RUN], w[RV_RUN];
+            const f2 n0 = *(const f2 *)in_c, n1 = *(const f2 *)(in_c + 2), n2 = *(const f2 *)(in_c + 4);
+            // the lane's 6 damping steps as one affine map of the state entering it: out = damp^6 in + b
+#pragma unroll
+            for (int i = 0; i < RV_RUN; ++i) pq[i] = o[i] * omd;
+            float b = pq[0];
+#pragma unroll
+            for (int i = 1; i < RV_RUN; ++i) b = fmaf(b, damp, pq[i]);
+            b = fmaf(apw[0], cl == 0 ? last_in : 0.0f, b);  // the state entering the tile rides on lane 0's map
+            // inclusive scan over the comb's 32 lanes on the DPP network: shifts 1, 2, 4, 8 inside the 16-lane rows (lanes
+            // shifted in from outside read 0), then lane 15 of the first row into the second with the lane's distance
+            b = fmaf(apw[0], rv_dpp<0x111>(b), b);
+            b = fmaf(apw[1], rv_dpp<0x112>(b), b);
+            b = fmaf(apw[2], rv_dpp<0x114>(b), b);
+            b = fmaf(apw[3], rv_dpp<0x118>(b), b);
             b = fmaf(m15, rv_dpp<0x142, 0xA>(b), b);
-            b = fmaf(m31, rv_dpp<0x143, 0xC>(b), b);
-            const float carry = rv_dpp<0x138>(b) + dlane * last_in;  // wave_shr:1, lane 0 reads 0
-            float last = carry;
+            // state entering this lane's run = the scan of the lane before it (lane 0 of the comb: the tile's entering state)
+            const float prev = rv_dpp<0x138>(b);  // wave_shr:1
+            float filt = cl == 0 ? last_in : prev;
+            const float inv[RV_RUN] = {n0.x, n0.y, n1.x, n1.y, n2.x, n2.y};
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                last = (o[i] * omd) + (last * damp);
-                w[i] = in_c[3 * lane + i] + (last * fbk);
+            for (int i = 0; i < RV_RUN; ++i) {
+                filt = fmaf(filt, damp, pq[i]);
+                w[i] = inv[i] + (filt * fbk);
             }
+            if (straight) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                cbuf[idx[i]] = w[i];
-                cmb[wv * RV_TT + 3 * lane + i] = o[i];
+                for (int i = 0; i < RV_RUN; ++i) cbuf[base + i] = w[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < RV_RUN; ++i) {
+                    int p = base + i;
+                    p = p >= csz ? p - csz : p;
+                    cbuf[p] = w[i];
+                }
             }
-            last_in = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(last), 63));
+            *(f2 *)cmb = (f2){o[0], o[1]};
+            *(f2 *)(cmb + 2) = (f2){o[2], o[3]};
+            *(f2 *)(cmb + 4) = (f2){o[4], o[5]};
+            // the comb's last lane holds the state leaving the tile
+            const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(filt), 31));
+            const float e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(filt), 63));
+            last_in = lane < 32 ? e0 : e1;
             cpos += RV_TT;
             cpos = cpos >= csz ? cpos - csz : cpos;
+            base = cpos + RV_RUN * cl;
+            base = base >= csz ? base - csz : base;
+            straight = base + RV_RUN <= csz;  // the lane's run does not cross the end of the circular line
+            if (straight) {
+#pragma unroll
+                for (int i = 0; i < RV_RUN; ++i) o[i] = cbuf[base + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < RV_RUN; ++i) {
+                    int p = base + i;
+                    p = p >= csz ? p - csz : p;
+                    o[i] = cbuf[p];
+                }
+            }
+        }
+    } else if (wv < RV_COMB_WAVES + RV_AP_WAVES) {
+        // ---- all-pass role: thread u = (channel u & 1, sample u >> 1) of tile k - 1: comb sum, 4 series all-passes, width mix
+        // (the other channel of the sample is the neighbouring lane), wet/dry, store
+        const int u = tid - RV_COMB_WAVES * 64, c2 = u & 1, t2 = u >> 1;
+        float *yc_g = c2 == 0 ? yl : yr;
+        int appos[4] = {0, 0, 0, 0}, apsz[4], apoff[4];  // geometry copied out of the kernel-argument struct once
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            apsz[j] = g.ap_size[c2 * 4 + j];
+            apoff[j] = g.ap_off[c2 * 4 + j];
+        }
+        int m3 = 2;            // (k - 1) % 3 at k = 0
+        int64_t t_out = -(int64_t)RV_TT + t2;
+        for (int k = 0; k <= ntiles; ++k) {
+            RV_BARRIER();
+            if (k >= 1) {
+                const float *cmb = s_comb + ((k - 1) & 1) * RV_CB + c2 * (8 * RV_TT + RV_PAD) + t2;
+                float cs[8], bv[4];
+                float *abp[4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cs[j] = cmb[j * RV_TT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // every line is read before any is written: one LDS round trip, not four
+                    int p = appos[j] + t2;
+                    p = p >= apsz[j] ? p - apsz[j] : p;
+                    abp[j] = state + apoff[j] + p;
+                    bv[j] = *abp[j];
+                    appos[j] += RV_TT;
+                    appos[j] = appos[j] >= apsz[j] ? appos[j] - apsz[j] : appos[j];
+                }
+                const float xd = s_x[m3 * RV_XB + c2 * (RV_TT + RV_PAD) + t2];
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += cs[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *abp[j] = acc + (bv[j] * 0.5f);
+                    acc = bv[j] - acc;
+                }
+                const float other = rv_dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the other channel of this sample
+                if (t_out < L) yc_g[t_out] = acc * wet1 + other * wet2 + xd * dry;
+            }
+            m3 = m3 == 2 ? 0 : m3 + 1;
+            t_out += RV_TT;
+        }
+    } else {
+        // ---- staging role: thread v < RV_TT / 2 owns samples 2 v, 2 v + 1 of both channels.  Tile k + 1 is written to LDS in
+        // step k out of the ring slot filled RV_PD steps earlier; loads are clamped, not branched around.
+        const int v = tid - (RV_COMB_WAVES + RV_AP_WAVES) * 64;
+        const bool act = v < RV_TT / 2;
+        const int64_t Lm1 = L - 1;
+        f4 ring[RV_PD];  // (l0, l1, r0, r1) of tile t in ring[t % RV_PD]
+        auto fetch = [&](int64_t t) -> f4 {
+            const int64_t i0 = t * RV_TT + 2 * (act ? v : 0), i1 = i0 + 1;
+            const int64_t j0 = i0 < Lm1 ? i0 : Lm1, j1 = i1 < Lm1 ? i1 : Lm1;
+            const float a0 = xl[j0], a1 = xl[j1], b0 = xr[j0], b1 = xr[j1];
+            return (f4){i0 < L ? a0 : 0.0f, i1 < L ? a1 : 0.0f, i0 < L ? b0 : 0.0f, i1 < L ? b1 : 0.0f};
+        };
+        auto put = [&](const f4 &q, int buf3, int buf2) {
+            if (act) {
+                *(f2 *)(s_x + buf3 * RV_XB + 2 * v) = (f2){q.x, q.y};
+                *(f2 *)(s_x + buf3 * RV_XB + RV_TT + RV_PAD + 2 * v) = (f2){q.z, q.w};
+                *(f2 *)(s_in + buf2 * RV_TT + 2 * v) = (f2){(q.x + q.z) * 0.015f, (q.y + q.w) * 0.015f};
+            }
+        };
+        put(fetch(0), 0, 0);
+#pragma unroll
+        for (int j = 0; j < RV_PD; ++j) ring[(j + 1) % RV_PD] = fetch(j + 1);
+        int m3 = 1;  // (k + 1) % 3 at k = 0
+        for (int k0 = 0; k0 <= ntiles; k0 += RV_PD) {
+#pragma unroll
+            for (int kk = 0; kk < RV_PD; ++kk) {
+                const int k = k0 + kk;
+                if (k > ntiles) break;
+                RV_BARRIER();
+                put(ring[(kk + 1) % RV_PD], m3, (k + 1) & 1);   // tile k + 1 (zeros past the end of the signal)
+                ring[(kk + 1) % RV_PD] = fetch((int64_t)k + 1 + RV_PD);
+                m3 = m3 == 2 ? 0 : m3 + 1;
+            }
         }
     }
 }
@@ -794,8 +883,10 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                 reverb_geometry(sample_rate, g);
                 int mins = g.ap_size[0];
                 for (int k = 0; k < 8; ++k) mins = g.ap_size[k] < mins ? g.ap_size[k] : mins;
-                const size_t lds = (size_t)(g.state_floats + RV_TT * (2 + 6 + 32)) * sizeof(float);
-                STITO_REQUIRE(mins >= RV_TT && lds <= 160 * 1024, STITO_E_UNSUPPORTED,
+                const size_t lds = (size_t)(g.state_floats + RV_TILE_FLOATS) * sizeof(float);
+                int minc = g.comb_size[0];
+                for (int k = 0; k < 16; ++k) minc = g.comb_size[k] < minc ? g.comb_size[k] : minc;
+                STITO_REQUIRE(mins >= RV_TT && minc >= 2 * RV_TT + RV_RUN && lds <= 160 * 1024, STITO_E_UNSUPPORTED,
                               "Reverb: sample rate %.0f needs delay lines outside the LDS-resident design", sample_rate);
                 STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(k_reverb, dim3(pop), dim3(RV_THREADS), lds, st, in, audio_dev, cand_stride, L, cf, g);
