@@ -1158,6 +1158,8 @@ extern "C" int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed
         return stito_conv3x3_bn_relu(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cin, cout, pool, algo, stream);
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
     STITO_REQUIRE(cin % 8 == 0 && cout % 64 == 0 && wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
+    STITO_REQUIRE(stito_conv3x3_supported(n, H, W, cin, cout, pool, algo), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(4x4,3x3), hoisted input transform): %dx%d map, %d -> %d channels not covered (cout must be a multiple of 256)", H, W, cin, cout);
     STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
     return launch_wino43_pre(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
                              (float *)workspace_dev, workspace_bytes, (hipStream_t)stream);

@@ -46,6 +46,9 @@ def test_error_paths(dev, pm):
     assert lib.stito_conv3x3_supported(4, 16, 16, 12, 64, 0, 0) == 0   # cin not a multiple of the K chunk
     rc = lib.stito_conv3x3_bn_relu(None, None, None, None, None, 4, 16, 16, 12, 64, 0, 0, None)
     assert rc != 0 and len(lib.stito_last_error()) > 0                  # status code + message, no crash
+    # the hoisted-transform algorithm on a shape it does not cover (cout not a multiple of 256): refused before any launch
+    rc = lib.stito_conv3x3_bn_relu_ws(None, None, None, None, None, 4, 16, 16, 64, 64, 0, 3, None, 0, None)
+    assert rc == _hip.E_UNSUPPORTED and b"256" in lib.stito_last_error()
     # reverb declared mono is a spec error like the reference's channel handling (run_optim.py:401-406)
     bad = E.make_plugins([("Reverb", E.BasicReverb, 1)])
     with pytest.raises(ValueError):

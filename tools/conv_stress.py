@@ -29,6 +29,9 @@ for li, r in enumerate(r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 
     Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
     outs = {}
     for m in [0] + [int(v) for v in a.modes.split(",")]:
+        if not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m):
+            print(f"layer {li}: algo {m} does not cover this shape, skipped", flush=True)
+            continue
         packed = torch.empty(L.stito_cnn14_packed_conv_floats(r["cout"], r["cin"], m), device=dev)
         _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), r["cout"], r["cin"], m, _hip.ptr(packed), st))
         for rep in range(1 if m == 0 else a.reps):
