@@ -77,7 +77,8 @@ typedef struct {
 
 const char *stito_last_error(void);
 /* ABI version: 4 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
- * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes). */
+ * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
+ * was `reserved`: 0 keeps the packed-run layout of versions 1-3). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
