@@ -69,10 +69,32 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     const int64_t base = fe.no_center ? t * fe.hop : t * fe.hop - N2;
 
     // ---- load, normalise, mid/side, window, pack even/odd samples as complex ------------------
-    // Interior frames whose first sample is 8-byte aligned (every frame but the reflected ends when hop and the stream
-    // offsets are even) fetch sample pairs as one 8-byte load: half the load instructions and index arithmetic of the
-    // general path (measured by ablation: this stage was 1.0 of the kernel's 2.3 ms).  Same values, same operations.
-    const bool fast = base >= 0 && base + N <= L && (((uintptr_t)(xl + base) | (uintptr_t)(xr + base) | (uintptr_t)fe.window) & 7) == 0;
+    // Interior frames (every frame but the reflected ends) fetch four samples per 16-byte load when the frame start is
+    // 16-byte aligned (hop and stream offsets multiples of 4), sample pairs per 8-byte load when it is 8-byte aligned: a
+    // quarter / half of the load instructions and index arithmetic of the general path (by ablation this stage was 1.0 of
+    // the kernel's 2.3 ms).  Same values, same operations.
+    const bool inside = base >= 0 && base + N <= L;
+    const uintptr_t al = (uintptr_t)(xl + base) | (uintptr_t)(xr + base) | (uintptr_t)fe.window;
+    if (inside && (al & 15) == 0 && (N2 & 1) == 0) {  // four samples = two packed points per 16-byte load
+        const float4 *l4 = (const float4 *)(xl + base), *r4 = (const float4 *)(xr + base), *w4 = (const float4 *)fe.window;
+        for (int j = tid; j < (N2 >> 1); j += FE_THREADS) {
+            const float4 a = l4[j], w = w4[j];
+            float a0 = a.x * r1, a1 = a.y * r1, a2 = a.z * r1, a3 = a.w * r1;
+            if (second) { a0 = a0 * r2; a1 = a1 * r2; a2 = a2 * r2; a3 = a3 * r2; }
+            if (C == 2) {
+                const float4 b = r4[j];
+                float b0 = b.x * r1, b1 = b.y * r1, b2 = b.z * r1, b3 = b.w * r1;
+                if (second) { b0 = b0 * r2; b1 = b1 * r2; b2 = b2 * r2; b3 = b3 * r2; }
+                const float m0 = (a0 + b0) * 0.5f, m1 = (a1 + b1) * 0.5f, m2 = (a2 + b2) * 0.5f, m3 = (a3 + b3) * 0.5f;  // / 2 is exact
+                const float s0 = (a0 - b0) * 0.5f, s1 = (a1 - b1) * 0.5f, s2 = (a2 - b2) * 0.5f, s3 = (a3 - b3) * 0.5f;
+                *(float4 *)(bufA + 2 * j) = make_float4(m0 * w.x, m1 * w.y, m2 * w.z, m3 * w.w);
+                *(float4 *)(bufA + N2 + 2 * j) = make_float4(s0 * w.x, s1 * w.y, s2 * w.z, s3 * w.w);
+            } else {
+                *(float4 *)(bufA + 2 * j) = make_float4(a0 * w.x, a1 * w.y, a2 * w.z, a3 * w.w);
+            }
+        }
+    } else {
+    const bool fast = inside && (al & 7) == 0;
     for (int m = tid; m < N2; m += FE_THREADS) {
         float a0, a1, b0 = 0.0f, b1 = 0.0f, w0, w1;
         if (fast) {
@@ -96,6 +118,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
         } else {
             bufA[m] = make_float2(a0 * w0, a1 * w1);
         }
+    }
     }
     __syncthreads();
 
@@ -166,18 +189,28 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     __syncthreads();
 
     // ---- mel bands, 10 log10(clamp(., 1e-10)), input norm ---------------------------------------
+    // four lanes per (stream, band), each summing a quarter of the band's run of bins, joined in a fixed order (quarter 0 +
+    // 1, 2 + 3, then the two halves): the widest bands are ~60 bins and with one lane per band the waves that hold them
+    // kept the whole workgroup waiting -- 0.7 ms of the kernel's 2.0 by ablation
     const int M = fe.n_mels;
-    for (int q = tid; q < C * M; q += FE_THREADS) {
-        const int c = q / M, m = q - c * M;
+    for (int q0 = 0; q0 < 4 * C * M; q0 += FE_THREADS) {
+        const int q = q0 + tid;
+        const bool live = q < 4 * C * M;    // C * M * 4 is a multiple of 4: a quad of lanes is live or not as a whole
+        const int part = q & 3, cm = live ? q >> 2 : 0;
+        const int c = cm / M, m = cm - c * M;
         const int st = fe.mel_start[m], ln = fe.mel_len[m];
-        // weights at w[i * mel_stride]: with the interleaved table (stride = n_mels, offset = m) the lanes of a wave read
-        // consecutive floats per step; with packed runs (stride 1) every lane is on its own cache line -- 64 lines per
-        // load instruction, which made this loop 0.85 of the kernel's 2.3 ms
+        const int lq = (ln + 3) >> 2;
+        const int beg = part * lq < ln ? part * lq : ln, end = beg + lq < ln ? beg + lq : ln;
+        // weights at w[i * mel_stride]: with the interleaved table (stride = n_mels, offset = m) neighbouring bands read
+        // neighbouring floats per step; with packed runs (stride 1) every lane is on its own cache line
         const float *w = fe.mel_w + fe.mel_off[m];
         const int ws = fe.mel_stride;
         const float *p = pw + c * (N2 + 1) + st;
         float acc = 0.0f;
-        for (int i = 0; i < ln; ++i) acc = fmaf(p[i], w[i * ws], acc);
+        for (int i = beg; i < end; ++i) acc = fmaf(p[i], w[i * ws], acc);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (!live || part) continue;
         float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
         if (fe.norm_mode == STITO_NORM_MINMAX) {
             v = fminf(fmaxf(v, -80.0f), 40.0f);
