@@ -66,7 +66,7 @@ def _oracle_chain_raw(op, x, w):
 
 
 SINGLE_FX = [
-    ("ParametricEQ", 1, 2e-6), ("ParametricEQ", 2, 2e-6), ("Compressor", 2, 2e-5), ("Distortion", 1, 2e-6),
+    ("ParametricEQ", 1, 2e-6), ("ParametricEQ", 2, 2e-6), ("Compressor", 2, 2e-6), ("Distortion", 1, 2e-6),
     ("Gain", 2, 1e-6), ("Delay", 1, 2e-6), ("Delay", 2, 2e-6), ("Reverb", 2, 2e-5), ("Reverb", 1, 2e-5),
 ]
 
@@ -96,7 +96,7 @@ def test_compressor_ballistics_corners(dev):
     an odd length.  The GPU evaluates the switching one-pole as max(c_a y + (1-c_a) v, c_r y + (1-c_r) v)
     and crosses 15-sample blocks with their composed (max, +) block functions (compressor.hip); the oracle
     walks v + c (y - v) sample by sample: the same real-number map with different float32 rounding
-    (measured here: <= 3e-7 of peak; bound 2e-5 like the other compressor test)."""
+    (measured here: <= 2.4e-7 of peak; bound 2e-6 like the other compressor test)."""
     op, pp = _plugins_pair(["Compressor"])
     raw = lambda v, lo, hi: (v - lo) / (hi - lo)
     rows = []
@@ -112,7 +112,7 @@ def test_compressor_ballistics_corners(dev):
             assert np.abs(ref).max() < 0.5 * np.abs(x).max()  # it really compresses
             err = np.abs(got[p] - ref).max() / max(1.0, np.abs(ref).max())
             print(f"compressor att/rel corner {p} n={n}: err {err:.3e}")
-            assert err < 2e-5
+            assert err < 2e-6
 
 
 @pytest.mark.parametrize("n", [1, 14, 15, 16, 29, 30, 31, 479, 480, 481, 495, 7681])
