@@ -730,7 +730,7 @@ extern "C" int stito_chain_num_dims(const stito_fx_desc *chain, int n_fx) {
 
 extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n_fx, int in_channels,
                                                int64_t n_samples, int pop) {
-    const int cout = stito_chain_out_channels(chain, n_fx, in_channels);
+    (void)in_channels;  // the compressor's share is sized for two channels per candidate whatever the chain does
     size_t coef = align_up((size_t)(n_fx > 0 ? n_fx : 1) * pop * COEF_STRIDE * sizeof(double), 256);
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
