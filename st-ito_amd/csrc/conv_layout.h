@@ -53,6 +53,28 @@ __device__ __forceinline__ void glds16_m0(const float *sbase, unsigned voff, uns
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
+// Division by a runtime divisor that is fixed per launch (map height, tile rows per stream, ...).  hipcc turns `a / d`
+// into a ~35-instruction sequence; a conv workgroup does ten of them before it can issue its first copy (measured: 700 of
+// its ~7 400 prologue cycles).  For 0 <= a < 2^22 and 1 <= d < 2^22 the float quotient is off by at most one, which the
+// remainder check repairs exactly; larger operands take the compiler's division.
+struct FDiv {
+    int d;
+    float rcp;
+};
+static inline FDiv make_fdiv(int d) { return FDiv{d, 1.0f / (float)d}; }
+__device__ __forceinline__ int fdiv(int a, const FDiv f, int &rem) {
+    if ((unsigned)(a | f.d) >= (1u << 22)) {
+        rem = a % f.d;
+        return a / f.d;
+    }
+    int q = (int)(__int2float_rn(a) * f.rcp);
+    int r = a - q * f.d;
+    if (r < 0) { --q; r += f.d; }
+    else if (r >= f.d) { ++q; r -= f.d; }
+    rem = r;
+    return q;
+}
+
 // conv_wino43.hip
 bool wino43_supported(const ConvShape &c, bool pool);
 double wino43_issued_flops(const ConvShape &c, bool pool);

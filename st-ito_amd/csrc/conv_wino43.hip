@@ -58,6 +58,7 @@ struct Wino43Geom {
     int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
     int n_mblocks;     // pixel blocks (MODE 1: the grid is padded to whole XCD rounds)
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
+    FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
     // FUSE1 instantiation (conv_block1: the Cin = 1 first conv computed on the fly while staging the patch):
     const float *fw;   // first-conv weights, BN scale folded, packed [16 chunks][9 taps][4 channels]
@@ -148,8 +149,10 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
-    int m_blk = blockIdx.x / n_tiles;  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    int n0 = VOUT ? 0 : (blockIdx.x % n_tiles) * 64;
+    int ct_;
+    int m_blk = VOUT ? (int)blockIdx.x / n_tiles : fdiv((int)blockIdx.x, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    if (VOUT) ct_ = (int)blockIdx.x % n_tiles;
+    int n0 = VOUT ? 0 : ct_ * 64;
     if constexpr (PREV) {
         // MODE 1 streams 18 KB of V and 36 KB of U per period through L2, and workgroup b runs on XCD b % 8 (own L2 each).
         // With the channel tile fastest the 8+ sharers of a V slab sit on 8 different XCDs: every slab is fetched 8 times
@@ -163,16 +166,18 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         n0 = ct * 64;
         if (m_blk >= g.n_mblocks) return;
     }
-    const int cb = m_blk % g.n_col_blocks;
-    const int rb = m_blk / g.n_col_blocks;
+    int cb;
+    const int rb = fdiv(m_blk, g.fNCB, cb);
     const int vtr0 = rb * TTH;  // first virtual tile row (s * TR + tr) of the block
     const int tc0 = cb * TTW;
     // MODE 2: this workgroup transforms chunks c_base .. c_base + n_chunks - 1 of the pixel block (an even count >= 2)
     const int n_chunks_all = g.Cin / W43_K;
     const int n_chunks = VOUT ? n_chunks_all / g.n_cgroups : n_chunks_all;
-    const int c_base = VOUT ? (blockIdx.x % n_tiles) * n_chunks : 0;
+    const int c_base = VOUT ? ct_ * n_chunks : 0;
     float *patch0 = smem + 2 * BUF;
-    const int iv_lo = (vtr0 / g.TR) * g.H + 4 * (vtr0 % g.TR) - 1;  // input virtual row (s*H + h) of patch row 0
+    int tr0_;
+    const int s0_ = fdiv(vtr0, g.fTR, tr0_);
+    const int iv_lo = s0_ * g.H + 4 * tr0_ - 1;  // input virtual row (s*H + h) of patch row 0
 
 #define W43_STAMP(SLOT)                                                                                 \
     if (TRACE && (blockIdx.x & 255) == 100 && (blockIdx.x >> 8) < 8 && lane == 0 && (wv & 3) == 0)      \
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     const float *v_base = in + (int64_t)m_blk * n_chunks_all * W43_V;  // PREV: this pixel block's V slabs
 
     // ---- halo patch staging by LDS-DMA: slot q = tid + 512 j of the permuted layout (W43Patch) holds pixel (pr, pc) ------
-    const int s_first = (iv_lo < 0 ? 0 : iv_lo) / g.H;
+    int h_first;  // row of the first patch row that exists, inside its stream
+    const int s_first = fdiv(iv_lo < 0 ? 0 : iv_lo, g.fH, h_first);
     const int64_t plane8 = (int64_t)g.H * g.W * 8;  // floats per 8-channel plane of one stream
     const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W) + (int64_t)(c_base >> 1) * plane8;
     unsigned p_off[NPL];                             // per-lane byte offset from the chunk's base
@@ -216,13 +222,15 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             const int iv = iv_lo + pr;
             const int w = 4 * tc0 - 1 + pc;
             const bool ok = q < PL::SLOTS && pr < g.PR && pc < PWC && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
-            const int s_ = ok ? iv / g.H : s_first, h_ = ok ? iv % g.H : 0, w_ = ok ? w : 0;
+            int hq_;
+            const int sq_ = fdiv(ok ? iv : 0, g.fH, hq_);
+            const int s_ = ok ? sq_ : s_first, h_ = ok ? hq_ : 0, w_ = ok ? w : 0;
             p_off[j] = FUSE1 ? 0u : (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
             p_mask[j] = __builtin_amdgcn_ballot_w64(ok);
             if (FUSE1) {
                 // window coordinates: rows in PADDED virtual-row space pv = s (H + 2) + h + 1 (a zero row above and below every
                 // stream, so the first conv's own padding needs no test), columns w - (4 tc0 - 2)
-                const int pv = s_ * (g.H + 2) + h_ + 1, pv0 = s_first * (g.H + 2) + (iv_lo < 0 ? 0 : iv_lo) % g.H;  // pv0 = pv(first row) - 1
+                const int pv = s_ * (g.H + 2) + h_ + 1, pv0 = s_first * (g.H + 2) + h_first;  // pv0 = pv(first row) - 1
                 f_win[j] = ok ? (pv - pv0 - 1) * W43_WIN_COLS + pc : 0;          // top-left neighbour (row pv - 1, column w - 1)
                 f_dst[j] = ok ? q * W43_K : -1;                                  // lanes without a pixel write a trash row
             }
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     if (!FUSE1) W43_COPY_P(1, 1)
     if (FUSE1) {
         // raw log-mel window (1 channel) of the block: rows in padded virtual-row space from pv0, columns from 4 tc0 - 2
-        const int pv0 = s_first * (g.H + 2) + (iv_lo < 0 ? 0 : iv_lo) % g.H;
+        const int pv0 = s_first * (g.H + 2) + h_first;
         for (int e = tid; e < W43_WIN_ROWS * W43_WIN_COLS; e += W43_THREADS) {
             const int rw = e / W43_WIN_COLS, cw = e % W43_WIN_COLS;
             const int pv = pv0 + rw, s_ = pv / (g.H + 2), h_ = pv % (g.H + 2) - 1;
@@ -399,7 +407,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = 5; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
         }
         const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
-        const int s_ = vtr / g.TR, tr = vtr % g.TR;
+        int tr;
+        const int s_ = fdiv(vtr, g.fTR, tr);
         const int pc0 = s_ * g.H + 4 * tr - 1 - iv_lo;  // patch row of this tile's first input row
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
@@ -581,7 +590,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         const int vtr = vtr0 + e_tile / TTW;
         const int tc = tc0 + e_tile % TTW;
         if (vtr < g.VTR && tc < g.TC) {
-            const int s = vtr / g.TR, tr = vtr % g.TR;
+            int tr;
+            const int s = fdiv(vtr, g.fTR, tr);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -651,6 +661,7 @@ static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &l
     if (g.TR < 1 || g.TC < 1) return false;
     g.VTR = (int64_t)g.S * g.TR;
     g.n_col_blocks = (g.TC + TTW - 1) / TTW;
+    g.fH = make_fdiv(g.H); g.fTR = make_fdiv(g.TR); g.fNCB = make_fdiv(g.n_col_blocks); g.fNT = make_fdiv(g.Cout / 64);
     const int64_t nrb = (g.VTR + TTH - 1) / TTH;
     blocks = nrb * g.n_col_blocks * (g.Cout / 64);
     if (nrb * g.n_col_blocks >= (1 << 30) || blocks >= (1ll << 31)) return false;
