@@ -461,3 +461,26 @@ def test_eval_pst_chain_catalogue():
         assert list(pl) == names and n == ndim == len(init)
     with pytest.raises(ValueError):
         ep.get_plugins("general-vst")
+
+
+def test_bench_measurement_bookkeeping(tmp_path, monkeypatch):
+    """bench.py's roofline inputs: the conv table sums to SURVEY 8(d)'s 37.22 GFLOP per 10 s stream (37.15 for the eleven
+    MFMA layers), the committed PMC file belongs to the kernel sources in this tree, and a PMC file taken on other sources
+    or another stream count is refused (traffic = None with the reason) rather than quoted."""
+    import json
+    import bench
+    rows = bench.conv_layer_table(469)
+    assert len(rows) == 12 and [r["cout"] for r in rows][::2] == [64, 128, 256, 512, 1024, 2048]
+    assert abs(sum(r["flops"] for r in rows) / 1e9 - 37.223) < 0.01
+    assert abs(sum(r["flops"] for r in rows if r["cin"] % 8 == 0) / 1e9 - 37.154) < 0.01
+    committed = json.load(open(bench.PMC_TRAFFIC_JSON))
+    assert committed["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/profile_round.sh after touching the conv kernels"
+    t, note = bench.pmc_traffic_per_launch(committed["n_streams"])
+    assert t == committed["traffic_bytes_per_launch"] and t > committed["algorithmic_bytes_per_launch"] and "round2_conv_pmc_traffic" in note
+    assert bench.pmc_traffic_per_launch(committed["n_streams"] + 1)[0] is None
+    stale = dict(committed, kernel_source_hash="0" * 16)
+    p = tmp_path / "pmc.json"
+    p.write_text(json.dumps(stale))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_JSON", str(p))
+    t, note = bench.pmc_traffic_per_launch(committed["n_streams"])
+    assert t is None and "was taken on kernel sources" in note
