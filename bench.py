@@ -39,6 +39,8 @@ import torch  # noqa: E402
 
 SR = 48000
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_32x32x16_f16), 1024 FLOP/clk/SIMD
+PIPE_PEAK = {"f32": MFMA_F32_PEAK_TFLOPS, "f16": MFMA_F16_PEAK_TFLOPS}
 
 
 def synth_audio(seed, chs, n):
@@ -99,13 +101,14 @@ def pmc_traffic_per_launch(n_streams):
     return float(d["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(PMC_TRAFFIC_JSON)}"
 
 
-ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)", 3: "winograd F(4x4,3x3), input transform hoisted (two kernels)"}
+ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)", 3: "winograd F(4x4,3x3), input transform hoisted (two kernels)",
+              4: "winograd F(4x4,3x3), input transform hoisted, f32 operands as f16 hi + lo on the f16 matrix pipe (3 products, f32 accumulate)"}
 
 
 def conv_layer_times(model, n_streams, T, reps=3):
     """Per-layer table (informational): every conv launch of the trunk timed on its own with HIP events on the launch
-    stream (torch's current stream is the stream the C ABI launches on).  -> (layers, issued MFMA FLOPs of the 11 MFMA
-    launches of one trunk pass at n_streams)."""
+    stream (torch's current stream is the stream the C ABI launches on).  -> (layers, per timed launch of one trunk pass
+    at n_streams, in launch order: (matrix pipe, MFMA FLOPs issued, bytes copied into LDS by the split-precision kernel))."""
     from st_ito import _hip
     L = _hip.lib()
     W, FE, _ = model._ensure()
@@ -115,7 +118,7 @@ def conv_layer_times(model, n_streams, T, reps=3):
     x = torch.randn((n_streams, T, 128), device=dev).clamp_(-1, 1)
     layers = []
     cur = x
-    issued_total = 0.0
+    order = []
     fused = bool(W.conv1_fused_w_dev) and bool(W.conv_wino_dev[1]) and W.conv_wino_algo[1] == 2 and \
         L.stito_conv_block1_fused_supported(n_streams, rows[0]["H"], rows[0]["W"], rows[0]["cout"], rows[1]["cout"], 1)
     for i, r in enumerate(rows):
@@ -136,13 +139,13 @@ def conv_layer_times(model, n_streams, T, reps=3):
             ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
             fl = (r["flops"] + rows[0]["flops"]) * n_streams
             issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 2)
-            issued_total += issued
+            order.append(("f32", issued, 0.0))
             layers.append(dict(layer="conv_block1 (conv1 fused into conv2's patch staging)", algo=ALGO_NAMES[2], H=r["H"], W=r["W"], cin=1,
                                cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2),
                                mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)))
             cur = out
             continue
-        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3) else 1
+        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3, 4) else 1
         wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], walgo)
         algo = walgo if wino else 0
         wsb = L.stito_conv3x3_workspace_bytes(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
@@ -159,15 +162,22 @@ def conv_layer_times(model, n_streams, T, reps=3):
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         fl = r["flops"] * n_streams
         issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
-        issued_total += issued
+        pipe = "f16" if algo == 4 else "f32"
+        # split-precision kernel: every operand element of every product travels L2 -> LDS as 4 bytes (hi + lo); per workgroup
+        # 36 positions x (32 tiles + 64 couts) x cin elements, i.e. 4 / (2 * 32 * 64 / 96) bytes per f32-equivalent MAC
+        fill = issued / 3.0 / 2.0 * (96.0 / (32.0 * 64.0)) * 4.0 if algo == 4 else 0.0
         row = dict(layer=f"conv_block{i // 2 + 1}.conv{i % 2 + 1}", algo=ALGO_NAMES[algo] if r["cin"] % 8 == 0 else "direct (VALU, cin = 1)",
                    H=r["H"], W=r["W"], cin=r["cin"], cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2))
         if issued:
+            order.append((pipe, issued, fill))
+            row["pipe"] = pipe
             row["mfma_issued_tflops"] = round(issued / ms / 1e9, 2)
-            row["mfma_frac"] = round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)
+            row["mfma_frac"] = round(issued / ms / 1e9 / PIPE_PEAK[pipe], 4)
+            if fill:
+                row["lds_fill_tbps"] = round(fill / ms / 1e9, 2)
         layers.append(row)
         cur = out
-    return layers, issued_total
+    return layers, order
 
 
 def _pool_render(args):
@@ -310,10 +320,10 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    conv_ms, conv_launches = ctypes.c_double(0.0), ctypes.c_int(0)
+    conv_each, conv_launches = (ctypes.c_double * 65536)(), ctypes.c_int(0)
     if timing:
         _hip.check(_hip.lib().stito_conv_timing_enable(0))
-        _hip.check(_hip.lib().stito_conv_timing_read(ctypes.byref(conv_ms), ctypes.byref(conv_launches)))
+        _hip.check(_hip.lib().stito_conv_timing_read_each(conv_each, 65536, ctypes.byref(conv_launches)))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -323,7 +333,10 @@ def main():
         "metric": "candidate-evals/sec (pop x iters), 48 kHz 10 s stereo, 5-effect chain",
         "value": round(P_total * args.steps / dt, 3), "unit": "candidate-evals/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (effects f32 / f64 as the reference; trunk convs with >= 256 output channels: f32 operands carried as f16 hi + lo pairs "
+                 "on the f16 matrix pipe, f32 accumulate -- as close to float64 as the f32 pipe, tools/ubench/split_mfma.hip)",
+        "data": "synthetic",
         "config": {"workload": f"ES evaluate-population: pop={args.pop_per_gpu}/GPU ({P_total} total), 48 kHz stereo "
                    f"{args.seconds:g} s, chain EQ/comp/reverb/EQ/gain (D={D}), AFx-Rep Cnn14 (seeded random weights), "
                    "CMA-ES seed 42", "pop_per_gpu": args.pop_per_gpu, "n_samples": n, "chain": kinds,
@@ -334,32 +347,62 @@ def main():
             T = n // 1024 + 1
             streams_per_launch = min(2 * args.pop_per_gpu, model.max_streams_per_pass)
             passes_per_step = (2 * args.pop_per_gpu + streams_per_launch - 1) // streams_per_launch
-            layers, issued_pass = conv_layer_times(model, streams_per_launch, T)
+            layers, order = conv_layer_times(model, streams_per_launch, T)
             # algorithmic conv FLOPs (direct-convolution count 2*9*cin*cout*H*W) of the MFMA launches of one step on this rank
             fl_step = sum(r["flops"] for r in conv_layer_table(T) if r["cin"] % 8 == 0) * 2 * args.pop_per_gpu
-            n_l = max(conv_launches.value, 1)
-            issued_timed = issued_pass * passes_per_step * args.steps      # FLOPs the timed launches issued (full passes)
-            achieved = issued_timed / conv_ms.value / 1e9                  # TFLOP/s of MFMA work over the timed region's conv launches
+            n_timed = min(conv_launches.value, 65536)
+            # the timed launches repeat the pass's launch order; the last pass of a step may be partial (fewer streams): its
+            # issued work is scaled by its share of the streams
+            per_pass = len(order)
+            fam = {p: dict(ms=0.0, flops=0.0, fill=0.0, n=0) for p in ("f32", "f16")}
+            n_full, rem = divmod(2 * args.pop_per_gpu, streams_per_launch)
+            pass_scale = [1.0] * n_full + ([rem / streams_per_launch] if rem else [])
+            conv_ms_total = 0.0
+            for i in range(n_timed):
+                pipe, issued, fill = order[i % per_pass]
+                sc = pass_scale[(i // per_pass) % passes_per_step]
+                f = fam[pipe]
+                f["ms"] += conv_each[i]; f["flops"] += issued * sc; f["fill"] += fill * sc; f["n"] += 1
+                conv_ms_total += conv_each[i]
             traffic, traffic_note = pmc_traffic_per_launch(streams_per_launch)
-            algos = sorted({l["algo"] for l in layers if "mfma_frac" in l})
-            out["roofline"] = {
-                "bound": "mfma",
-                "kernel": "the 11 f32-MFMA 3x3-conv launches of a trunk pass (" + ", ".join(algos) + "; v_mfma_f32_32x32x2_f32). achieved = "
-                          "FLOPs of the MFMA instructions actually issued (tile padding included) / launch time; algorithmic_tflops "
-                          "counts direct-convolution FLOPs (2*9*cin*cout*H*W) of the same launches and may exceed the peak",
-                "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                "algorithmic_tflops": round(fl_step * args.steps / conv_ms.value / 1e9, 2),
-                "algorithmic_frac": round(fl_step * args.steps / conv_ms.value / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
-                "flops_per_launch": issued_timed / n_l, "algorithmic_flops_per_launch": fl_step * args.steps / n_l,
-                "avg_launch_ms": round(conv_ms.value / n_l, 4),
-                "launches_timed": conv_launches.value, "n_streams": streams_per_launch,
-                "conv_share_of_step": round(conv_ms.value / (dt * 1e3), 4),
-                # whole path (DSP + front end + trunk + host) in direct-convolution FLOPs against the same peak
+
+            def family(pipe):
+                f = fam[pipe]
+                if not f["n"]:
+                    return None
+                ach = f["flops"] / f["ms"] / 1e9
+                names = sorted({l["algo"] for l in layers if l.get("pipe") == pipe})
+                d = {"bound": "mfma", "pipe": pipe,
+                     "kernel": f"the {f['n'] // max(args.steps * passes_per_step, 1)} 3x3-conv launches of a trunk pass on the {pipe} matrix pipe (" + "; ".join(names) +
+                               "). achieved = FLOPs of the MFMA instructions actually issued (tile padding included) / launch time",
+                     "achieved": round(ach, 2), "peak": PIPE_PEAK[pipe], "unit": "TFLOP/s", "frac": round(ach / PIPE_PEAK[pipe], 4),
+                     "flops_per_launch": f["flops"] / f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 4), "launches_timed": f["n"],
+                     "share_of_step": round(f["ms"] / (dt * 1e3), 4)}
+                if pipe == "f16":
+                    d["note"] = ("this family is bound by filling LDS from L2, not by the matrix pipe: 4 bytes per operand element (f16 hi + lo) "
+                                 "for 21.3 MACs; lds_fill is those bytes / launch time (the transform pass included in the time), against "
+                                 "24 TB/s measured for L2-resident streams (tools/ubench/split_mfma.hip)")
+                    d["lds_fill"] = {"achieved": round(f["fill"] / f["ms"] / 1e9, 2), "peak": 24.0, "unit": "TB/s",
+                                     "frac": round(f["fill"] / f["ms"] / 1e9 / 24.0, 4)}
+                return d
+
+            f32_fam, f16_fam = family("f32"), family("f16")
+            dominant, other = (f32_fam, f16_fam) if (f16_fam is None or (f32_fam and fam["f32"]["ms"] >= fam["f16"]["ms"])) else (f16_fam, f32_fam)
+            out["roofline"] = dict(dominant)
+            out["roofline"].update({
+                "algorithmic_tflops": round(fl_step * args.steps / conv_ms_total / 1e9, 2),
+                "algorithmic_note": "direct-convolution FLOPs (2*9*cin*cout*H*W) of ALL MFMA conv launches / their time; the Winograd "
+                                    "kernels need 2.25 / 9 of them, so this may exceed any peak",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE), all conv launches", "traffic_source": traffic_note,
+                "n_streams": streams_per_launch,
+                "conv_share_of_step": round(conv_ms_total / (dt * 1e3), 4),
+                "conv_ms_per_step": round(conv_ms_total / args.steps, 3),
+                # whole path (DSP + front end + trunk + host) in direct-convolution FLOPs against the f32 peak
                 "end_to_end_algorithmic_frac": round(fl_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 "layers": layers,
-            }
+            })
+            if other is not None:
+                out["roofline_other_pipe"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, kinds)
         print(json.dumps(out), flush=True)

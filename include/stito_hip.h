@@ -76,9 +76,9 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 4 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+/* ABI version: 5 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
- * was `reserved`: 0 keeps the packed-run layout of versions 1-3). */
+ * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
@@ -176,7 +176,14 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * to a workspace, the convolution streams them like the weights.  Same packed weights as STITO_CONV_WINOGRAD_F4,
         * same arithmetic and results; pays off when cout >= 512 (the workgroups that share a pixel block and differ only
         * in their 64 output channels no longer repeat the transform).  Needs stito_conv3x3_bn_relu_ws (ABI version 4). */
-       STITO_CONV_WINOGRAD_F4_PRE = 3 };
+       STITO_CONV_WINOGRAD_F4_PRE = 3,
+       /* The hoisted form on the f16 matrix pipe with float32 accumulation: every float32 operand (transformed input,
+        * transformed weight) travels as two f16 halves hi + lo of a power-of-two multiple of itself (22 significand bits;
+        * the scale is per layer for the weights and per stream for the input, chosen from the data so that nothing
+        * overflows), every product is hi hi' + hi lo' + lo hi'.  Results agree with the float32 forms to float32 rounding
+        * level (not bitwise); own packing (stito_cnn14_packed_conv_floats), needs cin % 64 == 0, cout % 256 == 0 and
+        * stito_conv3x3_bn_relu_ws (ABI version 5). */
+       STITO_CONV_WINOGRAD_F4_SPLIT = 4 };
 
 typedef struct {
     int32_t embed_dim;
@@ -188,7 +195,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4 or _F4_PRE (the latter two share a packing) */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing) or _F4_SPLIT */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -248,16 +255,19 @@ int stito_debug_wino_trace(long long *buf_dev);
  * GPU, like stito_last_error): enable and read from the thread that calls stito_cnn14_forward. */
 int stito_conv_timing_enable(int on);
 int stito_conv_timing_read(double *total_ms, int *n_launches);
+/* The same per launch, in launch order (bench.py attributes the launches to the matrix pipe they run on): fills
+ * ms_each[0 .. min(cap, n) - 1], returns n in *n_launches and clears the list. */
+int stito_conv_timing_read_each(double *ms_each, int cap, int *n_launches);
 /* FLOPs of the MFMA instructions one launch of this shape issues with `algo`, tile padding included (0 if unsupported or
- * cin % 8 != 0).  Measurement aid: bench.py divides it by the launch time for `roofline.achieved`. */
+ * cin % 8 != 0; STITO_CONV_WINOGRAD_F4_SPLIT: the three f16 products per element, i.e. f16-pipe FLOPs).  Measurement aid: bench.py divides it by the launch time for `roofline.achieved`. */
 double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int cout, int pool, int algo);
 /* 1 if stito_conv3x3_bn_relu can run this shape with `algo`, else 0. */
 int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
-/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE: the transformed input,
- * stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
+/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT: the transformed
+ * input, stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
 size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                              const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,

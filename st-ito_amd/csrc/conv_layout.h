@@ -84,6 +84,13 @@ int pack_wino43(const float *w_oihw, int cout, int cin, float *packed, hipStream
 size_t wino43_pre_workspace_bytes(const ConvShape &c, bool pool);  // hoisted input transform: bytes of V slabs (0: unsupported)
 int launch_wino43_pre(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                       bool pool, float *vbuf, size_t vbuf_bytes, hipStream_t st);
+// split-precision streaming kernel (f16 hi + lo operands, f32 accumulate)
+bool wino43_split_supported(const ConvShape &c, bool pool);
+size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool);
+size_t wino43_split_packed_floats(int cout, int cin);
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
+int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                        bool pool, void *ws, size_t ws_bytes, hipStream_t st);
 bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv
 int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st);
 int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,

@@ -36,6 +36,8 @@
 // stores into the channel-blocked activation layout.
 #include "conv_layout.h"
 
+#include <cstdlib>
+
 namespace stito {
 
 #ifndef W43_ABL
@@ -47,6 +49,13 @@ static constexpr int W43_U = 36 * 64 * W43_K;            // floats: [pos][cout][
 static constexpr int W43_V = 36 * 32 * W43_K;            // floats: [pos][tile][4]
 static constexpr int W43_BUF = W43_U + W43_V;
 static constexpr int W43_XT = 68;                        // exchange: floats per tile row ([pos][tile][64 cout], +4 pad)
+
+// split-precision streaming kernel (k_conv_wino43s): a slab = 8 position slots x 16 input channels of f16 halves hi + lo
+static constexpr int S43_VPART = 8 * 2048;               // bytes: per slot [hi | lo][channel octet 0, 1][32 tiles][8 f16]
+static constexpr int S43_UPART = 8 * 4096;               // bytes: per slot [hi | lo][channel octet 0, 1][64 couts][8 f16]
+static constexpr int S43_SLAB = S43_VPART + S43_UPART;   // 48 KB, three of them in LDS
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 struct Wino43Geom {
     int S, H, W, Cin, Cout;
@@ -126,6 +135,125 @@ __device__ __forceinline__ f32x2 pk_mul_lo(f32x2 x, f32x2 c) {
     return d;
 }
 
+// Split-precision kernel: power-of-two scale of a stream's transformed input, from the bit pattern of the stream's largest
+// activation (>= 0, after ReLU).  |B^T d B| <= 100 max|d| (the rows of B^T sum to at most 10 in magnitude), and with
+// amax < 2^e the scale 2^(8 - e) keeps every scaled element below 100 / 128 * 2^15: no f16 overflow, whatever the data.
+__host__ __device__ __forceinline__ float w43s_vscale(unsigned amax_bits) {
+    int e = (int)((amax_bits >> 23) & 0xff) - 126;  // amax = f * 2^e, f in [0.5, 1)
+    if (amax_bits == 0u) e = 8;                       // all-zero stream: scale 1
+    e = e < -40 ? -40 : (e > 60 ? 60 : e);            // (a denormal maximum or an inf / nan bit pattern: stay finite)
+    return __builtin_ldexpf(1.0f, 8 - e);
+}
+
+// ---- epilogue (shared by k_conv_wino43 and k_conv_wino43s) ---------------------------------------------------------
+// Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Three passes over the position rows
+// {1,2}, {3,4}, {0,5} (the pairs whose contributions share sums and differences); reader thread = (tile, channel
+// quad) keeps the 4x4 outputs of its 4 channels (64 VGPRs).  Packed arithmetic on register halves throughout.
+// Wave (pg, nh) owns the accumulators of positions 9 pg .. 9 pg + 8 x 32 tiles x channels nh * 32 .. + 31.
+// SPLIT: the accumulators carry the power-of-two operand scales of the split-precision kernel: 1 / (u_scale * v_scale(stream))
+// is folded into the BN scale (exact: powers of two).
+#define W43_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+template <int TTW, bool POOL, bool SPLIT>
+__device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh,
+                                             const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
+                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                             float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+#define A4(a, b) __builtin_shufflevector(pk_add(P2(a, 0), P2(b, 0)), pk_add(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
+#define S4(a, b) __builtin_shufflevector(pk_sub(P2(a, 0), P2(b, 0)), pk_sub(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
+#define F4(c2, a, b) __builtin_shufflevector(pk_fma(c2, P2(a, 0), P2(b, 0)), pk_fma(c2, P2(a, 1), P2(b, 1)), 0, 1, 2, 3) /* c a + b */
+    float *xch = smem;                      // [12 positions of the pass][32 tiles][W43_XT]
+    constexpr int XP = 32 * W43_XT;
+    const int e_quad = tid & 15, e_tile = tid >> 4;
+    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
+    f32x4 Yo[4][4];
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        W43_BARRIER()  // the main loop's (or the previous pass's) LDS reads are done
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int p = 9 * pg + q;  // wave-uniform
+            // exchange slot of position p in this pass: rows {1,2} -> p - 6, rows {3,4} -> p - 18, rows {0,5} -> p or p - 24
+            const int slot = pass == 0 ? p - 6 : pass == 1 ? p - 18 : (p < 6 ? p : p - 24);
+            const bool mine = pass == 0 ? (p >= 6 && p < 18) : pass == 1 ? (p >= 18 && p < 30) : (p < 6 || p >= 30);
+            if (mine) {
+                float *xp = xch + slot * XP + nh * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int trow = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    xp[trow * W43_XT] = acc[q][r];
+                }
+            }
+        }
+        W43_BARRIER()
+        f32x4 Z[2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            f32x4 m[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[j] = *(const f32x4 *)(xch + (ii * 6 + j) * XP + e_tile * W43_XT + e_quad * 4);
+            // column half: Z[c] = sum_j M[i][j] A[j][c]
+            const f32x4 s12 = A4(m[1], m[2]), d12 = S4(m[1], m[2]), s34 = A4(m[3], m[4]), d34 = S4(m[3], m[4]);
+            Z[ii][0] = A4(A4(m[0], s12), s34);
+            Z[ii][1] = F4(k2, d34, d12);
+            Z[ii][2] = F4(k4, s34, s12);
+            Z[ii][3] = A4(F4(k8, d34, d12), m[5]);
+        }
+        // row half: Y[r][c] += A^T[r][i] Z_i[c]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (pass == 0) {         // rows 1, 2: A^T columns (1,1,1,1) and (1,-1,1,-1); first pass: initialises Y
+                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
+                Yo[0][c] = sm; Yo[1][c] = df; Yo[2][c] = sm; Yo[3][c] = df;
+            } else if (pass == 1) {  // rows 3, 4: (1,2,4,8) and (1,-2,4,-8)
+                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
+                Yo[0][c] = A4(Yo[0][c], sm); Yo[1][c] = F4(k2, df, Yo[1][c]); Yo[2][c] = F4(k4, sm, Yo[2][c]); Yo[3][c] = F4(k8, df, Yo[3][c]);
+            } else {                 // rows 0, 5: (1,0,0,0) and (0,0,0,1)
+                Yo[0][c] = A4(Yo[0][c], Z[0][c]); Yo[3][c] = A4(Yo[3][c], Z[1][c]);
+            }
+        }
+    }
+#undef A4
+#undef S4
+#undef F4
+    // BN + ReLU (+ 2x2 average pool), 16-byte stores (4 channels) into NC8HW8
+    {
+        const int co = n0 + e_quad * 4;
+        f32x4 sc = *(const f32x4 *)(scale + co);
+        const f32x4 sh = *(const f32x4 *)(shift + co);
+        const int vtr = vtr0 + e_tile / TTW;
+        const int tc = tc0 + e_tile % TTW;
+        if (vtr < g.VTR && tc < g.TC) {
+            int tr;
+            const int s = fdiv(vtr, g.fTR, tr);
+            if constexpr (SPLIT) sc = sc * (u_inv / w43s_vscale(amax[s]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Yo[r][c] = __builtin_elementwise_max(Yo[r][c] * sc + sh, (f32x4)(0.0f));
+            if (POOL) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int oh = 2 * tr + pr, ow = 2 * tc + pc;
+                        if (oh < g.Ho && ow < g.Wo)
+                            *(f32x4 *)(out + act_off(s, co, oh, ow, g.Cout, g.Ho, g.Wo)) =
+                                (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int hh = 4 * tr + r, ww = 4 * tc + c;
+                        if (hh < g.H && ww < g.W) *(f32x4 *)(out + act_off(s, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r][c];
+                    }
+            }
+        }
+    }
+}
+
 // MODE 0: the whole convolution (patch -> V in the workgroup).  The workgroups of one pixel block that differ only in their
 // 64 output channels all repeat the same input transform (8 .. 32 times for Cout >= 512), and it is paid in the same
 // ALUs the f32 MFMAs run on; for those layers the transform is hoisted: MODE 2 runs the production pipeline alone (one
@@ -142,7 +270,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
     constexpr int PFL = PL::PFL;      // floats per patch buffer
     constexpr int BUF = W43_BUF;
-    constexpr bool PREV = MODE == 1, VOUT = MODE == 2;
+    constexpr bool PREV = MODE == 1, VOUT = MODE == 2 || MODE == 3, V16 = MODE == 3;
     static_assert(!(FUSE1 && MODE != 0), "the fused first conv only exists for MODE 0");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -178,6 +306,17 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     int tr0_;
     const int s0_ = fdiv(vtr0, g.fTR, tr0_);
     const int iv_lo = s0_ * g.H + 4 * tr0_ - 1;  // input virtual row (s*H + h) of patch row 0
+
+    // MODE 3: the V slabs leave as scaled f16 halves hi + lo in the slab order of k_conv_wino43s.  Thread -> tile tid % 32 for
+    // all of its (position, tile) items; the scale belongs to the tile's stream (`scale` carries the streams' maxima).
+    const int v16_tile = tid & 31;
+    float v16_s = 1.0f;
+    if constexpr (V16) {
+        int vt_ = vtr0 + v16_tile / TTW, tr_;
+        vt_ = vt_ < (int)g.VTR ? vt_ : (int)g.VTR - 1;
+        v16_s = w43s_vscale(((const unsigned *)scale)[fdiv(vt_, g.fTR, tr_)]);
+    }
+    const int n_slabs16 = (g.Cin >> 5) * 9;
 
 #define W43_STAMP(SLOT)                                                                                 \
     if (TRACE && (blockIdx.x & 255) == 100 && (blockIdx.x >> 8) < 8 && lane == 0 && (wv & 3) == 0)      \
@@ -281,6 +420,32 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             if (e_ < W43_V / 4) vo_[e_] = vs_[e_];                                                       \
         }                                                                                                \
     }
+// V16: V(k) -> f16 halves.  Chunk kc = 4 channels c = 4 kc .. 4 kc + 3 of the 16-channel group (c % 32) / 16 of super-step c / 32;
+// position p = 9 pg + q sits in slab 9 (c / 32) + e / 2, slot 2 pg + e % 2 with e = 9 ((c % 32) / 16) + q (the order in which
+// k_conv_wino43s walks a wave's nine blocks twice per 32 channels); inside a slot [hi | lo][(c % 16) / 8][tile][c % 8].
+#define W43_STORE_V16(K_, CUR)                                                                           \
+    {                                                                                                    \
+        const int kc_ = c_base + (K_);                                                                   \
+        const int kg_ = (kc_ >> 2) & 1;                                                                  \
+        char *vo_ = (char *)out + ((int64_t)m_blk * n_slabs16 + 9 * (kc_ >> 3)) * S43_VPART +            \
+                    (((kc_ >> 1) & 1) * 32 + v16_tile) * 16 + (kc_ & 1) * 8;                             \
+        const float *vs_ = smem + (CUR) + W43_U;                                                         \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+            const int p_ = (tid >> 5) + 16 * j;                                                          \
+            if (p_ < 36) {                                                                               \
+                const int pg_ = p_ / 9, e_ = kg_ * 9 + p_ - 9 * pg_;                                     \
+                const f32x2 x01 = *(const f32x2 *)(vs_ + p_ * 128 + v16_tile * 2) * v16_s;               \
+                const f32x2 x23 = *(const f32x2 *)(vs_ + p_ * 128 + 64 + ((v16_tile + 16) & 31) * 2) * v16_s; \
+                h4 hi_, lo_;                                                                             \
+                hi_[0] = (_Float16)x01[0]; hi_[1] = (_Float16)x01[1]; hi_[2] = (_Float16)x23[0]; hi_[3] = (_Float16)x23[1]; \
+                lo_[0] = (_Float16)(x01[0] - (float)hi_[0]); lo_[1] = (_Float16)(x01[1] - (float)hi_[1]); \
+                lo_[2] = (_Float16)(x23[0] - (float)hi_[2]); lo_[3] = (_Float16)(x23[1] - (float)hi_[3]); \
+                char *d_ = vo_ + (int64_t)(e_ >> 1) * S43_VPART + (pg_ * 2 + (e_ & 1)) * 2048;           \
+                *(h4 *)d_ = hi_;                                                                         \
+                *(h4 *)(d_ + 1024) = lo_;                                                                \
+            }                                                                                            \
+        }                                                                                                \
+    }
 // patch(CH) -> patch buffer PB (0, 1): two masked LDS-DMA instructions per wave (pixels wv*64 + 512 j + lane)
 #define W43_COPY_P(CH, PB)                                                                              \
     {                                                                                                   \
@@ -343,7 +508,6 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         asm volatile("" : "+v"(acc[3 * (G) + (T_)]));                                                   \
     }
 #define W43_FENCE() __builtin_amdgcn_sched_barrier(0);
-#define W43_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define W43_GAP(S, G, T_, E_, WORK) W43_MFMA(S, G, T_, E_) WORK W43_FENCE()
 
     f32x16 acc[9];
@@ -455,7 +619,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
         const float *sb = smem + cur;                                                                    \
         const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
-        if (VOUT) W43_STORE_V(k, cur)                                                                    \
+        if (V16) W43_STORE_V16(k, cur) else if (VOUT) W43_STORE_V(k, cur)                                \
         if (!(FIRST)) {                                                                                  \
             W43_GAP(P2, 2, 0, 0, if (MORE_ && !(W43_ABL & 4)) { if (PREV) { W43_COPY_V1(k + 1, nxt, 0) } else if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) } else W43_COPY_P(k + 2, k & 1) }) \
             W43_GAP(P2, 2, 1, 0, W43_OPS(W43_LOAD_OPS(G0, sb, 0)) W43_UCP(W43_COPY_U1(k + 1, nxt, 0)))   \
@@ -522,101 +686,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     }
     W43_STAMP(2)
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------
-    // Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Three passes over the position rows
-    // {1,2}, {3,4}, {0,5} (the pairs whose contributions share sums and differences); reader thread = (tile, channel
-    // quad) keeps the 4x4 outputs of its 4 channels (64 VGPRs).  Packed arithmetic on register halves throughout.
-#define A4(a, b) __builtin_shufflevector(pk_add(P2(a, 0), P2(b, 0)), pk_add(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
-#define S4(a, b) __builtin_shufflevector(pk_sub(P2(a, 0), P2(b, 0)), pk_sub(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
-#define F4(c2, a, b) __builtin_shufflevector(pk_fma(c2, P2(a, 0), P2(b, 0)), pk_fma(c2, P2(a, 1), P2(b, 1)), 0, 1, 2, 3) /* c a + b */
-    float *xch = smem;                      // [12 positions of the pass][32 tiles][W43_XT]
-    constexpr int XP = 32 * W43_XT;
-    const int e_quad = tid & 15, e_tile = tid >> 4;
-    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
-    f32x4 Yo[4][4];
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
-        W43_BARRIER()  // the main loop's (or the previous pass's) LDS reads are done
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int p = 9 * pg + q;  // wave-uniform
-            // exchange slot of position p in this pass: rows {1,2} -> p - 6, rows {3,4} -> p - 18, rows {0,5} -> p or p - 24
-            const int slot = pass == 0 ? p - 6 : pass == 1 ? p - 18 : (p < 6 ? p : p - 24);
-            const bool mine = pass == 0 ? (p >= 6 && p < 18) : pass == 1 ? (p >= 18 && p < 30) : (p < 6 || p >= 30);
-            if (mine) {
-                float *xp = xch + slot * XP + nh * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int trow = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    xp[trow * W43_XT] = acc[q][r];
-                }
-            }
-        }
-        W43_BARRIER()
-        f32x4 Z[2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            f32x4 m[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[j] = *(const f32x4 *)(xch + (ii * 6 + j) * XP + e_tile * W43_XT + e_quad * 4);
-            // column half: Z[c] = sum_j M[i][j] A[j][c]
-            const f32x4 s12 = A4(m[1], m[2]), d12 = S4(m[1], m[2]), s34 = A4(m[3], m[4]), d34 = S4(m[3], m[4]);
-            Z[ii][0] = A4(A4(m[0], s12), s34);
-            Z[ii][1] = F4(k2, d34, d12);
-            Z[ii][2] = F4(k4, s34, s12);
-            Z[ii][3] = A4(F4(k8, d34, d12), m[5]);
-        }
-        // row half: Y[r][c] += A^T[r][i] Z_i[c]
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (pass == 0) {         // rows 1, 2: A^T columns (1,1,1,1) and (1,-1,1,-1); first pass: initialises Y
-                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
-                Yo[0][c] = sm; Yo[1][c] = df; Yo[2][c] = sm; Yo[3][c] = df;
-            } else if (pass == 1) {  // rows 3, 4: (1,2,4,8) and (1,-2,4,-8)
-                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
-                Yo[0][c] = A4(Yo[0][c], sm); Yo[1][c] = F4(k2, df, Yo[1][c]); Yo[2][c] = F4(k4, sm, Yo[2][c]); Yo[3][c] = F4(k8, df, Yo[3][c]);
-            } else {                 // rows 0, 5: (1,0,0,0) and (0,0,0,1)
-                Yo[0][c] = A4(Yo[0][c], Z[0][c]); Yo[3][c] = A4(Yo[3][c], Z[1][c]);
-            }
-        }
-    }
-#undef A4
-#undef S4
-#undef F4
-    // BN + ReLU (+ 2x2 average pool), 16-byte stores (4 channels) into NC8HW8
-    {
-        const int co = n0 + e_quad * 4;
-        const f32x4 sc = *(const f32x4 *)(scale + co), sh = *(const f32x4 *)(shift + co);
-        const int vtr = vtr0 + e_tile / TTW;
-        const int tc = tc0 + e_tile % TTW;
-        if (vtr < g.VTR && tc < g.TC) {
-            int tr;
-            const int s = fdiv(vtr, g.fTR, tr);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) Yo[r][c] = __builtin_elementwise_max(Yo[r][c] * sc + sh, (f32x4)(0.0f));
-            if (POOL) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) {
-                        const int oh = 2 * tr + pr, ow = 2 * tc + pc;
-                        if (oh < g.Ho && ow < g.Wo)
-                            *(f32x4 *)(out + act_off(s, co, oh, ow, g.Cout, g.Ho, g.Wo)) =
-                                (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
-                    }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int hh = 4 * tr + r, ww = 4 * tc + c;
-                        if (hh < g.H && ww < g.W) *(f32x4 *)(out + act_off(s, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r][c];
-                    }
-            }
-        }
-    }
+    w43_epilogue<TTW, POOL, false>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, 1.0f, nullptr);
     W43_STAMP(3)
 }
 
@@ -639,6 +709,177 @@ __global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, fl
             const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
             o[((((int64_t)chunk * 36 + a * 6 + b) * 2 + (c4 >> 1)) * Cout + co) * 2 + (c4 & 1)] = (float)u;
         }
+}
+
+// ---- split-precision streaming convolution ----------------------------------------------------------------------------
+// The same convolution as MODE 1 (transformed input and weights both streamed), on the f16 matrix pipe: every f32 operand x
+// is carried as two f16 halves  hi = rn16(s x), lo = rn16(s x - hi)  (s a power of two: per layer for the weights, per
+// stream for the transformed input, chosen from the data so that nothing overflows: w43s_vscale), 22 significand bits
+// against float32's 24, and every product as  hi hi' + hi lo' + lo hi'  on v_mfma_f32_32x32x16_f16 with float32
+// accumulation.  Measured against float64 on K = 2 048 .. 18 432 products of random and of heavy-tailed data
+// (tools/ubench/split_mfma.hip) the result is as close as the exact-f32 MFMA's (rms 1.6e-7 / 4.4e-7 of the output maximum
+// against 2.4e-7 / 6.9e-7: the f32 pipe rounds after every rank-2 update, this one after every rank-16), the dropped
+// lo lo' term changes nothing in the last digit shown, and three f16 MFMAs do in 96 cycles what eight f32 MFMAs do in 512.
+// With the matrix pipe out of the way the loop is bound by filling LDS (24 TB/s of L2 -> LDS over the chip = 41 B/clk/CU,
+// same ubench), so it is built around the copies: a slab = 8 position slots x 16 input channels x (32 tiles + 64 couts) x
+// (hi, lo) = 48 KB, three slabs in LDS; period k multiplies slab k (two blocks = 6 MFMAs per wave) while slab k + 1 is
+// landing and slab k + 2 is issued.  The waves form two sets that issue on alternate periods: a wave waits vmcnt(0)
+// only just before the barrier that precedes its next issue (the rule of this file: no partial vmcnt waits around LDS-DMA),
+// a slab has two periods to land, and there is always one in flight.
+// Wave (pg, nh) owns positions 9 pg .. 9 pg + 8 x channel half nh as in k_conv_wino43 (same epilogue); a 32-channel
+// super-step walks its nine blocks twice (channels 0..15, then 16..31), two per period: 9 periods, slab 9 ss + e / 2 holds
+// walk index e = 9 kg + q in slot 2 pg + e % 2.  The loop body is 18 periods (64 channels) so that ring buffer, issuing set
+// and accumulator index are all compile-time.
+template <int TTW, bool POOL>
+__global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__restrict__ vsl, const char *__restrict__ usl,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               float *__restrict__ out, Wino43Geom g,
+                                                               const unsigned *__restrict__ amax, const float *__restrict__ u_inv_p) {
+    constexpr int TTH = 32 / TTW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup order: as MODE 1 (XCD b % 8 runs ct_group channel tiles x 32 / ct_group pixel blocks at a time)
+    const int n_tiles = g.Cout / 64;
+    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    const int a = g.ct_group, n_ctg = n_tiles / a;
+    const int ct = (gi % n_ctg) * a + (r % a);
+    const int m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+    const int n0 = ct * 64;
+    if (m_blk >= g.n_mblocks) return;
+    int cb;
+    const int rb = fdiv(m_blk, g.fNCB, cb);
+    const int vtr0 = rb * TTH, tc0 = cb * TTW;
+    const int n_slabs = (g.Cin >> 5) * 9;
+    const char *vbase = vsl + (int64_t)m_blk * n_slabs * S43_VPART;
+    const char *ubase = usl + (int64_t)ct * n_slabs * S43_UPART;
+    const int set = wv >> 2, w4 = wv & 3, pg = wv >> 1, nh = wv & 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const char *a_rd = (const char *)smem + pg * 2 * 2048 + lane * 16;
+    const char *b_rd = (const char *)smem + S43_VPART + pg * 2 * 4096 + ((lane >> 5) * 64 + nh * 32 + (lane & 31)) * 16;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+
+// slab SL -> ring buffer BUF: 48 pieces of 1 KB (0..15 transformed input, 16..47 weights), 12 per wave of the issuing set
+#define S43_ISSUE(SL, BUF)                                                                               \
+    _Pragma("unroll") for (int c_ = 0; c_ < 12; ++c_) {                                                   \
+        const int piece_ = w4 * 12 + c_;                                                                  \
+        const char *src_ = piece_ < 16 ? vbase + (int64_t)(SL) * S43_VPART + piece_ * 1024                \
+                                       : ubase + (int64_t)(SL) * S43_UPART + (piece_ - 16) * 1024;        \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43_SLAB + piece_ * 1024)); \
+    }
+#define S43_MFMA(Q, A_, B_) acc[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc[Q], 0, 0, 0);
+#define S43_PERIOD(K18, SL)                                                                              \
+    {                                                                                                    \
+        constexpr int BUF_ = (K18) % 3, NB_ = ((K18) + 2) % 3;                                            \
+        constexpr int Q0_ = (2 * ((K18) % 9)) % 9, Q1_ = (2 * ((K18) % 9) + 1) % 9;                       \
+        const bool mine_ = set == ((K18) & 1);                                                            \
+        if (mine_ && (SL) + 2 < n_slabs) { S43_ISSUE((SL) + 2, NB_) }                                     \
+        const char *pa_ = a_rd + BUF_ * S43_SLAB, *pb_ = b_rd + BUF_ * S43_SLAB;                          \
+        const h8 ah0 = *(const h8 *)(pa_), al0 = *(const h8 *)(pa_ + 1024);                               \
+        const h8 bh0 = *(const h8 *)(pb_), bl0 = *(const h8 *)(pb_ + 2048);                               \
+        const h8 ah1 = *(const h8 *)(pa_ + 2048), al1 = *(const h8 *)(pa_ + 3072);                        \
+        const h8 bh1 = *(const h8 *)(pb_ + 4096), bl1 = *(const h8 *)(pb_ + 6144);                        \
+        S43_MFMA(Q0_, al0, bh0) S43_MFMA(Q1_, al1, bh1)                                                   \
+        S43_MFMA(Q0_, ah0, bl0) S43_MFMA(Q1_, ah1, bl1)                                                   \
+        S43_MFMA(Q0_, ah0, bh0) S43_MFMA(Q1_, ah1, bh1)                                                   \
+        if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        W43_BARRIER()                                                                                     \
+    }
+
+    if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W43_BARRIER()
+    for (int sl = 0; sl < n_slabs; sl += 18) {  // Cin % 64 == 0
+        S43_PERIOD(0, sl) S43_PERIOD(1, sl + 1) S43_PERIOD(2, sl + 2) S43_PERIOD(3, sl + 3) S43_PERIOD(4, sl + 4) S43_PERIOD(5, sl + 5)
+        S43_PERIOD(6, sl + 6) S43_PERIOD(7, sl + 7) S43_PERIOD(8, sl + 8) S43_PERIOD(9, sl + 9) S43_PERIOD(10, sl + 10) S43_PERIOD(11, sl + 11)
+        S43_PERIOD(12, sl + 12) S43_PERIOD(13, sl + 13) S43_PERIOD(14, sl + 14) S43_PERIOD(15, sl + 15) S43_PERIOD(16, sl + 16) S43_PERIOD(17, sl + 17)
+    }
+    w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
+}
+
+// Largest activation of every stream (>= 0 after ReLU; the sign bit is dropped anyway) as a bit pattern: amax[s] is zeroed
+// by the launcher, one atomicMax per wave.  grid (splits, S).
+__global__ __launch_bounds__(256) void k_stream_absmax(const float *__restrict__ x, int64_t per_stream, unsigned *__restrict__ amax) {
+    const f32x4 *xs = (const f32x4 *)(x + (int64_t)blockIdx.y * per_stream);
+    const int64_t n4 = per_stream >> 2;  // per_stream % 8 == 0 (channel-blocked layout)
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = xs[i];
+        const unsigned a0 = __float_as_uint(v[0]) & 0x7fffffffu, a1 = __float_as_uint(v[1]) & 0x7fffffffu;
+        const unsigned a2 = __float_as_uint(v[2]) & 0x7fffffffu, a3 = __float_as_uint(v[3]) & 0x7fffffffu;
+        m = max(max(m, max(a0, a1)), max(a2, a3));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax + blockIdx.y, m);
+}
+
+// Weights of the split-precision kernel: U = G g G^T as in k_pack_wino43 (float64, rounded once to float32), then scaled by
+// the layer's power of two and split.  PASS 0: max |U| (bit pattern) into hdr[0]; PASS 1: the slabs,
+// [cout / 64][slab][slot][hi | lo][channel octet][64 couts][8 f16].  hdr = {max bits, 1 / scale, scale} behind the slabs.
+template <int PASS>
+__global__ void k_pack_wino43s(const float *__restrict__ w, int Cout, int Cin, char *__restrict__ o, unsigned *__restrict__ hdr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double gk[3][3], t[6][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) gk[a][b] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + b];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * gk[0][b] + G[a][1] * gk[1][b] + G[a][2] * gk[2][b];
+    const int n_slabs = (Cin >> 5) * 9;
+    const int ss = ci >> 5, kg = (ci >> 4) & 1, h = (ci >> 3) & 1, i8 = ci & 7;
+    const float su = PASS == 1 ? __uint_as_float(hdr[2]) : 1.0f;
+    unsigned mx = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            const float u = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+            if (PASS == 0) {
+                mx = max(mx, __float_as_uint(u) & 0x7fffffffu);
+            } else {
+                const int p = a * 6 + b, pg = p / 9, e = kg * 9 + p - 9 * pg;
+                const float us = u * su;
+                const _Float16 hi = (_Float16)us, lo = (_Float16)(us - (float)hi);
+                char *d = o + ((int64_t)(co >> 6) * n_slabs + 9 * ss + (e >> 1)) * S43_UPART + (pg * 2 + (e & 1)) * 4096 +
+                          (h * 64 + (co & 63)) * 16 + i8 * 2;
+                *(_Float16 *)d = hi;
+                *(_Float16 *)(d + 2048) = lo;
+            }
+        }
+    if (PASS == 0 && mx) atomicMax(hdr, mx);
+}
+
+__global__ void k_pack_wino43s_scale(unsigned *hdr) {
+    // max |U| < 2^e  ->  scale 2^(14 - e): every scaled weight below 2^14
+    const unsigned mb = hdr[0];
+    int e = (int)((mb >> 23) & 0xff) - 126;
+    if (mb == 0u) e = 14;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    hdr[1] = __float_as_uint(__builtin_ldexpf(1.0f, e - 14));
+    hdr[2] = __float_as_uint(__builtin_ldexpf(1.0f, 14 - e));
+}
+
+size_t wino43_split_packed_floats(int cout, int cin) { return (size_t)36 * cout * cin + 64; }
+
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st) {
+    STITO_REQUIRE(cin % 64 == 0 && cout % 64 == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
+    const int64_t n = (int64_t)cout * cin;
+    unsigned *hdr = (unsigned *)(packed + (size_t)36 * cout * cin);
+    STITO_HIP_CHECK(hipMemsetAsync(hdr, 0, 64 * sizeof(float), st));
+    hipLaunchKernelGGL(k_pack_wino43s<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
+    STITO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pack_wino43s_scale, dim3(1), dim3(1), 0, st, hdr);
+    STITO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pack_wino43s<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
 }
 
 static int w43_ttw(const ConvShape &c, bool pool) {
@@ -851,6 +1092,83 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
         case 4: return pool ? launch_w43_pre<4, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<4, false>(in, upk, scale, shift, out, c, vbuf, st);
         case 2: return pool ? launch_w43_pre<2, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<2, false>(in, upk, scale, shift, out, c, vbuf, st);
         default: return pool ? launch_w43_pre<1, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<1, false>(in, upk, scale, shift, out, c, vbuf, st);
+    }
+}
+
+// Split-precision variant of the hoisted path: stream maxima -> MODE 3 (V slabs as scaled f16 halves) -> k_conv_wino43s.
+// Workspace: the V slabs (the same bytes as MODE 2's) followed by one unsigned per stream.
+bool wino43_split_supported(const ConvShape &c, bool pool) {
+    return c.Cin % 64 == 0 && c.Cout % 256 == 0 && wino43_supported(c, pool) && ((int64_t)c.Cin * c.H * c.W) % 8 == 0;
+}
+
+size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool) {
+    if (!wino43_split_supported(c, pool)) return 0;
+    return align_up(wino43_pre_workspace_bytes(c, pool), 256) + align_up((size_t)c.S * sizeof(unsigned), 256);
+}
+
+template <int TTW, bool POOL>
+static int launch_w43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                            char *ws, hipStream_t st) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
+    const int64_t m_blocks = blocks / (c.Cout / 64);
+    unsigned *amax = (unsigned *)(ws + align_up((size_t)m_blocks * (c.Cin / W43_K) * W43_V * sizeof(float), 256));
+    {   // stream maxima
+        STITO_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)c.S * sizeof(unsigned), st));
+        const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
+        int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));  // >= 16 float4 per thread
+        const int cap = (4096 + c.S - 1) / c.S;                            // ~16 workgroups per CU in total
+        splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
+        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax);
+        STITO_LAUNCH_CHECK();
+    }
+    {   // V slabs (MODE 3): grid as MODE 2
+        Wino43Geom gv = g;
+        const int n_chunks = c.Cin / W43_K;
+        int ncg = 1;
+        while (m_blocks * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
+        gv.n_cgroups = ncg;
+        auto kern = k_conv_wino43<TTW, POOL, false, false, 3>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds, st, in, (const float *)nullptr,
+                           (const float *)amax, (const float *)nullptr, (float *)ws, gv);
+        STITO_LAUNCH_CHECK();
+    }
+    auto kern = k_conv_wino43s<TTW, POOL>;
+    const size_t lds1 = (size_t)3 * S43_SLAB;
+    static_assert((size_t)12 * 32 * W43_XT * sizeof(float) <= (size_t)3 * S43_SLAB, "epilogue exchange fits the slab ring");
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    g.n_mblocks = (int)m_blocks;
+    const int n_tiles = c.Cout / 64;
+    int a = n_tiles >= 16 ? 8 : 4;
+    if (const char *e = getenv("STITO_W43S_CTG")) a = atoi(e);  // tuning aid (tools/conv_bench.py): channel tiles per XCD round
+    STITO_REQUIRE(a >= 1 && a <= 32 && (a & (a - 1)) == 0 && n_tiles % a == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cout %d", c.Cout);
+    g.ct_group = a;
+    const int bm = 32 / a;
+    const int64_t m_groups = ((m_blocks + 7) / 8 + bm - 1) / bm;
+    blocks = 8 * m_groups * (n_tiles / a) * 32;
+    STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv (split-precision winograd): grid");
+    const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                       (const unsigned *)amax, u_inv);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                        bool pool, void *ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = wino43_split_workspace_bytes(c, pool);
+    STITO_REQUIRE(need > 0 && ws != nullptr && ws_bytes >= need, STITO_E_WORKSPACE,
+                  "conv (split-precision winograd F(4x4,3x3)): workspace have %zu need %zu", ws_bytes, need);
+    char *w = (char *)ws;
+    switch (w43_ttw(c, pool)) {
+        case 8: return pool ? launch_w43_split<8, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<8, false>(in, upk, scale, shift, out, c, w, st);
+        case 4: return pool ? launch_w43_split<4, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<4, false>(in, upk, scale, shift, out, c, w, st);
+        case 2: return pool ? launch_w43_split<2, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<2, false>(in, upk, scale, shift, out, c, w, st);
+        default: return pool ? launch_w43_split<1, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<1, false>(in, upk, scale, shift, out, c, w, st);
     }
 }
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("STITO_LIB_PATH") or os.path.join(_HERE, "_lib", "libs
 FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB = range(7)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
 FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
-CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE = 0, 1, 2, 3
+CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE, CONV_WINOGRAD_F4_SPLIT = 0, 1, 2, 3, 4
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "stito_debug_wino_trace": (c_int, [c_void_p]),
     "stito_conv_timing_enable": (c_int, [c_int]),
     "stito_conv_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
+    "stito_conv_timing_read_each": (c_int, [POINTER(ctypes.c_double), c_int, POINTER(c_int)]),
     "stito_cnn14_pack_conv1_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "stito_conv_block1_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv_block1_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

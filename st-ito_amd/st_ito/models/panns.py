@@ -123,6 +123,12 @@ class Cnn14(nn.Module):
         # F(4x4,3x3) layers with at least this many output channels run with the input transform hoisted into its own
         # pass (CONV_WINOGRAD_F4_PRE): from 512 up the 8+ workgroups sharing a pixel block stop repeating it (0 = never)
         self.conv_pre_min_cout = int(os.environ.get("STITO_CONV_PRE_MIN_COUT", "512"))
+        # ... and, unless STITO_CONV_SPLIT=0, on the f16 matrix pipe with split operands (CONV_WINOGRAD_F4_SPLIT: every f32
+        # operand as f16 hi + lo, three products, f32 accumulation -- as accurate as the f32 pipe, measured) where cin % 64 == 0
+        self.conv_split = os.environ.get("STITO_CONV_SPLIT", "1") != "0"
+        # from 256 output channels up (measured at 512 streams: 128 -> 256 channels 4.0 -> 3.6 ms, 256 -> 256 6.4 -> 5.7 ms; below,
+        # the transformed input's round trip through HBM costs more than the matrix pipe saves)
+        self.conv_split_min_cout = int(os.environ.get("STITO_CONV_SPLIT_MIN_COUT", "256"))
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -167,11 +173,14 @@ class Cnn14(nn.Module):
                 packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, _hip.CONV_DIRECT), dtype=torch.float32, device=dev)
                 _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.CONV_DIRECT, _hip.ptr(packed), st))
                 if self.conv_algo != _hip.CONV_DIRECT and cin % 8 == 0 and cout % 64 == 0:
-                    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, self.conv_algo), dtype=torch.float32, device=dev)
-                    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, self.conv_algo, _hip.ptr(upk), st))
-                    W.conv_wino_dev[2 * b + j] = upk.data_ptr()
                     pre = self.conv_algo == _hip.CONV_WINOGRAD_F4 and 0 < self.conv_pre_min_cout <= cout
-                    W.conv_wino_algo[2 * b + j] = _hip.CONV_WINOGRAD_F4_PRE if pre else self.conv_algo
+                    split = (self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and 0 < self.conv_split_min_cout <= cout and
+                             cin % 64 == 0 and cout % 256 == 0 and (cout < 1024 or cout % 512 == 0))
+                    algo = _hip.CONV_WINOGRAD_F4_SPLIT if split else (_hip.CONV_WINOGRAD_F4_PRE if pre else self.conv_algo)
+                    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)
+                    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(upk), st))
+                    W.conv_wino_dev[2 * b + j] = upk.data_ptr()
+                    W.conv_wino_algo[2 * b + j] = algo
                     keep.append(upk)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)

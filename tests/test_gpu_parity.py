@@ -325,7 +325,7 @@ CONV_CASES = [  # (n, H, W, cin, cout, pool)
 ]
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
 def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     from st_ito import _hip
@@ -357,7 +357,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
     sd, hd = scale.to(dev), shift.to(dev)
     wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, algo)
-    assert (wsb > 0) == (algo == 3)
+    assert (wsb > 0) == (algo in (3, 4))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
                                           n, H, W, cin, cout, pool, algo, _hip.ptr(ws), wsb, st))
@@ -372,10 +372,65 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
                                        n, H, W, cin, cout, pool, 3, st) == _hip.E_WORKSPACE  # no workspace, no launch
     err = (got - ref).abs().max().item()
     print(f"conv algo {algo} {n}x{H}x{W} {cin}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
+    if algo == 4:
+        assert L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
+                                       n, H, W, cin, cout, pool, 4, st) == _hip.E_WORKSPACE  # no workspace, no launch
     # F(4x4,3x3): random SIGNED inputs are the worst case for the cancellation in its output transform (3.3e-5 of the
     # maximum at cin = 2048); on real trunk activations it is as accurate as the direct kernel (tools/trunk_accuracy.py)
     tol = 5e-5 if algo >= 2 else 2e-5
     assert err < tol * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,pool", [(6, 14, 4, 512, 512, 0), (5, 29, 8, 256, 512, 1), (9, 58, 16, 64, 256, 0)])
+def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool):
+    """STITO_CONV_WINOGRAD_F4_SPLIT carries every operand as f16 hi + lo of a power-of-two multiple of itself; the
+    multiple is chosen per stream from the stream's own largest activation.  Streams 1e4 and 1e-4 times the others, an
+    all-zero stream and a stream with one huge outlier sit in ONE launch (several streams per workgroup tile on these
+    maps): every stream must come out as accurate, relative to ITS OWN maximum, as the float32 kernels (no f16
+    overflow, no loss on the quiet streams), and bitwise independent of what else is in the batch."""
+    from st_ito import _hip
+    L = _hip.lib()
+    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, 4)
+    g = torch.Generator().manual_seed(H * 7 + cin)
+    x = torch.relu(torch.randn((n, cin, H, W), generator=g))
+    x[1] *= 1e4
+    x[2] *= 1e-4
+    x[3] = 0.0
+    x[4, cin // 2, H // 2, W // 2] = 3e3
+    w = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)
+    scale = 0.5 + torch.rand(cout, generator=g)
+    shift = torch.zeros(cout)   # no shift: the outputs scale with the stream, so a per-stream relative bound is meaningful
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double()[None, :, None, None])
+    if pool:
+        ref = torch.nn.functional.avg_pool2d(ref, 2)
+    def blocked(t):
+        n_, C_, H_, W_ = t.shape
+        return t.reshape(n_, C_ // 8, 8, H_, W_).permute(0, 1, 3, 4, 2).contiguous()
+    st = _hip.stream_ptr()
+    wd, sd, hd = w.contiguous().to(dev), scale.to(dev), shift.to(dev)
+    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, 4), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, 4, _hip.ptr(packed), st))
+
+    def run(xs):
+        k = xs.shape[0]
+        xd = blocked(xs).to(dev)
+        out = torch.full((k, cout // 8) + tuple(ref.shape[2:]) + (8,), float("nan"), device=dev, dtype=torch.float32)
+        wsb = L.stito_conv3x3_workspace_bytes(k, H, W, cin, cout, pool, 4)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
+                                              k, H, W, cin, cout, pool, 4, _hip.ptr(ws), wsb, st))
+        return out.cpu()
+    got = run(x)
+    refb = blocked(ref)
+    for s_ in range(n):
+        mx = refb[s_].abs().max().item()
+        err = (got[s_].double() - refb[s_]).abs().max().item()
+        print(f"stream {s_}: max {mx:.3e} err {err:.3e}")
+        assert torch.isfinite(got[s_]).all()
+        assert err <= 5e-5 * mx if mx > 0 else err == 0.0, (s_, err, mx)
+    # batch independence: stream 2 (quiet) and stream 0 evaluated alone / in another order give the same bits
+    alone = run(x[[2, 0]])
+    assert torch.equal(alone[0], got[2]) and torch.equal(alone[1], got[0])
 
 
 @pytest.mark.parametrize("n,H,W,c1,cout,pool", [(2, 33, 128, 64, 64, 1), (3, 9, 64, 64, 64, 1), (5, 6, 32, 64, 128, 1),
@@ -450,29 +505,41 @@ def test_model_vs_golden_reference(dev, golden_dir, norm):
 
 
 def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
-    """The model's default (F(4x4,3x3) with the input transform hoisted into its own pass from 512 output channels up:
-    conv_block4-6, STITO_CONV_WINOGRAD_F4_PRE) against the same trunk with every layer transforming in-kernel
-    (conv_pre_min_cout = 0): same arithmetic in the same order, so the embeddings are identical bit for bit -- on a
-    bench-shaped input (10 s: the 469 x 128 map, all tile widths 8 / 4 / 2 / 1) and on a short one (ragged tiles)."""
+    """The float32 trunk (conv_split = False): F(4x4,3x3) with the input transform hoisted into its own pass from 512
+    output channels up (conv_block4-6, STITO_CONV_WINOGRAD_F4_PRE) against the same trunk with every layer transforming
+    in-kernel (conv_pre_min_cout = 0): same arithmetic in the same order, so the embeddings are identical bit for bit -- on
+    a bench-shaped input (10 s: the 469 x 128 map, all tile widths 8 / 4 / 2 / 1) and on a short one (ragged tiles).
+    The model's default (conv_split: the layers from 256 output channels up on the f16 matrix pipe with split operands,
+    STITO_CONV_WINOGRAD_F4_SPLIT) is not bitwise the float32 trunk; it must sit inside float32 rounding of it."""
     from st_ito import _hip
     from st_ito.models.panns import Cnn14
     om = O.fill_deterministic(O.Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "batchnorm"), 0).eval()
     outs = {}
-    for pre in (512, 0):
+    for pre in (512, 0, "split"):
         pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "batchnorm")
         pm.load_state_dict(om.state_dict())
         pm.eval().to(dev)
-        pm.conv_pre_min_cout = pre
+        if pre == "split":
+            assert pm.conv_split and pm.conv_split_min_cout == 256   # the defaults
+        else:
+            pm.conv_split = False
+            pm.conv_pre_min_cout = pre
         W, _, _ = pm._ensure()
         algos = [int(W.conv_wino_algo[i]) for i in range(12)]
-        assert algos[1:6] == [_hip.CONV_WINOGRAD_F4] * 5
-        assert algos[6:] == [_hip.CONV_WINOGRAD_F4_PRE if pre else _hip.CONV_WINOGRAD_F4] * 6
+        if pre == "split":
+            assert algos[1:4] == [_hip.CONV_WINOGRAD_F4] * 3 and algos[4:] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 8
+        else:
+            assert algos[1:6] == [_hip.CONV_WINOGRAD_F4] * 5
+            assert algos[6:] == [_hip.CONV_WINOGRAD_F4_PRE if pre else _hip.CONV_WINOGRAD_F4] * 6
         for n in (480000, 40001):
             x = torch.stack([O.synth_audio(70 + i, 2, n) for i in range(3)])
             outs[(pre, n)] = [t.clone() for t in pm(x.to(dev))]
     for n in (480000, 40001):
-        for a, b in zip(outs[(512, n)], outs[(0, n)]):
+        for a, b, c in zip(outs[(512, n)], outs[(0, n)], outs[("split", n)]):
             assert torch.equal(a, b)
+            rel = ((c - a).abs().max() / a.abs().max()).item()
+            print(f"split-precision trunk vs float32 trunk, n = {n}: {rel:.2e} of the embedding maximum")
+            assert rel < 5e-6, rel
 
 
 @pytest.mark.parametrize("tag", ["stereo", "mono"])

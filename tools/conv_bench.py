@@ -18,18 +18,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames", type=int, default=469)
-    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 9 = production mix (3 for cout >= 512, else 2)")
+    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 9 = production mix (4 for cout >= 512, else 2)")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     L = _hip.lib()
     dev = torch.device("cuda", 0)
     st = _hip.stream_ptr()
     rows = [r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 0]
-    # mode 9 = the production mix of st_ito/models/panns.py: algo 3 for cout >= 512, algo 2 below
+    # mode 9 = the production mix of st_ito/models/panns.py: algo 4 for cout >= 512 (3 where 4 does not cover the shape), algo 2 below
     modes = [int(m) for m in a.modes.split(",")]
     def algo_of(m, r):
         if m == 9:
-            return 3 if r["cout"] >= 512 else 2
+            m = 4 if r["cout"] >= 512 else 2
+        if m == 4 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 4):
+            m = 3
         if m == 3 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 3):
             return 2  # the hoisted transform needs cout % 256 == 0
         return m

@@ -1,0 +1,276 @@
+// Micro-benchmarks behind the split-precision streaming convolution (conv_wino43.hip, k_conv_wino43s):
+//   A. numerics: a K-deep 32x32 product from f32 operands on (1) the exact-f32 MFMA, (2) f16 MFMA with every operand split
+//      in two halves hi + lo (11 + 11 significand bits, power-of-two pre-scale) and the products hi*hi + hi*lo + lo*hi,
+//      (3) the same with lo*lo, (4) bf16 MFMA with three-way splits and six products -- all accumulated in f32 by the
+//      matrix pipe, against a float64 reference;
+//   B. issue rate of v_mfma_f32_32x32x16_f16 with one and two waves per SIMD;
+//   C. LDS fill: a 512-thread workgroup streaming 48 KB slabs through a ring of three by LDS-DMA (two wave sets that
+//      issue on alternate periods, so each wave waits vmcnt(0) before it issues again and a slab has two periods to land),
+//      with and without the MFMA / ds_read work of the convolution, under three sharing patterns of the source streams.
+//   hipcc --offload-arch=gfx950 -O3 split_mfma.hip -o split_mfma
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+
+// ---- A ---------------------------------------------------------------------------------------------------------
+// A (32 x K) row-major, B (K x 32) row-major, D (32 x 32).  One wave.
+template <int VAR>
+__global__ void k_num(const float *A, const float *B, int K, float sa, float sb, float *D) {
+    const int l = threadIdx.x, m = l & 31, kh = l >> 5;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (VAR == 0) {
+        for (int k = 0; k < K; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m * K + k + kh], B[(k + kh) * 32 + m], acc, 0, 0, 0);
+    } else if (VAR == 1 || VAR == 2) {
+        for (int k = 0; k < K; k += 16) {
+            h8 ah, al, bh, bl;
+            for (int i = 0; i < 8; ++i) {
+                const float a = A[m * K + k + 8 * kh + i] * sa, b = B[(k + 8 * kh + i) * 32 + m] * sb;
+                ah[i] = (_Float16)a; al[i] = (_Float16)(a - (float)ah[i]);
+                bh[i] = (_Float16)b; bl[i] = (_Float16)(b - (float)bh[i]);
+            }
+            if (VAR == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        }
+    } else {
+        for (int k = 0; k < K; k += 16) {
+            b8 a0, a1, a2, b0, b1, b2;
+            for (int i = 0; i < 8; ++i) {
+                float a = A[m * K + k + 8 * kh + i], b = B[(k + 8 * kh + i) * 32 + m];
+                a0[i] = (__bf16)a; a -= (float)a0[i]; a1[i] = (__bf16)a; a -= (float)a1[i]; a2[i] = (__bf16)a;
+                b0[i] = (__bf16)b; b -= (float)b0[i]; b1[i] = (__bf16)b; b -= (float)b1[i]; b2[i] = (__bf16)b;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+        }
+    }
+    const float inv = (VAR == 1 || VAR == 2) ? 1.0f / (sa * sb) : 1.0f;
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + m] = acc[r] * inv;
+}
+
+static float pow2_scale(const std::vector<float> &v, int target_log2) {
+    float mx = 0.f;
+    for (float x : v) mx = std::fmax(mx, std::fabs(x));
+    if (mx == 0.f) return 1.f;
+    int e;
+    std::frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1)  =>  mx <= 2^e
+    return std::ldexp(1.0f, target_log2 - e);
+}
+
+static void numerics(int K, int kind) {
+    std::mt19937 rng(1234 + kind);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> A(32 * K), B(K * 32);
+    for (auto &x : A) {
+        const float g = nd(rng);
+        x = kind == 0 ? g : (kind == 1 ? std::fmax(g, 0.f) * std::exp(1.5f * nd(rng)) : g * std::exp(3.0f * nd(rng)));
+    }
+    for (auto &x : B) x = 0.02f * nd(rng) * (kind == 2 ? std::exp(2.0f * nd(rng)) : 1.f);
+    std::vector<double> ref(1024, 0.0);
+    for (int m = 0; m < 32; ++m)
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < 32; ++n) ref[m * 32 + n] += (double)A[m * K + k] * (double)B[k * 32 + n];
+    double rmax = 0;
+    for (double r : ref) rmax = std::fmax(rmax, std::fabs(r));
+    float *dA, *dB, *dD;
+    hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dD, 4096);
+    hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+    const float sa = pow2_scale(A, 15), sb = pow2_scale(B, 14);
+    static const char *names[] = {"f32 mfma", "f16x2, 3 products", "f16x2, 4 products", "bf16x3, 6 products"};
+    static const char *kinds[] = {"signed normal", "relu x lognormal(1.5)", "heavy tails (lognormal 3 / 2)"};
+    printf("K = %d, A %s  (scales 2^%d, 2^%d)\n", K, kinds[kind], (int)std::log2(sa), (int)std::log2(sb));
+    for (int var = 0; var < 4; ++var) {
+        if (var == 0) hipLaunchKernelGGL(k_num<0>, dim3(1), dim3(64), 0, 0, dA, dB, K, sa, sb, dD);
+        if (var == 1) hipLaunchKernelGGL(k_num<1>, dim3(1), dim3(64), 0, 0, dA, dB, K, sa, sb, dD);
+        if (var == 2) hipLaunchKernelGGL(k_num<2>, dim3(1), dim3(64), 0, 0, dA, dB, K, sa, sb, dD);
+        if (var == 3) hipLaunchKernelGGL(k_num<3>, dim3(1), dim3(64), 0, 0, dA, dB, K, sa, sb, dD);
+        std::vector<float> D(1024);
+        hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost);
+        double emax = 0, e2 = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const double e = std::fabs((double)D[i] - ref[i]);
+            emax = std::fmax(emax, e);
+            e2 += e * e;
+        }
+        printf("  %-20s max err / max|ref| = %.3e   rms err / max|ref| = %.3e\n", names[var], emax / rmax, std::sqrt(e2 / 1024) / rmax);
+    }
+    hipFree(dA); hipFree(dB); hipFree(dD);
+}
+
+// ---- B ---------------------------------------------------------------------------------------------------------
+template <int MW>
+__global__ __launch_bounds__(256 * MW) void k_rate(int nm, float *out, long long *res) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(1.0f + lane * 1e-3f); b[i] = (_Float16)0.5f; }
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < nm / 4; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * 512 + tid] = s;
+    if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; }
+}
+
+template <int MW>
+static void rate(float *out, long long *res_d) {
+    const int nm = 4096;
+    long long res[16];
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_rate<MW>, dim3(256), dim3(256 * MW), 0, 0, nm, out, res_d);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+    long long lo = res[0], hi = res[1];
+    for (int w = 0; w < 4 * MW; ++w) { lo = res[2 * w] < lo ? res[2 * w] : lo; hi = res[2 * w + 1] > hi ? res[2 * w + 1] : hi; }
+    printf("v_mfma_f32_32x32x16_f16, %d wave(s) per SIMD: %.1f cycles per MFMA per SIMD\n", MW, (double)(hi - lo) / ((double)nm * MW));
+}
+
+// ---- C ---------------------------------------------------------------------------------------------------------
+static constexpr int SLAB = 48 * 1024, VPART = 16 * 1024;  // per slab: 8 position slots x (V hi 1K, V lo 1K | U hi 2K, U lo 2K)
+__device__ __forceinline__ void glds16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+// WORK bit 0: ds_read_b128 of the operands, bit 1: MFMAs (3 per block, 2 blocks per period and wave)
+template <int WORK>
+__global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc, int pattern, int n_periods, float *out, long long *res) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int set = wv >> 2, w4 = wv & 3;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, r = j & 31;
+    // pattern 0: every workgroup its own streams; 1: the convolution's XCD round (4 pixel blocks x 8 channel tiles per XCD,
+    // all XCDs the same channel tiles); 2: every workgroup the same streams
+    long long vb, ut;
+    if (pattern == 0) { vb = b & 255; ut = b & 255; }
+    else if (pattern == 1) { vb = xcd * 4 + (r >> 3); ut = r & 7; }
+    else { vb = 0; ut = 0; }
+    const char *vbase = vsrc + vb * (long long)n_periods * VPART;
+    const char *ubase = usrc + ut * (long long)n_periods * (SLAB - VPART);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    f32x16 acc[2];
+    for (int q = 0; q < 2; ++q)
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    // copies of slab s into ring buffer `buf`: 48 pieces of 1 KB, 12 per wave of the issuing set: pieces 0..15 = V, 16..47 = U
+#define ISSUE(S, BUF)                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < 12; ++c) {                                                       \
+        const int piece = w4 * 12 + c;                                                                     \
+        const char *src = piece < 16 ? vbase + (long long)(S) * VPART + piece * 1024                       \
+                                     : ubase + (long long)(S) * (SLAB - VPART) + (piece - 16) * 1024;      \
+        glds16(src, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * SLAB + piece * 1024));                 \
+    }
+    if (set == 0) { ISSUE(0, 0) } else { ISSUE(1, 1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int pg = wv >> 1, nh = wv & 1;
+    const long long t0 = __builtin_readcyclecounter();
+    int buf = 0;
+    for (int k = 0; k < n_periods; ++k) {
+        const bool mine = (k & 1) == set;
+        int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
+        if (mine && k + 2 < n_periods) { ISSUE(k + 2, nb) }
+        if (WORK & 1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int slot = pg * 2 + q;
+                const char *vs = smem + buf * SLAB + slot * 2048, *us = smem + buf * SLAB + VPART + slot * 4096;
+                const h8 ah = *(const h8 *)(vs + lane * 16), al = *(const h8 *)(vs + 1024 + lane * 16);
+                const h8 bh = *(const h8 *)(us + ((lane >> 5) * 64 + nh * 32 + (lane & 31)) * 16);
+                const h8 bl = *(const h8 *)(us + 2048 + ((lane >> 5) * 64 + nh * 32 + (lane & 31)) * 16);
+                if (WORK & 2) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[q], 0, 0, 0);
+                } else {
+                    acc[q][0] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3];
+                }
+            }
+        }
+        if (!mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int q = 0; q < 2; ++q)
+        for (int i = 0; i < 16; ++i) s += acc[q][i];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) { res[2 * blockIdx.x] = t0; res[2 * blockIdx.x + 1] = t1; }
+}
+
+template <int WORK>
+static void fill(const char *vsrc, const char *usrc, int pattern, int n_periods, int blocks, float *out, long long *res_d) {
+    hipFuncSetAttribute((const void *)k_fill<WORK>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SLAB);
+    std::vector<long long> res(2 * blocks);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_fill<WORK>, dim3(blocks), dim3(512), 3 * SLAB, 0, vsrc, usrc, pattern, n_periods, out, res_d);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemcpy(res.data(), res_d, res.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0, mx = 0;
+    for (int i = 0; i < blocks; ++i) {
+        const double c = (double)(res[2 * i + 1] - res[2 * i]) / n_periods;
+        sum += c;
+        mx = c > mx ? c : mx;
+    }
+    static const char *pn[] = {"own streams", "XCD round 4 x 8", "one stream"};
+    const double bytes = (double)blocks * n_periods * SLAB;
+    printf("fill work=%d %-16s: %7.1f cycles per 48 KB period (max %7.1f) = %5.1f B/clk/CU;  %.3f ms, %.2f TB/s into LDS\n", WORK, pn[pattern],
+           sum / blocks, mx, SLAB / (sum / blocks), ms, bytes / ms / 1e9);
+}
+
+int main(int argc, char **argv) {
+    const int what = argc > 1 ? atoi(argv[1]) : 7;
+    if (what & 1) {
+        for (int kind = 0; kind < 3; ++kind) numerics(2048, kind);
+        numerics(18432, 0);
+        numerics(18432, 1);
+    }
+    float *out;
+    long long *res_d;
+    hipMalloc(&out, 4096 * 512 * 4);
+    hipMalloc(&res_d, 4096 * 16);
+    if (what & 2) { rate<1>(out, res_d); rate<2>(out, res_d); }
+    if (what & 4) {
+        const int n_periods = 288, blocks = 1024;  // Cin = 1024: 64 groups of 16 channels x 4.5 periods
+        char *vsrc, *usrc;
+        const size_t vbytes = (size_t)256 * n_periods * VPART, ubytes = (size_t)256 * n_periods * (SLAB - VPART);
+        hipMalloc(&vsrc, vbytes); hipMalloc(&usrc, ubytes);
+        hipMemset(vsrc, 0, vbytes); hipMemset(usrc, 0, ubytes);
+        for (int pattern = 2; pattern >= 0; --pattern) {
+            fill<0>(vsrc, usrc, pattern, n_periods, blocks, out, res_d);
+            fill<1>(vsrc, usrc, pattern, n_periods, blocks, out, res_d);
+            fill<3>(vsrc, usrc, pattern, n_periods, blocks, out, res_d);
+        }
+    }
+    return 0;
+}
