@@ -2,7 +2,8 @@
 """bench.py -- candidate-evals/sec of the ES evaluate-population hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., one rank
+    per GPU, or from a bare shell: without WORLD_SIZE in the environment bench.py launches those N ranks itself)
 
 One step = one ES iteration on synthetic input: ask() -> render the population through the
 effect chain -> log-mel -> AFx-Rep (Cnn14) -> cosine loss -> [all-gather fitness] -> tell().
@@ -250,14 +251,48 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pop512", action="store_true", help="skip the second timed region at BASELINE.json's target population (512 per GPU)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started from a bare shell: launch one rank per GPU through torch.distributed.run (what the driver does itself
+        # for its scaling runs) and hand its exit code back; rank 0 of the children prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or start bench.py without "
+                         "WORLD_SIZE in the environment: it launches the ranks itself)")
+    if os.environ.get("STITO_BENCH_DRYRUN") == "1":
+        # launch-path check without a GPU (tests/test_host_logic.py): rendezvous over gloo, the barrier + max-over-ranks
+        # timing skeleton of the real run, one JSON line from rank 0
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        seen = [None] * world
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_gather_object(seen, rank)
+        else:
+            seen = [0]
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": seen, "max_over_ranks": float(t.item()),
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # STITO_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional check of the N > 1 path on a
@@ -329,6 +364,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # second timed region: BASELINE.json's target line is quoted at pop = 512 (per GPU); configs[1], on which `value` is
+    # measured, has 256.  Same chain / input / model, fresh CMA-ES state, same barrier + max-over-ranks bracket.
+    pop512 = None
+    if not args.no_pop512 and args.pop_per_gpu != 512:
+        P512 = 512 * world
+        es512 = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P512, "seed": 42})
+
+        def step512():
+            W = es512.ask()
+            lo, hi = shard_bounds(P512, rank, world)
+            loss, _, _ = ev.evaluate(W[lo:hi])
+            es512.tell(W, gather_fitness(loss, P512).tolist())
+        step512()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step512()
+        fence()
+        dt512 = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([dt512], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt512 = float(t.item())
+        pop512 = {"value": round(P512 * args.steps / dt512, 3), "unit": "candidate-evals/s", "pop_per_gpu": 512,
+                  "ms_per_step": round(dt512 / args.steps * 1e3, 3), "steps": args.steps, "warmup": 1}
+
+    ranks_seen = [0]
+    if dist is not None:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, (rank, torch.cuda.get_device_properties(dev).name, local_dev))
+
     out = {
         "metric": "candidate-evals/sec (pop x iters), 48 kHz 10 s stereo, 5-effect chain",
         "value": round(P_total * args.steps / dt, 3), "unit": "candidate-evals/s", "n_gpus": world,
@@ -340,8 +406,11 @@ def main():
         "config": {"workload": f"ES evaluate-population: pop={args.pop_per_gpu}/GPU ({P_total} total), 48 kHz stereo "
                    f"{args.seconds:g} s, chain EQ/comp/reverb/EQ/gain (D={D}), AFx-Rep Cnn14 (seeded random weights), "
                    "CMA-ES seed 42", "pop_per_gpu": args.pop_per_gpu, "n_samples": n, "chain": kinds,
-                   "parallelism": f"population sharded over {world} GPU(s), fitness all-gather"},
+                   "parallelism": f"population sharded over {world} GPU(s), fitness all-gather",
+                   "backend": backend if world > 1 else None, "ranks": ranks_seen},
     }
+    if pop512 is not None:
+        out["north_star_pop512"] = pop512
     if rank == 0:
         if not args.no_roofline:
             T = n // 1024 + 1

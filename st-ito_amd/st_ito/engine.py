@@ -198,7 +198,11 @@ class PopulationEvaluator:
         self.n_inputs = x.shape[0]
         self.x_full = x.to(self.device, torch.float32).contiguous()
         self.embed_func = embed_func
-        self.fused = embed_func is None or embed_func is _utils.get_param_embeds
+        # the fused path embeds the rendered audio as 48 kHz audio; at any other rate the reference resamples inside
+        # get_param_embeds (utils.py:462-463), on both sides of the distance: that goes through the generic path
+        self.fused = (embed_func is None or embed_func is _utils.get_param_embeds) and int(sample_rate) == 48000
+        if embed_func is None and not self.fused:
+            self.embed_func = _utils.get_param_embeds
         self.targets = {k: v.detach().to(self.device, torch.float32).contiguous().view(-1, v.shape[-1])
                         for k, v in target_embeds.items()}
         for k, v in self.targets.items():
@@ -210,10 +214,13 @@ class PopulationEvaluator:
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         self._streams = None
 
-    def _input(self, random_crop: bool, rng) -> torch.Tensor:
-        """Length policy of style_transfer.py:505-518 (one crop position for all inputs of a batch)."""
+    def _input(self, random_crop: bool, rng, parallel: bool = False) -> torch.Tensor:
+        """Length policy of style_transfer.py:505-518 (one crop position for all inputs of a batch).  The reference's
+        parallel=True branch (499-502) hands x to the pool as it is: no padding to 262144, no crop."""
         x = self.x_full
         n = x.shape[-1]
+        if parallel:
+            return x
         if n > CROP_LEN:
             if random_crop:  # 506-514: start 0 unless more than 16384 samples are spare (the crop still happens)
                 start = int(rng.randint(16384, n - CROP_LEN)) if (n - CROP_LEN) > 16384 else 0
@@ -232,7 +239,8 @@ class PopulationEvaluator:
         g = int(os.environ.get("STITO_PIPELINE_GROUPS", "1"))
         return max(1, min(g, P))
 
-    def evaluate(self, W, random_crop: bool = False, rng=np.random, want_audio: bool = False, dropout: float = 0.0):
+    def evaluate(self, W, random_crop: bool = False, rng=np.random, want_audio: bool = False, dropout: float = 0.0,
+                 parallel: bool = False):
         """Fitness of every row of W.  With more than one group (see _groups) the population is
         software-pipelined over two HIP streams: while group g runs log-mel + Cnn14 + loss on the
         embed stream, group g+1 runs its effect chain on the render stream.  A candidate's result
@@ -240,7 +248,7 @@ class PopulationEvaluator:
         Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
         if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
             raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
-        x = self._input(random_crop, rng)
+        x = self._input(random_crop, rng, parallel)
         P = Wt.shape[0]
         B = self.n_inputs
         if P % B:

@@ -180,8 +180,9 @@ def run_es(
 ):
     """Run CMA-ES optimization to find the best parameters (reference style_transfer.py:399-692).
 
-    Same arguments and result dict as the reference (`parallel` is accepted and ignored: the whole
-    population is rendered on the GPU at once).  Extensions: `seed` (CMA-ES + find_w0 RNG; the
+    Same arguments and result dict as the reference.  `parallel` selects the reference's pool branch (499-502), whose only
+    observable difference is the length policy: the candidates are rendered from the input as it is (no zero padding to
+    262144 samples, no random crop); the whole population is rendered on the GPU at once either way.  Extensions: `seed` (CMA-ES + find_w0 RNG; the
     reference is unseeded) and `early_stop` (False disables the break of lines 655-670 for fixed
     work benchmarks).  Under torch.distributed each rank evaluates a contiguous shard of the
     population and the fitness scalars are all-gathered; the CMA-ES state is replicated."""
@@ -216,7 +217,7 @@ def run_es(
     def evaluate(W, dropout: float = 0.0, want_audio: bool = False):
         """GPU replacement of the reference's evaluate closure (474-573)."""
         out = sharded_evaluate(W, lambda Ws: evaluator.evaluate(Ws, random_crop=random_crop, rng=rng,
-                                                                want_audio=want_audio, dropout=dropout))
+                                                                want_audio=want_audio, dropout=dropout, parallel=parallel))
         warn = evaluator.nan_warning()  # after the fitness download: no extra synchronisation
         if warn:
             print(warn)

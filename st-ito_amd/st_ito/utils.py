@@ -34,7 +34,14 @@ def get_param_embeds(
     L2-normalised, returned with x's device/dtype.
 
     The per-item peak normalisation (utils.py:473-474) is fused into the STFT loader of the HIP
-    front-end instead of rewriting x; the NaN scrub and F.normalize run in stito_embed_loss."""
+    front-end; the NaN scrub and F.normalize run in stito_embed_loss.
+
+    Side effect kept from the reference: there `x.type_as(model parameter)` returns x itself when x already has the
+    model's dtype and device type and no resampling happens, so lines 473-474 peak-normalise the CALLER's tensor in
+    place.  The HIP model always lives on the GPU; the device the reference's model would be on is the one
+    load_param_model was asked for (`model.reference_device`: "cuda" for use_gpu=True, else "cpu"; a model built
+    directly counts as living where its parameters are).  When x is float32 on that device type at 48 kHz it comes back
+    normalised, exactly as from the reference; otherwise it is left untouched, as there."""
     if x.dim() != 3:
         raise ValueError("expected (bs, chs, seq_len)")
     if requires_grad:
@@ -67,6 +74,9 @@ def get_param_embeds(
         print("Warning: NaNs found in mid_embeddings")
     elif fl[1]:
         print("Warning: NaNs found in side_embeddings")
+    ref_dev = getattr(model, "reference_device", None) or dev.type
+    if x.dtype == torch.float32 and sample_rate == 48000 and x.device.type == ref_dev and not x.requires_grad:
+        x.div_(peaks.to(x.device).clamp(min=1e-8).view(-1, 1, 1))  # utils.py:473-474 on the caller's tensor
     return {"mid": mid.type_as(x_device), "side": side.type_as(x_device)}
 
 
@@ -77,7 +87,7 @@ def _load_checkpoint(ckpt_path: str) -> dict:
     was written for unpickles arbitrary objects.  Here the file is read with weights_only=True; classes
     the checkpoint mentions outside torch's allow-list (Lightning / jsonargparse hyper-parameter
     containers, callbacks state, ...) are mapped to inert stand-ins of the same qualified name -- their
-    attributes are restored as plain data, no constructor or reducer of the real class ever runs -- since
+    constructor arguments and state are discarded, no constructor or reducer of the real class ever runs -- since
     only checkpoint["state_dict"] is used.  STITO_TRUST_CHECKPOINT=1 restores the reference's full unpickle."""
     import pickle
     import re
@@ -95,7 +105,14 @@ def _load_checkpoint(ckpt_path: str) -> dict:
                 raise
             module, _, name = m.group(1).rpartition(".")
             stand_ins.append(type(name, (), {"__module__": module, "__qualname__": name,
-                                             "__setstate__": lambda self, state: None}))
+                                             "__new__": lambda cls, *a, **k: object.__new__(cls),
+                                             "__init__": lambda self, *a, **k: None,
+                                             "__setstate__": lambda self, state: None,
+                                             "__call__": lambda self, *a, **k: None}))
+        except Exception as e:  # a foreign object the restricted unpickler cannot rebuild even as an inert stand-in
+            raise pickle.UnpicklingError(
+                f"{ckpt_path}: cannot be read without executing pickled code ({type(e).__name__}: {e}). If the file is "
+                "trusted, set STITO_TRUST_CHECKPOINT=1 to load it with the reference's full torch.load") from e
     raise pickle.UnpicklingError(f"{ckpt_path}: too many foreign classes in the checkpoint")
 
 
@@ -131,6 +148,7 @@ def load_param_model(ckpt_path: str = None, use_gpu: bool = False):
     model.eval()
     if use_gpu or torch.cuda.is_available():
         model.cuda()
+    model.reference_device = "cuda" if use_gpu else "cpu"  # where the reference's model would live (get_param_embeds)
     return model
 
 

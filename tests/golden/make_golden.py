@@ -18,6 +18,7 @@ orchestration, not the front-end ("parity unpinned" ther
   G4 params_to_dict.npz   style_transfer.py:324-359
   G5 param_embeds_toy.npz utils.py:444-508 with a deterministic toy model
   G6 cnn14_trunk_*.npz    panns.py:209-281 conv stack (+ this repo's front-end)
+  G6b cnn14_trunk_minmax_262144.npz  the same on a 257 x 128 map (input stored as its synth_audio recipe)
   G7 evaluate_*.npz       style_transfer.py:399-692 run_es -> evaluate losses (fake `cma`)
   G8 features.npz         features.py:166-264 bark spectrum (3 modes, 2 FFT sizes), RMS, crest factor
                           on O.synth_audio(seed, 2, n) inputs (the fixture stores the recipe, not the audio)
@@ -250,6 +251,18 @@ def g7():
              fvals=np.array(FakeES.told, dtype=np.float64), wopt=np.asarray(res["wopt"]),
              fopt=np.array(res["fopt"]), output_audio=res["output_audio"].numpy(), seed=np.array(0))
 
+def g6b():
+    """One bench-shaped map through the reference's own conv stack: n = 262 144 -> 257 x 128 log-mel,
+    final map 8 x 4.  minmax only; the fixture stores the input's recipe (O.synth_audio(seed, 2, n)), not the audio."""
+    n, seed = 262144, 24
+    x = O.synth_audio(seed, 2, n)[None]
+    m = _ref_cnn14("minmax")
+    with torch.no_grad():
+        mid, side = m(x)
+        e = RU.get_param_embeds(x.clone(), m, SR)
+    save("cnn14_trunk_minmax_262144.npz", audio_seed=np.array(seed), n=np.array(n), mid=mid.numpy(), side=side.numpy(),
+         embed_mid=e["mid"].numpy(), embed_side=e["side"].numpy(), seed=np.array(0))
+
 
 def g8():
     import st_ito.features as RF  # reference (torchaudio / pyloudnorm are stand-ins: centroid and LUFS are not pinned)
@@ -267,6 +280,6 @@ def g8():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g6b", "g7", "g8"]
     for name in which:
-        {"g1": g1, "g2": g2, "g3": g3_g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8}[name]()
+        {"g1": g1, "g2": g2, "g3": g3_g4, "g5": g5, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8}[name]()

@@ -114,6 +114,100 @@ def test_full_size_config1_properties(dev, pm):
         assert torch.equal(e1["mid"][0], emb["mid"][idx]) and torch.equal(e1["side"][0], emb["side"][idx])
 
 
+def test_full_size_config3_per_gpu_share_properties(dev, pm):
+    """BASELINE.json configs[3]: one GPU's share of the 8-GPU job (pop 2048 sharded 256 per GPU, 48 kHz stereo 30 s,
+    T = 1407 frames) at full size through size-independent properties: finite cosine losses, normalised audio peaks at
+    exactly 1, and three candidates of the batch are bitwise the ones evaluated alone (so the share a rank computes does
+    not depend on what else is in its batch -- the property the sharding relies on)."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds
+    n, P = 1440000, 256
+    x = O.synth_audio(1234, 2, n)[None]
+    tgt = O.synth_audio(4321, 2, n)[None]
+    ev = PopulationEvaluator(x, SR, E.make_plugins("bench5"), pm, get_param_embeds(tgt, pm, SR))
+    W = np.random.default_rng(2026).random((P, 45))
+    loss, emb, audio = ev.evaluate(W, want_audio=True)
+    lossn = loss.cpu().numpy()
+    assert lossn.shape == (P,) and np.isfinite(lossn).all() and (np.abs(lossn) <= 1.0001).all()
+    assert audio.shape == (P, 2, n)
+    pk = audio.abs().amax(dim=(1, 2)).cpu().numpy()
+    np.testing.assert_array_equal(pk, np.ones(P, np.float32))
+    del audio
+    for idx in (0, 131, 255):
+        l1, e1, _ = ev.evaluate(W[idx:idx + 1])
+        assert l1.item() == lossn[idx]
+        assert torch.equal(e1["mid"][0], emb["mid"][idx]) and torch.equal(e1["side"][0], emb["side"][idx])
+
+
+def test_get_param_embeds_normalises_the_callers_tensor_like_the_reference(dev, pm):
+    """reference utils.py:457, 473-474: `x.type_as(model parameter)` is x itself when dtype and device type already match
+    and no resampling happens, so the per-item peak normalisation lands in the CALLER's tensor.  The HIP model always
+    lives on the GPU; `model.reference_device` says where the reference's model would live."""
+    from st_ito.utils import get_param_embeds
+    x0 = 0.3 * O.synth_audio(5, 2, 50000)[None].repeat(2, 1, 1)
+    x0[1] *= 0.5
+    want = x0.clone()
+    for b in range(2):
+        want[b] /= want[b].abs().max().clamp(1e-8)
+    # a model built directly lives on the GPU: a CPU tensor is copied by the reference (untouched) ...
+    assert getattr(pm, "reference_device", None) in (None, "cuda")
+    pm.reference_device = "cuda"
+    x = x0.clone()
+    e_cpu = get_param_embeds(x, pm, SR)
+    assert torch.equal(x, x0)
+    # ... a float32 GPU tensor is normalised in place
+    xg = x0.clone().to(dev)
+    e_gpu = get_param_embeds(xg, pm, SR)
+    assert torch.equal(xg.cpu(), want)
+    assert torch.equal(e_gpu["mid"].cpu(), e_cpu["mid"])
+    # the model load_param_model(use_gpu=False) returns stands for a CPU model: the CPU tensor is normalised in place
+    pm.reference_device = "cpu"
+    try:
+        x = x0.clone()
+        e2 = get_param_embeds(x, pm, SR)
+        assert torch.equal(x, want) and torch.equal(e2["mid"], e_cpu["mid"])
+        xd = x0.clone().double()      # dtype change -> copy -> untouched
+        get_param_embeds(xd, pm, SR)
+        assert torch.equal(xd, x0.double())
+        x441 = x0.clone()             # resampled -> copy -> untouched
+        get_param_embeds(x441, pm, 44100)
+        assert torch.equal(x441, x0)
+    finally:
+        pm.reference_device = "cuda"
+
+
+def test_parallel_flag_keeps_the_reference_length_policy(dev):
+    """reference style_transfer.py:499-502: with parallel=True the pool renders x as it is -- no zero padding to 262144
+    samples, no crop -- so a short input is evaluated on its own length.  Serial branch: padded (517-518)."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds
+    from st_ito.models.panns import Cnn14
+    om = O.make_synthetic_model(0)
+    pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "minmax")   # the oracle model's weights
+    pm.load_state_dict(om.state_dict())
+    pm.eval().to(dev)
+    n = 60000
+    x = O.synth_audio(21, 2, n)[None]
+    tgt = O.synth_audio(22, 2, n)[None]
+    kinds = ["ParametricEQ", "Compressor"]
+    op = O.make_plugins(kinds)
+    W = np.random.default_rng(3).random((3, 22))
+    ev = PopulationEvaluator(x, SR, E.make_plugins("eq-comp"), pm, get_param_embeds(tgt.clone(), pm, SR))
+    l_par, _, a_par = ev.evaluate(W, parallel=True, want_audio=True)
+    l_ser, _, a_ser = ev.evaluate(W, parallel=False, want_audio=True)
+    assert a_par.shape[-1] == n and a_ser.shape[-1] == 262144
+    te_ref = O.get_param_embeds(tgt.clone(), om, SR)
+    f_ser, _, _ = O.evaluate(list(W), x, SR, op, te_ref, om)                    # the oracle's serial branch pads
+    audios = torch.stack([torch.from_numpy(O.process_audio(x[0].numpy(), w, SR, op)) for w in W])
+    emb = O.get_param_embeds(audios, om, SR)                                     # the pool branch: no padding
+    f_par = np.mean([(-torch.cosine_similarity(emb[k], te_ref[k], dim=-1)).numpy() for k in emb], axis=0)
+    assert np.abs(l_ser.cpu().numpy() - np.array(f_ser)).max() < 1e-4
+    assert np.abs(l_par.cpu().numpy() - f_par).max() < 1e-4
+    assert np.abs(l_par.cpu().numpy() - l_ser.cpu().numpy()).max() > 1e-5        # the two policies do differ on a short input
+
+
 def test_config3_length_30s(dev, pm):
     """BASELINE.json configs[3] per-candidate shape (48 kHz stereo 30 s, T = 1407 frames): the
     whole path runs at that length and agrees with the oracle on one candidate."""

@@ -504,6 +504,25 @@ def test_model_vs_golden_reference(dev, golden_dir, norm):
         assert np.abs(e[key].numpy() - ref).max() / np.abs(ref).max() < 1e-4
 
 
+def test_model_vs_golden_reference_bench_shaped_map(dev, golden_dir):
+    """The reference's OWN conv stack on a 257 x 128 log-mel map (n = 262 144, the CLI's default crop; final map 8 x 4):
+    tests/golden/cnn14_trunk_minmax_262144.npz (make_golden.py g6b) -- the small fixtures above only reach a 1 x 4 final
+    map.  Raw fc outputs and get_param_embeds within 1e-4 of the reference's values."""
+    from st_ito.utils import get_param_embeds
+    g = np.load(os.path.join(golden_dir, "cnn14_trunk_minmax_262144.npz"))
+    _, pm = _models(dev, "minmax", int(g["seed"]))
+    x = O.synth_audio(int(g["audio_seed"]), 2, int(g["n"]))[None]
+    mid, side = pm(x.to(dev))
+    for got, key in ((mid, "mid"), (side, "side")):
+        rel = np.abs(got.cpu().numpy() - g[key]).max() / np.abs(g[key]).max()
+        print(f"{key}: {rel:.2e} of the reference's maximum")
+        assert rel < 1e-4, f"{key}: {rel:.3e}"
+    e = get_param_embeds(x.clone(), pm, SR)
+    for key in ("mid", "side"):
+        ref = g[f"embed_{key}"]
+        assert np.abs(e[key].numpy() - ref).max() / np.abs(ref).max() < 1e-4
+
+
 def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
     """The float32 trunk (conv_split = False): F(4x4,3x3) with the input transform hoisted into its own pass from 512
     output channels up (conv_block4-6, STITO_CONV_WINOGRAD_F4_PRE) against the same trunk with every layer transforming

@@ -287,7 +287,7 @@ np.random.seed(1000 + rank)               # the ranks' global RNGs differ, like 
 class FakeEvaluator:                      # stands in for the GPU evaluator
     def __init__(self, x, sr, plugins, model, target_embeds, **kw):
         self.ndims = 4
-    def evaluate(self, W, random_crop=False, rng=None, want_audio=False, dropout=0.0):
+    def evaluate(self, W, random_crop=False, rng=None, want_audio=False, dropout=0.0, parallel=False):
         W = np.asarray(W)
         f = torch.tensor([float(np.sum((w - 0.3) ** 2)) for w in W], dtype=torch.float32)
         audio = torch.stack([torch.full((1, 8), float(w[0])) for w in W]) if want_audio else None
@@ -487,3 +487,23 @@ def test_bench_measurement_bookkeeping(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "PMC_TRAFFIC_JSON", str(p))
     t, note = bench.pmc_traffic_per_launch(committed["n_streams"])
     assert t is None and "was taken on kernel sources" in note
+
+
+def test_bench_self_launches_ranks_dryrun():
+    """bench.py started from a bare shell with --gpus 2 and no WORLD_SIZE launches its own ranks through
+    torch.distributed.run.  STITO_BENCH_DRYRUN=1 stops each rank after the gloo rendezvous + the
+    barrier / max-over-ranks skeleton, so the launch path is covered without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["STITO_BENCH_DRYRUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"dryrun": True, "n_gpus": 2, "ranks_seen": [0, 1], "max_over_ranks": 2.0, "steps": 3, "warmup": 1}
+    # a rank count that disagrees with the launcher's WORLD_SIZE is refused, not silently benchmarked
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)

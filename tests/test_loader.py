@@ -42,7 +42,11 @@ def _write_checkpoint(tmp_path, input_norm, use_batchnorm=True, seed=3, tamper=N
     mod._Booby = _Booby
     sys.modules["fake_lightning_pkg"] = mod
     ckpt = {"epoch": 12, "global_step": 3456, "pytorch-lightning_version": "2.1.0", "state_dict": sd,
-            "hyper_parameters": _Booby(lr=1e-4, num_instances=63), "optimizer_states": [{"state": {}, "param_groups": []}]}
+            "hyper_parameters": _Booby(lr=1e-4, num_instances=63), "optimizer_states": [{"state": {}, "param_groups": []}],
+            # objects Lightning checkpoints commonly carry and the reference's torch.load reads: they are pickled
+            # through REDUCE with arguments, so their stand-ins must accept (and drop) constructor arguments
+            "hparams_extra": {"ckpt_dir": __import__("pathlib").PosixPath("/tmp/run/ckpts"), "lr_np": np.float64(1e-4),
+                              "steps_np": np.int64(7)}}
     d = tmp_path / f"ckpt_{input_norm}_{use_batchnorm}"
     d.mkdir()
     torch.save(ckpt, str(d / "afx-rep.ckpt"))

@@ -150,23 +150,28 @@ static void rate(float *out, long long *res_d) {
 }
 
 // ---- C ---------------------------------------------------------------------------------------------------------
-static constexpr int SLAB = 48 * 1024, VPART = 16 * 1024;  // per slab: 8 position slots x (V hi 1K, V lo 1K | U hi 2K, U lo 2K)
+// slab = SLAB bytes (one third transformed input, two thirds weights), NRING slabs in LDS, NRING - 1 wave sets: set k % NSETS
+// issues slab k + NSETS in period k and waits vmcnt(0) at the end of period k + NSETS - 1, just before it issues again.
 __device__ __forceinline__ void glds16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
-// WORK bit 0: ds_read_b128 of the operands, bit 1: MFMAs (3 per block, 2 blocks per period and wave)
-template <int WORK>
+// WORK bit 0: ds_read_b128 of the operands, bit 1: MFMAs (3 per block, SLAB / 24 KB blocks per period and wave)
+template <int WORK, int SLAB, int NRING>
 __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc, int pattern, int n_periods, float *out, long long *res) {
+    constexpr int NSETS = NRING - 1, WPS = 8 / NSETS, PIECES = SLAB / 1024, PPW = PIECES / WPS, VPART = SLAB / 3, NBLK = SLAB / (24 * 1024);
+    static_assert(PIECES % WPS == 0 && VPART % 1024 == 0, "");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int set = wv >> 2, w4 = wv & 3;
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, r = j & 31;
+    const int set = wv / WPS, ws = wv % WPS;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, r = j & 31, round = b >> 8;
     // pattern 0: every workgroup its own streams; 1: the convolution's XCD round (4 pixel blocks x 8 channel tiles per XCD,
-    // all XCDs the same channel tiles); 2: every workgroup the same streams
+    // all XCDs the same channel tiles), the same streams in every round (they stay in the Infinity Cache); 2: every workgroup
+    // the same streams; 3: as 1 with fresh streams in every round of 256 workgroups (the real kernel)
     long long vb, ut;
     if (pattern == 0) { vb = b & 255; ut = b & 255; }
     else if (pattern == 1) { vb = xcd * 4 + (r >> 3); ut = r & 7; }
+    else if (pattern == 3) { vb = (round * 8 + xcd) * 4 + (r >> 3); ut = round * 8 + (r & 7); }
     else { vb = 0; ut = 0; }
     const char *vbase = vsrc + vb * (long long)n_periods * VPART;
     const char *ubase = usrc + ut * (long long)n_periods * (SLAB - VPART);
@@ -174,44 +179,46 @@ __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc
     f32x16 acc[2];
     for (int q = 0; q < 2; ++q)
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-    // copies of slab s into ring buffer `buf`: 48 pieces of 1 KB, 12 per wave of the issuing set: pieces 0..15 = V, 16..47 = U
 #define ISSUE(S, BUF)                                                                                     \
-    _Pragma("unroll") for (int c = 0; c < 12; ++c) {                                                       \
-        const int piece = w4 * 12 + c;                                                                     \
-        const char *src = piece < 16 ? vbase + (long long)(S) * VPART + piece * 1024                       \
-                                     : ubase + (long long)(S) * (SLAB - VPART) + (piece - 16) * 1024;      \
+    _Pragma("unroll") for (int c = 0; c < PPW; ++c) {                                                      \
+        const int piece = ws * PPW + c;                                                                    \
+        const char *src = piece < VPART / 1024 ? vbase + (long long)(S) * VPART + piece * 1024             \
+                                               : ubase + (long long)(S) * (SLAB - VPART) + (piece - VPART / 1024) * 1024; \
         glds16(src, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * SLAB + piece * 1024));                 \
     }
-    if (set == 0) { ISSUE(0, 0) } else { ISSUE(1, 1) }
+    for (int s0 = 0; s0 < NSETS; ++s0)
+        if (set == s0) { ISSUE(s0, s0) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int pg = wv >> 1, nh = wv & 1;
     const long long t0 = __builtin_readcyclecounter();
-    int buf = 0;
+    int buf = 0, turn = 0;  // turn = k % NSETS
     for (int k = 0; k < n_periods; ++k) {
-        const bool mine = (k & 1) == set;
-        int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-        if (mine && k + 2 < n_periods) { ISSUE(k + 2, nb) }
+        const bool mine = turn == set;
+        int nb = buf + NSETS; nb = nb >= NRING ? nb - NRING : nb;
+        if (mine && k + NSETS < n_periods) { ISSUE(k + NSETS, nb) }
         if (WORK & 1) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int slot = pg * 2 + q;
+            for (int q = 0; q < NBLK; ++q) {
+                const int slot = (wv >> 1) * NBLK + q;
                 const char *vs = smem + buf * SLAB + slot * 2048, *us = smem + buf * SLAB + VPART + slot * 4096;
                 const h8 ah = *(const h8 *)(vs + lane * 16), al = *(const h8 *)(vs + 1024 + lane * 16);
-                const h8 bh = *(const h8 *)(us + ((lane >> 5) * 64 + nh * 32 + (lane & 31)) * 16);
-                const h8 bl = *(const h8 *)(us + 2048 + ((lane >> 5) * 64 + nh * 32 + (lane & 31)) * 16);
+                const h8 bh = *(const h8 *)(us + ((lane >> 5) * 64 + (wv & 1) * 32 + (lane & 31)) * 16);
+                const h8 bl = *(const h8 *)(us + 2048 + ((lane >> 5) * 64 + (wv & 1) * 32 + (lane & 31)) * 16);
                 if (WORK & 2) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[q], 0, 0, 0);
+                    acc[q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[q & 1], 0, 0, 0);
+                    acc[q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[q & 1], 0, 0, 0);
+                    acc[q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[q & 1], 0, 0, 0);
                 } else {
-                    acc[q][0] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3];
+                    acc[q & 1][0] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3];
                 }
             }
         }
-        if (!mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the set that issues next period must have its previous slab landed
+        int nt = turn + 1; nt = nt == NSETS ? 0 : nt;
+        if (nt == set) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NRING - 1 ? 0 : buf + 1;
+        turn = nt;
     }
     const long long t1 = __builtin_readcyclecounter();
     float s = 0;
@@ -221,20 +228,22 @@ __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc
     if (tid == 0) { res[2 * blockIdx.x] = t0; res[2 * blockIdx.x + 1] = t1; }
 }
 
-template <int WORK>
-static void fill(const char *vsrc, const char *usrc, int pattern, int n_periods, int blocks, float *out, long long *res_d) {
-    hipFuncSetAttribute((const void *)k_fill<WORK>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SLAB);
+template <int WORK, int SLAB, int NRING>
+static void fill(const char *vsrc, const char *usrc, int pattern, long long bytes_per_wg, int blocks, float *out, long long *res_d) {
+    const int n_periods = (int)(bytes_per_wg / SLAB);
+    hipFuncSetAttribute((const void *)k_fill<WORK, SLAB, NRING>, hipFuncAttributeMaxDynamicSharedMemorySize, NRING * SLAB);
     std::vector<long long> res(2 * blocks);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_fill<WORK>, dim3(blocks), dim3(512), 3 * SLAB, 0, vsrc, usrc, pattern, n_periods, out, res_d);
+        hipLaunchKernelGGL((k_fill<WORK, SLAB, NRING>), dim3(blocks), dim3(512), NRING * SLAB, 0, vsrc, usrc, pattern, n_periods, out, res_d);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1);
     }
+    if (hipGetLastError() != hipSuccess) printf("launch failed\n");
     hipMemcpy(res.data(), res_d, res.size() * 8, hipMemcpyDeviceToHost);
     double sum = 0, mx = 0;
     for (int i = 0; i < blocks; ++i) {
@@ -242,10 +251,10 @@ static void fill(const char *vsrc, const char *usrc, int pattern, int n_periods,
         sum += c;
         mx = c > mx ? c : mx;
     }
-    static const char *pn[] = {"own streams", "XCD round 4 x 8", "one stream"};
+    static const char *pn[] = {"own streams", "XCD round 4 x 8 (same)", "one stream", "XCD round 4 x 8 (fresh)"};
     const double bytes = (double)blocks * n_periods * SLAB;
-    printf("fill work=%d %-16s: %7.1f cycles per 48 KB period (max %7.1f) = %5.1f B/clk/CU;  %.3f ms, %.2f TB/s into LDS\n", WORK, pn[pattern],
-           sum / blocks, mx, SLAB / (sum / blocks), ms, bytes / ms / 1e9);
+    printf("fill work=%d slab %2d KB x %d %-24s: %7.1f cycles per period (max %7.1f) = %5.1f B/clk/CU;  %.3f ms, %.2f TB/s into LDS\n", WORK,
+           SLAB / 1024, NRING, pn[pattern], sum / blocks, mx, SLAB / (sum / blocks), ms, bytes / ms / 1e9);
 }
 
 int main(int argc, char **argv) {
@@ -261,15 +270,19 @@ int main(int argc, char **argv) {
     hipMalloc(&res_d, 4096 * 16);
     if (what & 2) { rate<1>(out, res_d); rate<2>(out, res_d); }
     if (what & 4) {
-        const int n_periods = 288, blocks = 1024;  // Cin = 1024: 64 groups of 16 channels x 4.5 periods
+        const long long bytes_per_wg = 288ll * 48 * 1024;  // Cin = 1024 through the 32 x 64 tile: 288 slabs of 48 KB
+        const int blocks = 1024;
         char *vsrc, *usrc;
-        const size_t vbytes = (size_t)256 * n_periods * VPART, ubytes = (size_t)256 * n_periods * (SLAB - VPART);
+        const size_t vbytes = (size_t)256 * bytes_per_wg / 3, ubytes = (size_t)256 * bytes_per_wg * 2 / 3;
         hipMalloc(&vsrc, vbytes); hipMalloc(&usrc, ubytes);
         hipMemset(vsrc, 0, vbytes); hipMemset(usrc, 0, ubytes);
-        for (int pattern = 2; pattern >= 0; --pattern) {
-            fill<0>(vsrc, usrc, pattern, n_periods, blocks, out, res_d);
-            fill<1>(vsrc, usrc, pattern, n_periods, blocks, out, res_d);
-            fill<3>(vsrc, usrc, pattern, n_periods, blocks, out, res_d);
+        for (int pattern : {2, 1, 3, 0}) {
+            fill<0, 48 * 1024, 3>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
+            fill<3, 48 * 1024, 3>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
+            fill<3, 72 * 1024, 2>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
+            fill<3, 24 * 1024, 3>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
+            fill<3, 24 * 1024, 5>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
+            fill<0, 24 * 1024, 5>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
         }
     }
     return 0;
