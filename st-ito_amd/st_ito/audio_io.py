@@ -41,7 +41,9 @@ _kernel_cache = {}
 def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
     """torchaudio.functional.resample's kernel table (`_get_sinc_resample_kernel`, "sinc_interp_hann"), restated
     from the library's published algorithm (un-vendored dependency: parity unpinned): float64 design, float32
-    table.  -> (kernels (new, 2 * width + orig) float32, width, orig, new) with orig / new reduced by their gcd."""
+    table.  (functional.resample designs the table in the waveform's dtype, float32, and only transforms.Resample in
+    float64: against the call the reference makes this table therefore agrees to float32 rounding of the design,
+    about 1e-7 of the pass-band gain, not bitwise.)  -> (kernels (new, 2 * width + orig) float32, width, orig, new) with orig / new reduced by their gcd."""
     g = math.gcd(int(orig_freq), int(new_freq))
     orig, new = int(orig_freq) // g, int(new_freq) // g
     base_freq = min(orig, new) * rolloff

@@ -507,3 +507,34 @@ def test_bench_self_launches_ranks_dryrun():
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_compressor_scan_ring_registers_are_out_of_the_compilers_reach(tmp_path):
+    """k_comp_blockscan keeps its 32-block register ring and the in-flight loads in fixed VGPRs v100+ across separate asm
+    statements (generated: tools/gen/gen_comp_scan_asm.py); those registers are only declared as clobbers, so nothing tells
+    the compiler they are live in between.  Build check: the code hipcc itself emits for that kernel -- everything
+    outside the asm statements -- must stay below v100."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "st-ito_amd", "csrc", "compressor.hip")
+    out = tmp_path / "comp.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w", src, "-o", str(out)])
+    text = out.read_text()
+    m = re.search(r"^(_ZN5stito16k_comp_blockscan\w*):.*?^\s*s_endpgm", text, flags=re.S | re.M)
+    assert m, "k_comp_blockscan not found in the compiled assembly"
+    body, inside, highest, n_asm = m.group(0), False, -1, 0
+    for line in body.splitlines():
+        if "ASMSTART" in line:
+            inside, n_asm = True, n_asm + 1
+            continue
+        if "ASMEND" in line:
+            inside = False
+            continue
+        if inside:
+            continue
+        for a, b in re.findall(r"\bv(\d+)\b|\bv\[\d+:(\d+)\]", line.split(";")[0]):
+            highest = max(highest, int(a or b))
+    assert n_asm >= 3, "the ring's asm statements are gone: update this check"
+    assert 0 <= highest < 100, f"compiler-allocated code of k_comp_blockscan reaches v{highest}: it would clobber the ring (v100+)"
