@@ -78,7 +78,8 @@ typedef struct {
 const char *stito_last_error(void);
 /* ABI version: 5 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
- * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT). */
+ * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
+ * stito_conv_timing_read_each). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
@@ -183,7 +184,12 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * overflows), every product is hi hi' + hi lo' + lo hi'.  Results agree with the float32 forms to float32 rounding
         * level (not bitwise); own packing (stito_cnn14_packed_conv_floats), needs cin % 64 == 0, cout % 256 == 0 and
         * stito_conv3x3_bn_relu_ws (ABI version 5). */
-       STITO_CONV_WINOGRAD_F4_SPLIT = 4 };
+       STITO_CONV_WINOGRAD_F4_SPLIT = 4,
+       /* The same arithmetic per product on workgroup tiles twice as large (64 tiles x 64 channels), reached by going over the
+        * input channels twice -- 18 of the 36 Winograd positions per sweep, the first sweep's share of the outputs parked in
+        * the workspace: a third fewer bytes copied into LDS per MAC, which is what bounds _F4_SPLIT.  Own packing; sums in
+        * a different order than _F4_SPLIT (same accuracy, not the same bits). */
+       STITO_CONV_WINOGRAD_F4_SPLIT2 = 5 };
 
 typedef struct {
     int32_t embed_dim;
@@ -195,7 +201,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing) or _F4_SPLIT */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT or _F4_SPLIT2 */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -266,7 +272,7 @@ int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, in
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
-/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT: the transformed
+/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT / _F4_SPLIT2: the transformed
  * input, stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
 size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,

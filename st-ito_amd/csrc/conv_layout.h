@@ -88,7 +88,11 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
 bool wino43_split_supported(const ConvShape &c, bool pool);
 size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool);
 size_t wino43_split_packed_floats(int cout, int cin);
-int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, bool two_sweep, hipStream_t st);
+size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool);
+double wino43_split2_issued_flops(const ConvShape &c, bool pool);
+int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st);
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                         bool pool, void *ws, size_t ws_bytes, hipStream_t st);
 bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv

@@ -54,6 +54,9 @@ static constexpr int W43_XT = 68;                        // exchange: floats per
 static constexpr int S43_VPART = 8 * 2048;               // bytes: per slot [hi | lo][channel octet 0, 1][32 tiles][8 f16]
 static constexpr int S43_UPART = 8 * 4096;               // bytes: per slot [hi | lo][channel octet 0, 1][64 couts][8 f16]
 static constexpr int S43_SLAB = S43_VPART + S43_UPART;   // 48 KB, three of them in LDS
+// two-sweep kernel (k_conv_wino43s2): a slab = 6 positions (one row of the 6 x 6) x 16 input channels x (64 tiles | 64 couts)
+static constexpr int S43B_PART = 6 * 4096;               // bytes of the input half = bytes of the weight half of a slab
+static constexpr int S43B_SLAB = 2 * S43B_PART;          // 48 KB
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
     constexpr int PFL = PL::PFL;      // floats per patch buffer
     constexpr int BUF = W43_BUF;
-    constexpr bool PREV = MODE == 1, VOUT = MODE == 2 || MODE == 3, V16 = MODE == 3;
+    constexpr bool PREV = MODE == 1, VOUT = MODE >= 2, V16 = MODE == 3, V16B = MODE == 4;  // 3 / 4: f16 slabs of k_conv_wino43s / s2
     static_assert(!(FUSE1 && MODE != 0), "the fused first conv only exists for MODE 0");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -311,12 +314,12 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     // all of its (position, tile) items; the scale belongs to the tile's stream (`scale` carries the streams' maxima).
     const int v16_tile = tid & 31;
     float v16_s = 1.0f;
-    if constexpr (V16) {
+    if constexpr (V16 || V16B) {
         int vt_ = vtr0 + v16_tile / TTW, tr_;
         vt_ = vt_ < (int)g.VTR ? vt_ : (int)g.VTR - 1;
         v16_s = w43s_vscale(((const unsigned *)scale)[fdiv(vt_, g.fTR, tr_)]);
     }
-    const int n_slabs16 = (g.Cin >> 5) * 9;
+    const int n_slabs16 = V16B ? (g.Cin >> 4) * 3 : (g.Cin >> 5) * 9;
 
 #define W43_STAMP(SLOT)                                                                                 \
     if (TRACE && (blockIdx.x & 255) == 100 && (blockIdx.x >> 8) < 8 && lane == 0 && (wv & 3) == 0)      \
@@ -443,6 +446,34 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
                 char *d_ = vo_ + (int64_t)(e_ >> 1) * S43_VPART + (pg_ * 2 + (e_ & 1)) * 2048;           \
                 *(h4 *)d_ = hi_;                                                                         \
                 *(h4 *)(d_ + 1024) = lo_;                                                                \
+            }                                                                                            \
+        }                                                                                                \
+    }
+// V16B: the slab order of k_conv_wino43s2 (64-tile workgroups = pixel-block pairs, two sweeps over 18 positions each).
+// Position row i = p / 6 belongs to sweep i >= 3 ? 1 : 0 and is that sweep's local row [1, 2, 0][i] resp. i - 3 (so that rows
+// {1, 2} and {3, 4} -- the pairs whose contributions share sums and differences -- are local rows 0, 1); a slab holds one
+// local row x 16 channels: slab 3 (c / 16) + local row, position column j = p % 6 at 4 KB each:
+// [hi | lo][(c % 16) / 8][64 tiles][c % 8].
+#define W43_STORE_V16B(K_, CUR)                                                                          \
+    {                                                                                                    \
+        const int kc_ = c_base + (K_);                                                                   \
+        char *vo_ = (char *)out + ((int64_t)(m_blk >> 1) * 2 * n_slabs16 + 3 * (kc_ >> 2)) * S43B_PART +  \
+                    (((kc_ >> 1) & 1) * 64 + (m_blk & 1) * 32 + v16_tile) * 16 + (kc_ & 1) * 8;          \
+        const float *vs_ = smem + (CUR) + W43_U;                                                         \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+            const int p_ = (tid >> 5) + 16 * j;                                                          \
+            if (p_ < 36) {                                                                               \
+                const int i_ = p_ / 6, j_ = p_ - 6 * i_;                                                 \
+                const int sw_ = i_ >= 3, lr_ = sw_ ? i_ - 3 : (i_ == 0 ? 2 : i_ - 1);                    \
+                const f32x2 x01 = *(const f32x2 *)(vs_ + p_ * 128 + v16_tile * 2) * v16_s;               \
+                const f32x2 x23 = *(const f32x2 *)(vs_ + p_ * 128 + 64 + ((v16_tile + 16) & 31) * 2) * v16_s; \
+                h4 hi_, lo_;                                                                             \
+                hi_[0] = (_Float16)x01[0]; hi_[1] = (_Float16)x01[1]; hi_[2] = (_Float16)x23[0]; hi_[3] = (_Float16)x23[1]; \
+                lo_[0] = (_Float16)(x01[0] - (float)hi_[0]); lo_[1] = (_Float16)(x01[1] - (float)hi_[1]); \
+                lo_[2] = (_Float16)(x23[0] - (float)hi_[2]); lo_[3] = (_Float16)(x23[1] - (float)hi_[3]); \
+                char *d_ = vo_ + ((int64_t)sw_ * n_slabs16 + lr_) * S43B_PART + j_ * 4096;               \
+                *(h4 *)d_ = hi_;                                                                         \
+                *(h4 *)(d_ + 2048) = lo_;                                                                \
             }                                                                                            \
         }                                                                                                \
     }
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
         const float *sb = smem + cur;                                                                    \
         const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
-        if (V16) W43_STORE_V16(k, cur) else if (VOUT) W43_STORE_V(k, cur)                                \
+        if (V16) W43_STORE_V16(k, cur) else if (V16B) W43_STORE_V16B(k, cur) else if (VOUT) W43_STORE_V(k, cur) \
         if (!(FIRST)) {                                                                                  \
             W43_GAP(P2, 2, 0, 0, if (MORE_ && !(W43_ABL & 4)) { if (PREV) { W43_COPY_V1(k + 1, nxt, 0) } else if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) } else W43_COPY_P(k + 2, k & 1) }) \
             W43_GAP(P2, 2, 1, 0, W43_OPS(W43_LOAD_OPS(G0, sb, 0)) W43_UCP(W43_COPY_U1(k + 1, nxt, 0)))   \
@@ -802,6 +833,216 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
 }
 
+// ---- the same on 64 x 64 workgroup tiles, in two sweeps over the positions ----------------------------------------------
+// k_conv_wino43s is bound by what it copies into LDS (measured: L2 hits 41.5 B/clk/CU, L2 misses 11.3 B/clk/CU, and the two
+// add up: tools/ubench/split_mfma.hip), 4 bytes per operand element for 21.3 MACs on its 32-tile x 64-channel tile.  The tile
+// cannot grow while all 36 positions' accumulators have to sit in registers (36 x 32 x 64 floats = 288 of the CU's 512 KB).
+// Here a workgroup owns 64 tiles (two consecutive 32-tile pixel blocks) x 64 channels and goes over the input channels
+// twice: sweep 0 accumulates the position rows {1, 2, 0}, sweep 1 the rows {3, 4, 5} (18 x 64 x 64 floats each = the same
+// registers).  Y = A^T M A is linear in M, so each sweep's epilogue contributes its rows' part of the 4 x 4 outputs: sweep
+// 0 leaves it in a workgroup-private scratch area (f32, 256 KB, written and read back by the same threads), sweep 1 adds
+// its own and finishes (BN, ReLU, pool).  Per MAC the copies shrink by a third (32 MACs per 4 bytes), the misses with them.
+// Slab = one local row (6 positions) x 16 channels x (64 tiles | 64 couts) x (hi, lo) = 48 KB, ring of three, two wave sets
+// as in k_conv_wino43s; wave (th, nh, pp) = (tile half, channel half, position parity) owns the columns j = pp + 2 t of every
+// row: 3 blocks = 9 MFMAs per period, accumulator 3 * local row + t.  Six periods (32 channels) per loop trip.
+template <int TTW, bool POOL>
+__global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__restrict__ vsl, const char *__restrict__ usl,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                float *__restrict__ out, Wino43Geom g,
+                                                                const unsigned *__restrict__ amax, const float *__restrict__ u_inv_p,
+                                                                f32x4 *__restrict__ partial) {
+    constexpr int TTH = 32 / TTW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup order: as MODE 1, over pixel-block PAIRS (g.n_mblocks = number of pairs)
+    const int n_tiles = g.Cout / 64;
+    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    const int a = g.ct_group, n_ctg = n_tiles / a;
+    const int ct = (gi % n_ctg) * a + (r % a);
+    const int m_pair = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+    const int n0 = ct * 64;
+    if (m_pair >= g.n_mblocks) return;
+    const int n_slabs = (g.Cin >> 4) * 3;
+    const int set = wv >> 2, w4 = wv & 3, th = wv >> 2, nh = (wv >> 1) & 1, pp = wv & 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const int l31 = lane & 31, half = lane >> 5;
+    const char *a_rd = (const char *)smem + pp * 4096 + (half * 64 + th * 32 + l31) * 16;
+    const char *b_rd = (const char *)smem + S43B_PART + pp * 4096 + (half * 64 + nh * 32 + l31) * 16;
+    f32x4 *my_partial = partial + (int64_t)blockIdx.x * (2 * 16 * W43_THREADS) + tid;  // [tile half][r * 4 + c][thread]
+    const float u_inv = u_inv_p[0];
+
+    f32x16 acc[9];
+#define S43B_ISSUE(SL, BUF)                                                                              \
+    _Pragma("unroll") for (int c_ = 0; c_ < 12; ++c_) {                                                   \
+        const int piece_ = w4 * 12 + c_;                                                                  \
+        const char *src_ = piece_ < 24 ? vbase + (int64_t)(SL) * S43B_PART + piece_ * 1024                \
+                                       : ubase + (int64_t)(SL) * S43B_PART + (piece_ - 24) * 1024;        \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43B_SLAB + piece_ * 1024)); \
+    }
+#define S43B_BLOCK(T_, Q_)                                                                               \
+    {                                                                                                    \
+        const h8 ah_ = *(const h8 *)(pa_ + (T_) * 8192), al_ = *(const h8 *)(pa_ + (T_) * 8192 + 2048);   \
+        const h8 bh_ = *(const h8 *)(pb_ + (T_) * 8192), bl_ = *(const h8 *)(pb_ + (T_) * 8192 + 2048);   \
+        S43_MFMA(Q_, al_, bh_) S43_MFMA(Q_, ah_, bl_) S43_MFMA(Q_, ah_, bh_)                              \
+    }
+#define S43B_PERIOD(K6, SL)                                                                              \
+    {                                                                                                    \
+        constexpr int BUF_ = (K6) % 3, NB_ = ((K6) + 2) % 3, SUB_ = (K6) % 3;                             \
+        const bool mine_ = set == ((K6) & 1);                                                             \
+        if (mine_ && (SL) + 2 < n_slabs) { S43B_ISSUE((SL) + 2, NB_) }                                    \
+        const char *pa_ = a_rd + BUF_ * S43B_SLAB, *pb_ = b_rd + BUF_ * S43B_SLAB;                        \
+        S43B_BLOCK(0, 3 * SUB_) S43B_BLOCK(1, 3 * SUB_ + 1) S43B_BLOCK(2, 3 * SUB_ + 2)                   \
+        if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        W43_BARRIER()                                                                                     \
+    }
+
+    float *xch = smem;                      // [12 positions of the pass][32 tiles][W43_XT]
+    constexpr int XP = 32 * W43_XT;
+    const int e_quad = tid & 15, e_tile = tid >> 4;
+    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
+#define A4(a, b) __builtin_shufflevector(pk_add(P2(a, 0), P2(b, 0)), pk_add(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
+#define S4(a, b) __builtin_shufflevector(pk_sub(P2(a, 0), P2(b, 0)), pk_sub(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
+#define F4(c2, a, b) __builtin_shufflevector(pk_fma(c2, P2(a, 0), P2(b, 0)), pk_fma(c2, P2(a, 1), P2(b, 1)), 0, 1, 2, 3) /* c a + b */
+// exchange of the local rows R0 .. R0 + NR - 1 of tile half HB (written by the four waves with th == HB), then the column half
+// Z[ii][c] = sum_j M[row ii][j] A[j][c] in the reader thread (tile, channel quad)
+#define S43B_EXCHANGE(HB, R0, NR)                                                                        \
+    W43_BARRIER()                                                                                         \
+    if (th == (HB)) {                                                                                     \
+        _Pragma("unroll") for (int rr_ = 0; rr_ < (NR); ++rr_)                                            \
+            _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                            \
+                float *xp = xch + (rr_ * 6 + pp + 2 * t_) * XP + nh * 32 + l31;                           \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_)                                         \
+                    xp[((e_ & 3) + 8 * (e_ >> 2) + 4 * half) * W43_XT] = acc[3 * ((R0) + rr_) + t_][e_];  \
+            }                                                                                             \
+    }                                                                                                     \
+    W43_BARRIER()                                                                                         \
+    _Pragma("unroll") for (int ii = 0; ii < (NR); ++ii) {                                                 \
+        f32x4 m[6];                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) m[j] = *(const f32x4 *)(xch + (ii * 6 + j) * XP + e_tile * W43_XT + e_quad * 4); \
+        const f32x4 s12 = A4(m[1], m[2]), d12 = S4(m[1], m[2]), s34 = A4(m[3], m[4]), d34 = S4(m[3], m[4]); \
+        Z[ii][0] = A4(A4(m[0], s12), s34);                                                                \
+        Z[ii][1] = F4(k2, d34, d12);                                                                      \
+        Z[ii][2] = F4(k4, s34, s12);                                                                      \
+        Z[ii][3] = A4(F4(k8, d34, d12), m[5]);                                                            \
+    }
+
+#pragma unroll
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const char *vbase = vsl + ((int64_t)m_pair * 2 + sweep) * n_slabs * S43B_PART;
+        const char *ubase = usl + ((int64_t)ct * 2 + sweep) * n_slabs * S43B_PART;
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+        W43_BARRIER()  // (sweep 1: the epilogue's exchange reads are done before the ring is refilled)
+        if (set == 0) { S43B_ISSUE(0, 0) } else { S43B_ISSUE(1, 1) }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W43_BARRIER()
+        for (int sl = 0; sl < n_slabs; sl += 6) {  // Cin % 32 == 0
+            S43B_PERIOD(0, sl) S43B_PERIOD(1, sl + 1) S43B_PERIOD(2, sl + 2)
+            S43B_PERIOD(3, sl + 3) S43B_PERIOD(4, sl + 4) S43B_PERIOD(5, sl + 5)
+        }
+        // ---- this sweep's rows of Y = A^T M A, one tile half (= one 32-tile pixel block) at a time --------------------
+#pragma unroll 1
+        for (int hb = 0; hb < 2; ++hb) {
+            f32x4 Yo[4][4], Z[2][4];
+            f32x4 *pt = my_partial + hb * (16 * W43_THREADS);
+            if (sweep == 1) {  // sweep 0's contribution (issued ahead of the exchange that hides its latency)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Yo[e >> 2][e & 3] = pt[e * W43_THREADS];
+            }
+            S43B_EXCHANGE(hb, 0, 2)   // local rows 0, 1: position rows (1, 2) resp. (3, 4)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 sm = A4(Z[0][c], Z[1][c]), df = S4(Z[0][c], Z[1][c]);
+                if (sweep == 0) {  // A^T columns (1,1,1,1) and (1,-1,1,-1)
+                    Yo[0][c] = sm; Yo[1][c] = df; Yo[2][c] = sm; Yo[3][c] = df;
+                } else {           // (1,2,4,8) and (1,-2,4,-8)
+                    Yo[0][c] = A4(Yo[0][c], sm); Yo[1][c] = F4(k2, df, Yo[1][c]); Yo[2][c] = F4(k4, sm, Yo[2][c]); Yo[3][c] = F4(k8, df, Yo[3][c]);
+                }
+            }
+            S43B_EXCHANGE(hb, 2, 1)   // local row 2: position row 0 resp. 5: A^T column (1,0,0,0) resp. (0,0,0,1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (sweep == 0) Yo[0][c] = A4(Yo[0][c], Z[0][c]);
+                else Yo[3][c] = A4(Yo[3][c], Z[0][c]);
+            }
+            if (sweep == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pt[e * W43_THREADS] = Yo[e >> 2][e & 3];
+            } else {
+                // BN + ReLU (+ 2x2 average pool), 16-byte stores (4 channels) into NC8HW8; pixel block 2 m_pair + hb
+                const int m_blk = 2 * m_pair + hb;
+                int cb;
+                const int rb = fdiv(m_blk, g.fNCB, cb);
+                const int vtr = rb * TTH + e_tile / TTW, tc = cb * TTW + e_tile % TTW;
+                const int co = n0 + e_quad * 4;
+                f32x4 sc = *(const f32x4 *)(scale + co);
+                const f32x4 sh = *(const f32x4 *)(shift + co);
+                if (vtr < g.VTR && tc < g.TC) {
+                    int tr;
+                    const int s_ = fdiv(vtr, g.fTR, tr);
+                    sc = sc * (u_inv / w43s_vscale(amax[s_]));
+#pragma unroll
+                    for (int r_ = 0; r_ < 4; ++r_)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) Yo[r_][c] = __builtin_elementwise_max(Yo[r_][c] * sc + sh, (f32x4)(0.0f));
+                    if (POOL) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                            for (int pc = 0; pc < 2; ++pc) {
+                                const int oh = 2 * tr + pr, ow = 2 * tc + pc;
+                                if (oh < g.Ho && ow < g.Wo)
+                                    *(f32x4 *)(out + act_off(s_, co, oh, ow, g.Cout, g.Ho, g.Wo)) =
+                                        (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                            }
+                    } else {
+#pragma unroll
+                        for (int r_ = 0; r_ < 4; ++r_)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int hh = 4 * tr + r_, ww = 4 * tc + c;
+                                if (hh < g.H && ww < g.W) *(f32x4 *)(out + act_off(s_, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r_][c];
+                            }
+                    }
+                }
+            }
+        }
+    }
+#undef A4
+#undef S4
+#undef F4
+}
+
+// weights of k_conv_wino43s2: as k_pack_wino43s<1> in the slab order [cout / 64][sweep][slab = 3 (c / 16) + local row][column j]
+__global__ void k_pack_wino43s2(const float *__restrict__ w, int Cout, int Cin, char *__restrict__ o, const unsigned *__restrict__ hdr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double gk[3][3], t[6][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) gk[a][b] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + b];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * gk[0][b] + G[a][1] * gk[1][b] + G[a][2] * gk[2][b];
+    const int n_slabs = (Cin >> 4) * 3;
+    const int kg = ci >> 4, h = (ci >> 3) & 1, i8 = ci & 7;
+    const float su = __uint_as_float(hdr[2]);
+    for (int a = 0; a < 6; ++a) {
+        const int sw = a >= 3, lr = sw ? a - 3 : (a == 0 ? 2 : a - 1);
+        for (int b = 0; b < 6; ++b) {
+            const float us = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]) * su;
+            const _Float16 hi = (_Float16)us, lo = (_Float16)(us - (float)hi);
+            char *d = o + (((int64_t)(co >> 6) * 2 + sw) * n_slabs + 3 * kg + lr) * S43B_PART + b * 4096 + (h * 64 + (co & 63)) * 16 + i8 * 2;
+            *(_Float16 *)d = hi;
+            *(_Float16 *)(d + 2048) = lo;
+        }
+    }
+}
+
 // Largest activation of every stream (>= 0 after ReLU; the sign bit is dropped anyway) as a bit pattern: amax[s] is zeroed
 // by the launcher, one atomicMax per wave.  grid (splits, S).
 __global__ __launch_bounds__(256) void k_stream_absmax(const float *__restrict__ x, int64_t per_stream, unsigned *__restrict__ amax) {
@@ -868,7 +1109,7 @@ __global__ void k_pack_wino43s_scale(unsigned *hdr) {
 
 size_t wino43_split_packed_floats(int cout, int cin) { return (size_t)36 * cout * cin + 64; }
 
-int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st) {
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, bool two_sweep, hipStream_t st) {
     STITO_REQUIRE(cin % 64 == 0 && cout % 64 == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
     const int64_t n = (int64_t)cout * cin;
     unsigned *hdr = (unsigned *)(packed + (size_t)36 * cout * cin);
@@ -877,7 +1118,8 @@ int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, hip
     STITO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_wino43s_scale, dim3(1), dim3(1), 0, st, hdr);
     STITO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pack_wino43s<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
+    if (two_sweep) hipLaunchKernelGGL(k_pack_wino43s2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
+    else hipLaunchKernelGGL(k_pack_wino43s<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
@@ -1156,6 +1398,117 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
                        (const unsigned *)amax, u_inv);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
+}
+
+// Two-sweep variant: workspace = V slabs of the pixel-block pairs | stream maxima | per-workgroup partial outputs (256 KB each).
+template <int TTW>
+static int64_t w43_split2_grid(const ConvShape &c, bool pool, int64_t &m_pairs, int &ct_group) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    if (!w43_geometry<TTW>(c, pool, g, lds, blocks)) return 0;
+    const int64_t m_blocks = blocks / (c.Cout / 64);
+    m_pairs = (m_blocks + 1) / 2;
+    const int n_tiles = c.Cout / 64;
+    int a = n_tiles >= 16 ? 8 : 4;
+    if (const char *e = getenv("STITO_W43S_CTG")) a = atoi(e);
+    if (a < 1 || a > 32 || (a & (a - 1)) != 0 || n_tiles % a != 0) return 0;
+    ct_group = a;
+    const int bm = 32 / a;
+    const int64_t m_groups = ((m_pairs + 7) / 8 + bm - 1) / bm;
+    return 8 * m_groups * (n_tiles / a) * 32;
+}
+
+static int64_t w43_split2_grid_any(const ConvShape &c, bool pool, int64_t &m_pairs, int &ct_group) {
+    switch (w43_ttw(c, pool)) {
+        case 8: return w43_split2_grid<8>(c, pool, m_pairs, ct_group);
+        case 4: return w43_split2_grid<4>(c, pool, m_pairs, ct_group);
+        case 2: return w43_split2_grid<2>(c, pool, m_pairs, ct_group);
+        default: return w43_split2_grid<1>(c, pool, m_pairs, ct_group);
+    }
+}
+
+// f16-pipe FLOPs the two-sweep kernel issues: pixel-block pairs (a padded half included) x channel tiles x 64 x 64 x 36 x cin x 3 products
+double wino43_split2_issued_flops(const ConvShape &c, bool pool) {
+    if (!wino43_split_supported(c, pool)) return 0.0;
+    int64_t m_pairs = 0;
+    int a;
+    if (w43_split2_grid_any(c, pool, m_pairs, a) <= 0) return 0.0;
+    return 3.0 * 2.0 * (double)m_pairs * (c.Cout / 64) * 64.0 * 64.0 * 36.0 * c.Cin;
+}
+
+size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool) {
+    if (!wino43_split_supported(c, pool)) return 0;
+    int64_t m_pairs = 0;
+    int a;
+    const int64_t grid = w43_split2_grid_any(c, pool, m_pairs, a);
+    if (grid <= 0 || grid >= (1ll << 31)) return 0;
+    return align_up((size_t)m_pairs * 2 * (size_t)(c.Cin / 16) * 3 * S43B_PART, 256) + align_up((size_t)c.S * sizeof(unsigned), 256) +
+           (size_t)grid * 2 * 16 * W43_THREADS * sizeof(f32x4);
+}
+
+template <int TTW, bool POOL>
+static int launch_w43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                             char *ws, hipStream_t st) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
+    int64_t m_pairs = 0;
+    int a = 4;
+    const int64_t grid = w43_split2_grid<TTW>(c, POOL, m_pairs, a);
+    STITO_REQUIRE(grid > 0 && grid < (1ll << 31), STITO_E_UNSUPPORTED, "conv (two-sweep split-precision winograd): grid / cout %d", c.Cout);
+    const size_t vbytes = align_up((size_t)m_pairs * 2 * (size_t)(c.Cin / 16) * 3 * S43B_PART, 256);
+    unsigned *amax = (unsigned *)(ws + vbytes);
+    f32x4 *partial = (f32x4 *)(ws + vbytes + align_up((size_t)c.S * sizeof(unsigned), 256));
+    {   // stream maxima
+        STITO_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)c.S * sizeof(unsigned), st));
+        const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
+        int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
+        const int cap = (4096 + c.S - 1) / c.S;
+        splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
+        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax);
+        STITO_LAUNCH_CHECK();
+    }
+    {   // V slabs (MODE 4) of 2 * m_pairs pixel blocks (a block past the map transforms to zeros)
+        Wino43Geom gv = g;
+        const int n_chunks = c.Cin / W43_K;
+        const int64_t m_blocks2 = 2 * m_pairs;
+        int ncg = 1;
+        while (m_blocks2 * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
+        gv.n_cgroups = ncg;
+        auto kern = k_conv_wino43<TTW, POOL, false, false, 4>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks2 * ncg)), dim3(W43_THREADS), lds, st, in, (const float *)nullptr,
+                           (const float *)amax, (const float *)nullptr, (float *)ws, gv);
+        STITO_LAUNCH_CHECK();
+    }
+    auto kern = k_conv_wino43s2<TTW, POOL>;
+    const size_t lds1 = (size_t)3 * S43B_SLAB;
+    static_assert((size_t)12 * 32 * W43_XT * sizeof(float) <= (size_t)3 * S43B_SLAB, "epilogue exchange fits the slab ring");
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    g.n_mblocks = (int)m_pairs;
+    g.ct_group = a;
+    const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                       (const unsigned *)amax, u_inv, partial);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = wino43_split2_workspace_bytes(c, pool);
+    STITO_REQUIRE(need > 0 && ws != nullptr && ws_bytes >= need, STITO_E_WORKSPACE,
+                  "conv (two-sweep split-precision winograd F(4x4,3x3)): workspace have %zu need %zu", ws_bytes, need);
+    char *w = (char *)ws;
+    switch (w43_ttw(c, pool)) {
+        case 8: return pool ? launch_w43_split2<8, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<8, false>(in, upk, scale, shift, out, c, w, st);
+        case 4: return pool ? launch_w43_split2<4, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<4, false>(in, upk, scale, shift, out, c, w, st);
+        case 2: return pool ? launch_w43_split2<2, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<2, false>(in, upk, scale, shift, out, c, w, st);
+        default: return pool ? launch_w43_split2<1, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<1, false>(in, upk, scale, shift, out, c, w, st);
+    }
 }
 
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,

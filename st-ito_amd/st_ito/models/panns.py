@@ -129,6 +129,10 @@ class Cnn14(nn.Module):
         # from 256 output channels up (measured at 512 streams: 128 -> 256 channels 4.0 -> 3.6 ms, 256 -> 256 6.4 -> 5.7 ms; below,
         # the transformed input's round trip through HBM costs more than the matrix pipe saves)
         self.conv_split_min_cout = int(os.environ.get("STITO_CONV_SPLIT_MIN_COUT", "256"))
+        # ... on 64 x 64 workgroup tiles in two sweeps (CONV_WINOGRAD_F4_SPLIT2) from this many INPUT channels up: its longer
+        # epilogue (two sweeps, the first one's outputs parked in HBM) is repaid by a third fewer bytes per MAC only when the
+        # channel loop is long (measured at 512 streams: 512 -> 512 4.45 -> 4.20 ms, 2048 -> 2048 4.05 -> 3.05; 256 -> 512 2.51 -> 2.66)
+        self.conv_split2_min_cin = int(os.environ.get("STITO_CONV_SPLIT2_MIN_CIN", "512"))
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -177,6 +181,8 @@ class Cnn14(nn.Module):
                     split = (self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and 0 < self.conv_split_min_cout <= cout and
                              cin % 64 == 0 and cout % 256 == 0 and (cout < 1024 or cout % 512 == 0))
                     algo = _hip.CONV_WINOGRAD_F4_SPLIT if split else (_hip.CONV_WINOGRAD_F4_PRE if pre else self.conv_algo)
+                    if split and 0 < self.conv_split2_min_cin <= cin:
+                        algo = _hip.CONV_WINOGRAD_F4_SPLIT2
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)
                     _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()

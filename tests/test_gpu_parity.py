@@ -325,7 +325,7 @@ CONV_CASES = [  # (n, H, W, cin, cout, pool)
 ]
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
 def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     from st_ito import _hip
@@ -357,7 +357,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
     sd, hd = scale.to(dev), shift.to(dev)
     wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, algo)
-    assert (wsb > 0) == (algo in (3, 4))
+    assert (wsb > 0) == (algo in (3, 4, 5))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
                                           n, H, W, cin, cout, pool, algo, _hip.ptr(ws), wsb, st))
@@ -372,17 +372,18 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
                                        n, H, W, cin, cout, pool, 3, st) == _hip.E_WORKSPACE  # no workspace, no launch
     err = (got - ref).abs().max().item()
     print(f"conv algo {algo} {n}x{H}x{W} {cin}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
-    if algo == 4:
+    if algo in (4, 5):
         assert L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
-                                       n, H, W, cin, cout, pool, 4, st) == _hip.E_WORKSPACE  # no workspace, no launch
+                                       n, H, W, cin, cout, pool, algo, st) == _hip.E_WORKSPACE  # no workspace, no launch
     # F(4x4,3x3): random SIGNED inputs are the worst case for the cancellation in its output transform (3.3e-5 of the
     # maximum at cin = 2048); on real trunk activations it is as accurate as the direct kernel (tools/trunk_accuracy.py)
     tol = 5e-5 if algo >= 2 else 2e-5
     assert err < tol * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
 
 
+@pytest.mark.parametrize("algo", [4, 5])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", [(6, 14, 4, 512, 512, 0), (5, 29, 8, 256, 512, 1), (9, 58, 16, 64, 256, 0)])
-def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool):
+def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
     """STITO_CONV_WINOGRAD_F4_SPLIT carries every operand as f16 hi + lo of a power-of-two multiple of itself; the
     multiple is chosen per stream from the stream's own largest activation.  Streams 1e4 and 1e-4 times the others, an
     all-zero stream and a stream with one huge outlier sit in ONE launch (several streams per workgroup tile on these
@@ -390,7 +391,7 @@ def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool):
     overflow, no loss on the quiet streams), and bitwise independent of what else is in the batch."""
     from st_ito import _hip
     L = _hip.lib()
-    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, 4)
+    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)
     g = torch.Generator().manual_seed(H * 7 + cin)
     x = torch.relu(torch.randn((n, cin, H, W), generator=g))
     x[1] *= 1e4
@@ -408,17 +409,17 @@ def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool):
         return t.reshape(n_, C_ // 8, 8, H_, W_).permute(0, 1, 3, 4, 2).contiguous()
     st = _hip.stream_ptr()
     wd, sd, hd = w.contiguous().to(dev), scale.to(dev), shift.to(dev)
-    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, 4), device=dev)
-    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, 4, _hip.ptr(packed), st))
+    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, algo, _hip.ptr(packed), st))
 
     def run(xs):
         k = xs.shape[0]
         xd = blocked(xs).to(dev)
         out = torch.full((k, cout // 8) + tuple(ref.shape[2:]) + (8,), float("nan"), device=dev, dtype=torch.float32)
-        wsb = L.stito_conv3x3_workspace_bytes(k, H, W, cin, cout, pool, 4)
+        wsb = L.stito_conv3x3_workspace_bytes(k, H, W, cin, cout, pool, algo)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
-                                              k, H, W, cin, cout, pool, 4, _hip.ptr(ws), wsb, st))
+                                              k, H, W, cin, cout, pool, algo, _hip.ptr(ws), wsb, st))
         return out.cpu()
     got = run(x)
     refb = blocked(ref)
@@ -546,7 +547,7 @@ def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
         W, _, _ = pm._ensure()
         algos = [int(W.conv_wino_algo[i]) for i in range(12)]
         if pre == "split":
-            assert algos[1:4] == [_hip.CONV_WINOGRAD_F4] * 3 and algos[4:] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 8
+            assert algos[1:4] == [_hip.CONV_WINOGRAD_F4] * 3 and algos[4:7] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 3 and algos[7:] == [_hip.CONV_WINOGRAD_F4_SPLIT2] * 5
         else:
             assert algos[1:6] == [_hip.CONV_WINOGRAD_F4] * 5
             assert algos[6:] == [_hip.CONV_WINOGRAD_F4_PRE if pre else _hip.CONV_WINOGRAD_F4] * 6
