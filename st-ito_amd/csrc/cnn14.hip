@@ -1162,11 +1162,18 @@ extern "C" size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, in
     return wino43_pre_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
 }
 
-extern "C" int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
-                                        const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
-                                        int pool, int algo, void *workspace_dev, size_t workspace_bytes, void *stream) {
-    if (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2)
+// amax_in / amax_out: see conv_layout.h (per-stream output maxima handed from one layer to the next inside the trunk)
+static int conv3x3_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev, const float *shift_dev, float *out_dev,
+                      int n, int H, int W, int cin, int cout, int pool, int algo, void *workspace_dev, size_t workspace_bytes,
+                      void *stream, const unsigned *amax_in, unsigned *amax_out) {
+    if (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2) {
+        if (algo == STITO_CONV_WINOGRAD_F4 && amax_out != nullptr && n > 0 && H > 0 && W > 0 && cin % 8 == 0 && cout % 64 == 0 &&
+            wino_ok(cout, cin) && (!pool || (H >= 2 && W >= 2)))
+            return launch_wino43(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0, g_wino_trace,
+                                 (hipStream_t)stream, amax_out);
+        STITO_REQUIRE(amax_out == nullptr, STITO_E_INVALID, "conv: this algorithm does not report output maxima");
         return stito_conv3x3_bn_relu(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cin, cout, pool, algo, stream);
+    }
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2) {
         STITO_REQUIRE(stito_conv3x3_supported(n, H, W, cin, cout, pool, algo), STITO_E_UNSUPPORTED,
@@ -1174,16 +1181,23 @@ extern "C" int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed
         STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
         if (algo == STITO_CONV_WINOGRAD_F4_SPLIT2)
             return launch_wino43_split2(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
-                                        workspace_dev, workspace_bytes, (hipStream_t)stream);
+                                        workspace_dev, workspace_bytes, (hipStream_t)stream, amax_in, amax_out);
         return launch_wino43_split(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
-                                   workspace_dev, workspace_bytes, (hipStream_t)stream);
+                                   workspace_dev, workspace_bytes, (hipStream_t)stream, amax_in, amax_out);
     }
     STITO_REQUIRE(cin % 8 == 0 && cout % 64 == 0 && wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
     STITO_REQUIRE(stito_conv3x3_supported(n, H, W, cin, cout, pool, algo), STITO_E_UNSUPPORTED,
                   "conv (winograd F(4x4,3x3), hoisted input transform): %dx%d map, %d -> %d channels not covered (cout must be a multiple of 256)", H, W, cin, cout);
     STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
     return launch_wino43_pre(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
-                             (float *)workspace_dev, workspace_bytes, (hipStream_t)stream);
+                             (float *)workspace_dev, workspace_bytes, (hipStream_t)stream, amax_out);
+}
+
+extern "C" int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
+                                        const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
+                                        int pool, int algo, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    return conv3x3_ws(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cin, cout, pool, algo, workspace_dev, workspace_bytes,
+                      stream, nullptr, nullptr);
 }
 
 static void cnn14_dims(int64_t T, int M, int H[7], int W[7]) {
@@ -1217,7 +1231,8 @@ extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int 
         b = pooled > b ? pooled : b;
     }
     const size_t feat = (size_t)n_streams * w->channels[6];
-    return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + cnn14_pre_bytes(w, n_streams, H, W) + 256;
+    return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + cnn14_pre_bytes(w, n_streams, H, W) +
+           2 * align_up((size_t)n_streams * sizeof(unsigned), 256) + 256;  // + two per-stream output-maximum buffers (split-precision layers)
 }
 
 // ---- optional launch timing for bench.py: HIP events on the launch stream around the MFMA convs ----
@@ -1289,6 +1304,10 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     float *feat = (float *)(ws + align_up(a * 4, 256) + align_up(b * 4, 256));
     const size_t vbytes = cnn14_pre_bytes(w, S, H, W);
     void *vbuf = ws + align_up(a * 4, 256) + align_up(b * 4, 256) + align_up((size_t)S * w->channels[6] * 4, 256);
+    // per-stream output maxima, handed from a layer to the split-precision layer behind it (two buffers, alternating)
+    unsigned *amax_buf[2] = {(unsigned *)((char *)vbuf + vbytes), (unsigned *)((char *)vbuf + vbytes + align_up((size_t)S * sizeof(unsigned), 256))};
+    const unsigned *amax_have = nullptr;  // maxima of the current input, if its producer reported them
+    int amax_next = 0;
 
     const float *cur = logmel_dev;
     // conv_block1 as one launch when the fused first-conv weights and an F(4x4,3x3) packing of its second conv are there
@@ -1335,10 +1354,26 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                 }
                 STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
             }
-            const int rc = stito_conv3x3_bn_relu_ws(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
-                                                    w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
-                                                    wino ? walgo : STITO_CONV_DIRECT, vbuf, vbytes, stream);
+            const int algo_i = wino ? walgo : STITO_CONV_DIRECT;
+            // does the next conv run a split-precision kernel (it scales its transformed input by this layer's per-stream maxima)
+            // and can this layer's kernel report them?
+            unsigned *amax_out = nullptr;
+            if (i + 1 < STITO_CNN14_NUM_CONVS && algo_i >= STITO_CONV_WINOGRAD_F4) {
+                const int nb = (i + 1) / 2, nj = (i + 1) % 2;
+                const int nci = nj == 0 ? w->channels[nb] : w->channels[nb + 1], npool = (nj == 1 && nb < 5) ? 1 : 0;
+                const int nalgo = w->conv_wino_algo[i + 1];
+                if (w->conv_wino_dev[i + 1] != nullptr && (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2) &&
+                    stito_conv3x3_supported(S, H[nb], W[nb], nci, w->channels[nb + 1], npool, nalgo)) {
+                    amax_out = amax_buf[amax_next];
+                    STITO_HIP_CHECK(hipMemsetAsync(amax_out, 0, (size_t)S * sizeof(unsigned), st));
+                }
+            }
+            const int rc = conv3x3_ws(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
+                                      w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
+                                      algo_i, vbuf, vbytes, stream, amax_have, amax_out);
             if (rc) return rc;
+            amax_have = amax_out;
+            if (amax_out != nullptr) amax_next ^= 1;
             if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
         }
         cur = actB;

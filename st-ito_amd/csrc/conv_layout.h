@@ -78,12 +78,14 @@ __device__ __forceinline__ int fdiv(int a, const FDiv f, int &rem) {
 // conv_wino43.hip
 bool wino43_supported(const ConvShape &c, bool pool);
 double wino43_issued_flops(const ConvShape &c, bool pool);
+// amax_out (or NULL): per stream, the layer's largest output as a bit pattern (atomicMax into a buffer the caller zeroed);
+// amax_in (or NULL): the same of the layer that produced `in` -- without it the split-precision launchers scan `in` themselves
 int launch_wino43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                  bool pool, long long *trace, hipStream_t st);
+                  bool pool, long long *trace, hipStream_t st, unsigned *amax_out = nullptr);
 int pack_wino43(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
 size_t wino43_pre_workspace_bytes(const ConvShape &c, bool pool);  // hoisted input transform: bytes of V slabs (0: unsupported)
 int launch_wino43_pre(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                      bool pool, float *vbuf, size_t vbuf_bytes, hipStream_t st);
+                      bool pool, float *vbuf, size_t vbuf_bytes, hipStream_t st, unsigned *amax_out = nullptr);
 // split-precision streaming kernel (f16 hi + lo operands, f32 accumulate)
 bool wino43_split_supported(const ConvShape &c, bool pool);
 size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool);
@@ -92,9 +94,9 @@ int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, boo
 size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool);
 double wino43_split2_issued_flops(const ConvShape &c, bool pool);
 int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                         bool pool, void *ws, size_t ws_bytes, hipStream_t st);
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                        bool pool, void *ws, size_t ws_bytes, hipStream_t st);
+                        bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv
 int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st);
 int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,

@@ -72,6 +72,8 @@ struct Wino43Geom {
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
     FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
+    unsigned *amax_out;  // or NULL: per stream, the largest output of this layer as a bit pattern (atomicMax; zeroed by the caller):
+                         // what the split-precision kernels scale the NEXT layer's transformed input by (w43s_vscale)
     // FUSE1 instantiation (conv_block1: the Cin = 1 first conv computed on the fly while staging the patch):
     const float *fw;   // first-conv weights, BN scale folded, packed [16 chunks][9 taps][4 channels]
     const float *fsh;  // first-conv BN shifts (64)
@@ -146,6 +148,23 @@ __host__ __device__ __forceinline__ float w43s_vscale(unsigned amax_bits) {
     if (amax_bits == 0u) e = 8;                       // all-zero stream: scale 1
     e = e < -40 ? -40 : (e > 60 ? 60 : e);            // (a denormal maximum or an inf / nan bit pattern: stay finite)
     return __builtin_ldexpf(1.0f, 8 - e);
+}
+
+// Largest of the thread's stored outputs (>= 0 after ReLU: the bit patterns order like the values), reduced over the 16
+// lanes that share a tile (one DPP row: lanes differ in the channel quad), one atomicMax per tile into amax_out[stream].
+__device__ __forceinline__ void w43_amax_out(unsigned *amax_out, int s, unsigned m) {
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, true));  // row_ror:8
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, true));  // row_ror:4
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, true));  // row_ror:2
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, true));  // row_ror:1
+    // amax_out[s] only grows: a (possibly stale) load that already covers m makes the atomic unnecessary -- after a
+    // stream's first few tiles nearly all of them (measured: 30 000 workgroups x 32 atomics onto 512 words cost a 6.5 ms layer
+    // 3.7 ms before this check)
+    // (agent-scope load = sc1: served by L2, where the atomics land; a plain load would keep hitting the CU's own L1 line)
+    if ((threadIdx.x & 15) == 0 && m > __hip_atomic_load(amax_out + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out + s, m);
+}
+__device__ __forceinline__ unsigned w43_max4(f32x4 v) {
+    return max(max(__float_as_uint(v[0]), __float_as_uint(v[1])), max(__float_as_uint(v[2]), __float_as_uint(v[3])));
 }
 
 // ---- epilogue (shared by k_conv_wino43 and k_conv_wino43s) ---------------------------------------------------------
@@ -226,6 +245,8 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
         const f32x4 sh = *(const f32x4 *)(shift + co);
         const int vtr = vtr0 + e_tile / TTW;
         const int tc = tc0 + e_tile % TTW;
+        unsigned smax = 0;
+        int sidx = 0;
         if (vtr < g.VTR && tc < g.TC) {
             int tr;
             const int s = fdiv(vtr, g.fTR, tr);
@@ -234,15 +255,18 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) Yo[r][c] = __builtin_elementwise_max(Yo[r][c] * sc + sh, (f32x4)(0.0f));
+            unsigned mx = 0;
             if (POOL) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
                     for (int pc = 0; pc < 2; ++pc) {
                         const int oh = 2 * tr + pr, ow = 2 * tc + pc;
-                        if (oh < g.Ho && ow < g.Wo)
-                            *(f32x4 *)(out + act_off(s, co, oh, ow, g.Cout, g.Ho, g.Wo)) =
-                                (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                        if (oh < g.Ho && ow < g.Wo) {
+                            const f32x4 v = (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                            *(f32x4 *)(out + act_off(s, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
+                            mx = max(mx, w43_max4(v));
+                        }
                     }
             } else {
 #pragma unroll
@@ -250,10 +274,17 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int hh = 4 * tr + r, ww = 4 * tc + c;
-                        if (hh < g.H && ww < g.W) *(f32x4 *)(out + act_off(s, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r][c];
+                        if (hh < g.H && ww < g.W) {
+                            *(f32x4 *)(out + act_off(s, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r][c];
+                            mx = max(mx, w43_max4(Yo[r][c]));
+                        }
                     }
             }
+            smax = mx;
+            sidx = s;
         }
+        // (outside the branch: the DPP reduction reads all 16 lanes of the tile's row; a tile is valid or not as a whole)
+        if (g.amax_out != nullptr) w43_amax_out(g.amax_out, sidx, smax);
     }
 }
 
@@ -980,9 +1011,12 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
                 const int co = n0 + e_quad * 4;
                 f32x4 sc = *(const f32x4 *)(scale + co);
                 const f32x4 sh = *(const f32x4 *)(shift + co);
+                unsigned smax = 0;
+                int sidx = 0;
                 if (vtr < g.VTR && tc < g.TC) {
                     int tr;
                     const int s_ = fdiv(vtr, g.fTR, tr);
+                    sidx = s_;
                     sc = sc * (u_inv / w43s_vscale(amax[s_]));
 #pragma unroll
                     for (int r_ = 0; r_ < 4; ++r_)
@@ -994,9 +1028,11 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 #pragma unroll
                             for (int pc = 0; pc < 2; ++pc) {
                                 const int oh = 2 * tr + pr, ow = 2 * tc + pc;
-                                if (oh < g.Ho && ow < g.Wo)
-                                    *(f32x4 *)(out + act_off(s_, co, oh, ow, g.Cout, g.Ho, g.Wo)) =
-                                        (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                                if (oh < g.Ho && ow < g.Wo) {
+                                    const f32x4 v = (((Yo[2 * pr][2 * pc] + Yo[2 * pr][2 * pc + 1]) + Yo[2 * pr + 1][2 * pc]) + Yo[2 * pr + 1][2 * pc + 1]) * 0.25f;
+                                    *(f32x4 *)(out + act_off(s_, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
+                                    smax = max(smax, w43_max4(v));
+                                }
                             }
                     } else {
 #pragma unroll
@@ -1004,10 +1040,14 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const int hh = 4 * tr + r_, ww = 4 * tc + c;
-                                if (hh < g.H && ww < g.W) *(f32x4 *)(out + act_off(s_, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r_][c];
+                                if (hh < g.H && ww < g.W) {
+                                    *(f32x4 *)(out + act_off(s_, co, hh, ww, g.Cout, g.H, g.W)) = Yo[r_][c];
+                                    smax = max(smax, w43_max4(Yo[r_][c]));
+                                }
                             }
                     }
                 }
+                if (g.amax_out != nullptr) w43_amax_out(g.amax_out, sidx, smax);
             }
         }
     }
@@ -1238,13 +1278,14 @@ int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, 
 
 template <int TTW, bool POOL>
 static int launch_w43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                      long long *trace, hipStream_t st) {
+                      long long *trace, hipStream_t st, unsigned *amax_out) {
     Wino43Geom g;
     size_t lds;
     int64_t blocks;
     STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     g.trace = trace;
+    g.amax_out = amax_out;
     auto kern = trace ? k_conv_wino43<TTW, POOL, true> : k_conv_wino43<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g);
@@ -1253,12 +1294,12 @@ static int launch_w43(const float *in, const float *upk, const float *scale, con
 }
 
 int launch_wino43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                  bool pool, long long *trace, hipStream_t st) {
+                  bool pool, long long *trace, hipStream_t st, unsigned *amax_out) {
     switch (w43_ttw(c, pool)) {
-        case 8: return pool ? launch_w43<8, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<8, false>(in, upk, scale, shift, out, c, trace, st);
-        case 4: return pool ? launch_w43<4, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<4, false>(in, upk, scale, shift, out, c, trace, st);
-        case 2: return pool ? launch_w43<2, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<2, false>(in, upk, scale, shift, out, c, trace, st);
-        default: return pool ? launch_w43<1, true>(in, upk, scale, shift, out, c, trace, st) : launch_w43<1, false>(in, upk, scale, shift, out, c, trace, st);
+        case 8: return pool ? launch_w43<8, true>(in, upk, scale, shift, out, c, trace, st, amax_out) : launch_w43<8, false>(in, upk, scale, shift, out, c, trace, st, amax_out);
+        case 4: return pool ? launch_w43<4, true>(in, upk, scale, shift, out, c, trace, st, amax_out) : launch_w43<4, false>(in, upk, scale, shift, out, c, trace, st, amax_out);
+        case 2: return pool ? launch_w43<2, true>(in, upk, scale, shift, out, c, trace, st, amax_out) : launch_w43<2, false>(in, upk, scale, shift, out, c, trace, st, amax_out);
+        default: return pool ? launch_w43<1, true>(in, upk, scale, shift, out, c, trace, st, amax_out) : launch_w43<1, false>(in, upk, scale, shift, out, c, trace, st, amax_out);
     }
 }
 
@@ -1284,7 +1325,7 @@ size_t wino43_pre_workspace_bytes(const ConvShape &c, bool pool) {
 
 template <int TTW, bool POOL>
 static int launch_w43_pre(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                          float *vbuf, hipStream_t st) {
+                          float *vbuf, hipStream_t st, unsigned *amax_out) {
     Wino43Geom g;
     size_t lds;
     int64_t blocks;
@@ -1315,6 +1356,7 @@ static int launch_w43_pre(const float *in, const float *upk, const float *scale,
     const int a = n_tiles >= 16 ? 8 : 4;
     STITO_REQUIRE(n_tiles % a == 0, STITO_E_UNSUPPORTED, "conv (hoisted input transform): cout %d", c.Cout);
     g.ct_group = a;
+    g.amax_out = amax_out;
     const int bm = 32 / a;
     const int64_t m_groups = ((m_blocks + 7) / 8 + bm - 1) / bm;
     blocks = 8 * m_groups * (n_tiles / a) * 32;
@@ -1325,15 +1367,15 @@ static int launch_w43_pre(const float *in, const float *upk, const float *scale,
 }
 
 int launch_wino43_pre(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                      bool pool, float *vbuf, size_t vbuf_bytes, hipStream_t st) {
+                      bool pool, float *vbuf, size_t vbuf_bytes, hipStream_t st, unsigned *amax_out) {
     const size_t need = wino43_pre_workspace_bytes(c, pool);
     STITO_REQUIRE(need > 0 && vbuf != nullptr && vbuf_bytes >= need, STITO_E_WORKSPACE,
                   "conv (winograd F(4x4,3x3), hoisted input transform): workspace have %zu need %zu", vbuf_bytes, need);
     switch (w43_ttw(c, pool)) {
-        case 8: return pool ? launch_w43_pre<8, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<8, false>(in, upk, scale, shift, out, c, vbuf, st);
-        case 4: return pool ? launch_w43_pre<4, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<4, false>(in, upk, scale, shift, out, c, vbuf, st);
-        case 2: return pool ? launch_w43_pre<2, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<2, false>(in, upk, scale, shift, out, c, vbuf, st);
-        default: return pool ? launch_w43_pre<1, true>(in, upk, scale, shift, out, c, vbuf, st) : launch_w43_pre<1, false>(in, upk, scale, shift, out, c, vbuf, st);
+        case 8: return pool ? launch_w43_pre<8, true>(in, upk, scale, shift, out, c, vbuf, st, amax_out) : launch_w43_pre<8, false>(in, upk, scale, shift, out, c, vbuf, st, amax_out);
+        case 4: return pool ? launch_w43_pre<4, true>(in, upk, scale, shift, out, c, vbuf, st, amax_out) : launch_w43_pre<4, false>(in, upk, scale, shift, out, c, vbuf, st, amax_out);
+        case 2: return pool ? launch_w43_pre<2, true>(in, upk, scale, shift, out, c, vbuf, st, amax_out) : launch_w43_pre<2, false>(in, upk, scale, shift, out, c, vbuf, st, amax_out);
+        default: return pool ? launch_w43_pre<1, true>(in, upk, scale, shift, out, c, vbuf, st, amax_out) : launch_w43_pre<1, false>(in, upk, scale, shift, out, c, vbuf, st, amax_out);
     }
 }
 
@@ -1350,21 +1392,23 @@ size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool) {
 
 template <int TTW, bool POOL>
 static int launch_w43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                            char *ws, hipStream_t st) {
+                            char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
     Wino43Geom g;
     size_t lds;
     int64_t blocks;
     STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     const int64_t m_blocks = blocks / (c.Cout / 64);
-    unsigned *amax = (unsigned *)(ws + align_up((size_t)m_blocks * (c.Cin / W43_K) * W43_V * sizeof(float), 256));
-    {   // stream maxima
-        STITO_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)c.S * sizeof(unsigned), st));
+    const unsigned *amax = amax_in;
+    if (amax_in == nullptr) {   // stream maxima (not supplied by the layer that produced `in`)
+        unsigned *amax_ws = (unsigned *)(ws + align_up((size_t)m_blocks * (c.Cin / W43_K) * W43_V * sizeof(float), 256));
+        amax = amax_ws;
+        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
         const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
         int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));  // >= 16 float4 per thread
         const int cap = (4096 + c.S - 1) / c.S;                            // ~16 workgroups per CU in total
         splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
-        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax);
+        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax_ws);
         STITO_LAUNCH_CHECK();
     }
     {   // V slabs (MODE 3): grid as MODE 2
@@ -1393,6 +1437,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     const int64_t m_groups = ((m_blocks + 7) / 8 + bm - 1) / bm;
     blocks = 8 * m_groups * (n_tiles / a) * 32;
     STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv (split-precision winograd): grid");
+    g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
                        (const unsigned *)amax, u_inv);
@@ -1449,7 +1494,7 @@ size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool) {
 
 template <int TTW, bool POOL>
 static int launch_w43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                             char *ws, hipStream_t st) {
+                             char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
     Wino43Geom g;
     size_t lds;
     int64_t blocks;
@@ -1460,15 +1505,16 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
     const int64_t grid = w43_split2_grid<TTW>(c, POOL, m_pairs, a);
     STITO_REQUIRE(grid > 0 && grid < (1ll << 31), STITO_E_UNSUPPORTED, "conv (two-sweep split-precision winograd): grid / cout %d", c.Cout);
     const size_t vbytes = align_up((size_t)m_pairs * 2 * (size_t)(c.Cin / 16) * 3 * S43B_PART, 256);
-    unsigned *amax = (unsigned *)(ws + vbytes);
+    unsigned *amax_ws = (unsigned *)(ws + vbytes);
+    const unsigned *amax = amax_in != nullptr ? amax_in : amax_ws;
     f32x4 *partial = (f32x4 *)(ws + vbytes + align_up((size_t)c.S * sizeof(unsigned), 256));
-    {   // stream maxima
-        STITO_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)c.S * sizeof(unsigned), st));
+    if (amax_in == nullptr) {   // stream maxima (not supplied by the layer that produced `in`)
+        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
         const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
         int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
         const int cap = (4096 + c.S - 1) / c.S;
         splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
-        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax);
+        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax_ws);
         STITO_LAUNCH_CHECK();
     }
     {   // V slabs (MODE 4) of 2 * m_pairs pixel blocks (a block past the map transforms to zeros)
@@ -1490,6 +1536,7 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     g.n_mblocks = (int)m_pairs;
     g.ct_group = a;
+    g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
                        (const unsigned *)amax, u_inv, partial);
@@ -1498,30 +1545,30 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
 }
 
 int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                         bool pool, void *ws, size_t ws_bytes, hipStream_t st) {
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
     const size_t need = wino43_split2_workspace_bytes(c, pool);
     STITO_REQUIRE(need > 0 && ws != nullptr && ws_bytes >= need, STITO_E_WORKSPACE,
                   "conv (two-sweep split-precision winograd F(4x4,3x3)): workspace have %zu need %zu", ws_bytes, need);
     char *w = (char *)ws;
     switch (w43_ttw(c, pool)) {
-        case 8: return pool ? launch_w43_split2<8, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<8, false>(in, upk, scale, shift, out, c, w, st);
-        case 4: return pool ? launch_w43_split2<4, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<4, false>(in, upk, scale, shift, out, c, w, st);
-        case 2: return pool ? launch_w43_split2<2, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<2, false>(in, upk, scale, shift, out, c, w, st);
-        default: return pool ? launch_w43_split2<1, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split2<1, false>(in, upk, scale, shift, out, c, w, st);
+        case 8: return pool ? launch_w43_split2<8, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<8, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        case 4: return pool ? launch_w43_split2<4, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<4, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        case 2: return pool ? launch_w43_split2<2, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<2, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        default: return pool ? launch_w43_split2<1, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<1, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
     }
 }
 
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                        bool pool, void *ws, size_t ws_bytes, hipStream_t st) {
+                        bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
     const size_t need = wino43_split_workspace_bytes(c, pool);
     STITO_REQUIRE(need > 0 && ws != nullptr && ws_bytes >= need, STITO_E_WORKSPACE,
                   "conv (split-precision winograd F(4x4,3x3)): workspace have %zu need %zu", ws_bytes, need);
     char *w = (char *)ws;
     switch (w43_ttw(c, pool)) {
-        case 8: return pool ? launch_w43_split<8, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<8, false>(in, upk, scale, shift, out, c, w, st);
-        case 4: return pool ? launch_w43_split<4, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<4, false>(in, upk, scale, shift, out, c, w, st);
-        case 2: return pool ? launch_w43_split<2, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<2, false>(in, upk, scale, shift, out, c, w, st);
-        default: return pool ? launch_w43_split<1, true>(in, upk, scale, shift, out, c, w, st) : launch_w43_split<1, false>(in, upk, scale, shift, out, c, w, st);
+        case 8: return pool ? launch_w43_split<8, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split<8, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        case 4: return pool ? launch_w43_split<4, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split<4, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        case 2: return pool ? launch_w43_split<2, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split<2, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        default: return pool ? launch_w43_split<1, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split<1, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
     }
 }
 
