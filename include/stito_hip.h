@@ -79,7 +79,7 @@ const char *stito_last_error(void);
 /* ABI version: 5 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
- * stito_conv_timing_read_each). */
+ * _F4_SPLITK, stito_conv_timing_read_each). */
 int stito_version(void);
 
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
@@ -189,7 +189,12 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * input channels twice -- 18 of the 36 Winograd positions per sweep, the first sweep's share of the outputs parked in
         * the workspace: a third fewer bytes copied into LDS per MAC, which is what bounds _F4_SPLIT.  Own packing; sums in
         * a different order than _F4_SPLIT (same accuracy, not the same bits). */
-       STITO_CONV_WINOGRAD_F4_SPLIT2 = 5 };
+       STITO_CONV_WINOGRAD_F4_SPLIT2 = 5,
+       /* Split-precision products with the input transform INSIDE the convolution (no workspace round trip of the transformed
+        * input): for the layers below 256 output channels, whose activations are large and whose channel loops are short.
+        * A chunk of 4 input channels fills one f16 MFMA of depth 16 with hi hi' + hi lo' + lo hi'.  cin % 8 == 0,
+        * cout % 64 == 0; own packing; workspace = one word per stream. */
+       STITO_CONV_WINOGRAD_F4_SPLITK = 6 };
 
 typedef struct {
     int32_t embed_dim;
@@ -201,7 +206,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT or _F4_SPLIT2 */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2 or _F4_SPLITK */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -273,7 +278,7 @@ int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const 
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
 /* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT / _F4_SPLIT2: the transformed
- * input, stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
+ * input; _F4_SPLITK: per-stream maxima of the input, stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
 size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                              const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,

@@ -639,9 +639,11 @@ __global__ __launch_bounds__(WINO8_THREADS) void k_conv_wino8(const float *__res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in, const float *__restrict__ w /*[cout][9]*/,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
-                                                     float *__restrict__ out, int H, int W, int Cout, int64_t n_pix_per_stream) {
+                                                     float *__restrict__ out, int H, int W, int Cout, int64_t n_pix_per_stream,
+                                                     unsigned *__restrict__ amax_out) {
     const int s = blockIdx.y;
     const int oct = blockIdx.z;  // channels 8 oct .. 8 oct + 7
+    unsigned mx = 0;             // largest output of this thread (>= 0 after ReLU: bit patterns order like the values)
     float wr[8][9], sc[8], sh[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -674,6 +676,15 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
         o1.x = r[4]; o1.y = r[5]; o1.z = r[6]; o1.w = r[7];
         *(float4 *)(op + (int64_t)p * 8) = o0;
         *(float4 *)(op + (int64_t)p * 8 + 4) = o1;
+        if (amax_out != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mx = max(mx, __float_as_uint(r[c]));
+        }
+    }
+    if (amax_out != nullptr) {  // per-stream maximum for the split-precision layer behind (conv_layout.h): one atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+        if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(amax_out + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out + s, mx);
     }
 }
 
@@ -1006,7 +1017,7 @@ static int launch_wino_tw(const float *in, const float *upk, const float *scale,
 }
 
 static int conv_first(const float *in, const float *w, const float *scale, const float *shift, float *out, int S, int H,
-                      int W, int Cout, hipStream_t st) {
+                      int W, int Cout, hipStream_t st, unsigned *amax_out = nullptr) {
     STITO_REQUIRE(Cout % 8 == 0 && Cout / 8 <= 65535, STITO_E_UNSUPPORTED, "first conv: cout %d", Cout);
     const int64_t npix = (int64_t)H * W;
     STITO_REQUIRE(npix < (1ll << 30), STITO_E_UNSUPPORTED, "first conv: %dx%d map too large", H, W);
@@ -1014,7 +1025,7 @@ static int conv_first(const float *in, const float *w, const float *scale, const
     int64_t gx = (npix + 255) / 256;
     const int64_t cap = (256 * 64 + (int64_t)S * (Cout / 8) - 1) / ((int64_t)S * (Cout / 8));  // ~64 workgroups per CU in total
     gx = gx < cap ? gx : (cap < 1 ? 1 : cap);
-    hipLaunchKernelGGL(k_conv_first, dim3((unsigned)gx, S, Cout / 8), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix);
+    hipLaunchKernelGGL(k_conv_first, dim3((unsigned)gx, S, Cout / 8), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix, amax_out);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
@@ -1026,13 +1037,14 @@ using namespace stito;
 static bool wino_ok(int cout, int cin) { return cin % WK == 0 && cout % 64 == 0; }
 
 extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo) {
-    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2) return wino43_split_packed_floats(cout, cin);
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2 || algo == STITO_CONV_WINOGRAD_F4_SPLITK) return wino43_split_packed_floats(cout, cin);
     return (size_t)cout * cin * ((algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) ? 36 : algo == STITO_CONV_WINOGRAD ? 16 : 9);
 }
 
 extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream) {
-    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2)
-        return pack_wino43_split(w_oihw_dev, cout, cin, packed_dev, algo == STITO_CONV_WINOGRAD_F4_SPLIT2, (hipStream_t)stream);
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2 || algo == STITO_CONV_WINOGRAD_F4_SPLITK)
+        return pack_wino43_split(w_oihw_dev, cout, cin, packed_dev, algo == STITO_CONV_WINOGRAD_F4_SPLITK ? 2 : algo == STITO_CONV_WINOGRAD_F4_SPLIT2 ? 1 : 0,
+                                 (hipStream_t)stream);
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) {  // one packing for both
         STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
         return pack_wino43(w_oihw_dev, cout, cin, packed_dev, (hipStream_t)stream);
@@ -1090,6 +1102,8 @@ extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, i
     if (n <= 0 || H <= 0 || W <= 0 || cout % 4 != 0) return 0;
     if (pool && (H < 2 || W < 2)) return 0;
     if (algo == STITO_CONV_WINOGRAD_F4_PRE && (cout % 256 != 0 || (cout >= 1024 && cout % 512 != 0))) return 0;  // its workgroup order deals channel tiles in fours / eights
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLITK)
+        return cin % 8 == 0 && cout % 64 == 0 && wino43_splitk_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0) > 0 ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2)
         return (cout < 1024 || cout % 512 == 0) && wino43_split_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
@@ -1106,6 +1120,7 @@ extern "C" double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int c
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_issued_flops(c, pool != 0);
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT) return 3.0 * wino43_issued_flops(c, pool != 0);  // hi hi' + hi lo' + lo hi' on the f16 pipe
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT2) return wino43_split2_issued_flops(c, pool != 0);
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLITK) return 4.0 * wino43_issued_flops(c, pool != 0);  // one 32x32x16 f16 MFMA per block and 4 channels (12 of its 16 k-slots carry products)
     if (algo == STITO_CONV_WINOGRAD) {
         WinoGeom g;
         size_t lds;
@@ -1128,8 +1143,8 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
                                      int pool, int algo, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
-    STITO_REQUIRE(algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2, STITO_E_WORKSPACE,
-                  "conv: STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT need stito_conv3x3_bn_relu_ws");
+    STITO_REQUIRE(algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+                  algo != STITO_CONV_WINOGRAD_F4_SPLITK, STITO_E_WORKSPACE, "conv: STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT* need stito_conv3x3_bn_relu_ws");
     if (cin % 8 != 0) {
         STITO_REQUIRE(cin == 1 && !pool, STITO_E_UNSUPPORTED, "conv: cin=%d (only 1 or a multiple of 8)", cin);
         return conv_first(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cout, st);
@@ -1155,8 +1170,9 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
 }
 
 extern "C" size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo) {
-    if ((algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2) ||
-        !stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)) return 0;
+    if ((algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+         algo != STITO_CONV_WINOGRAD_F4_SPLITK) || !stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)) return 0;
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLITK) return wino43_splitk_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT) return wino43_split_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT2) return wino43_split2_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
     return wino43_pre_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
@@ -1166,6 +1182,16 @@ extern "C" size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, in
 static int conv3x3_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev, const float *shift_dev, float *out_dev,
                       int n, int H, int W, int cin, int cout, int pool, int algo, void *workspace_dev, size_t workspace_bytes,
                       void *stream, const unsigned *amax_in, unsigned *amax_out) {
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLITK) {
+        STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
+        STITO_REQUIRE(stito_conv3x3_supported(n, H, W, cin, cout, pool, algo), STITO_E_UNSUPPORTED,
+                      "conv (split-precision winograd F(4x4,3x3), in-kernel transform): %dx%d map, %d -> %d channels not covered", H, W, cin, cout);
+        STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
+        return launch_wino43_splitk(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
+                                    workspace_dev, workspace_bytes, (hipStream_t)stream, amax_in, amax_out);
+    }
+    if (algo == STITO_CONV_DIRECT && cin == 1 && amax_out != nullptr && !pool && n > 0 && H > 0 && W > 0)
+        return conv_first(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cout, (hipStream_t)stream, amax_out);
     if (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2) {
         if (algo == STITO_CONV_WINOGRAD_F4 && amax_out != nullptr && n > 0 && H > 0 && W > 0 && cin % 8 == 0 && cout % 64 == 0 &&
             wino_ok(cout, cin) && (!pool || (H >= 2 && W >= 2)))
@@ -1211,7 +1237,8 @@ static size_t cnn14_pre_bytes(const stito_cnn14_weights *w, int n_streams, const
     size_t v = 0;
     for (int i = 0; i < STITO_CNN14_NUM_CONVS; ++i) {
         const int algo = w->conv_wino_algo[i];
-        if (w->conv_wino_dev[i] == nullptr || (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2)) continue;
+        if (w->conv_wino_dev[i] == nullptr || (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+                                               algo != STITO_CONV_WINOGRAD_F4_SPLITK)) continue;
         const int blk = i / 2, j = i % 2;
         const int ci = j == 0 ? w->channels[blk] : w->channels[blk + 1], pool = (j == 1 && blk < 5) ? 1 : 0;
         const size_t need = stito_conv3x3_workspace_bytes(n_streams, H[blk], W[blk], ci, w->channels[blk + 1], pool, algo);
@@ -1339,7 +1366,8 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
             // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
             int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE ||
-                         w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2)
+                         w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 ||
+                         w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLITK)
                             ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;  // (a split packing has no float32 fallback: the direct kernel takes over)
             if (walgo == STITO_CONV_WINOGRAD_F4_PRE && !stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo))
                 walgo = STITO_CONV_WINOGRAD_F4;  // same packing
@@ -1358,11 +1386,12 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             // does the next conv run a split-precision kernel (it scales its transformed input by this layer's per-stream maxima)
             // and can this layer's kernel report them?
             unsigned *amax_out = nullptr;
-            if (i + 1 < STITO_CNN14_NUM_CONVS && algo_i >= STITO_CONV_WINOGRAD_F4) {
+            if (i + 1 < STITO_CNN14_NUM_CONVS && (algo_i >= STITO_CONV_WINOGRAD_F4 || (algo_i == STITO_CONV_DIRECT && ci == 1 && !pool))) {
                 const int nb = (i + 1) / 2, nj = (i + 1) % 2;
                 const int nci = nj == 0 ? w->channels[nb] : w->channels[nb + 1], npool = (nj == 1 && nb < 5) ? 1 : 0;
                 const int nalgo = w->conv_wino_algo[i + 1];
-                if (w->conv_wino_dev[i + 1] != nullptr && (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2) &&
+                if (w->conv_wino_dev[i + 1] != nullptr &&
+                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLITK) &&
                     stito_conv3x3_supported(S, H[nb], W[nb], nci, w->channels[nb + 1], npool, nalgo)) {
                     amax_out = amax_buf[amax_next];
                     STITO_HIP_CHECK(hipMemsetAsync(amax_out, 0, (size_t)S * sizeof(unsigned), st));

@@ -90,7 +90,10 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
 bool wino43_split_supported(const ConvShape &c, bool pool);
 size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool);
 size_t wino43_split_packed_floats(int cout, int cin);
-int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, bool two_sweep, hipStream_t st);
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st);  // 0: k_conv_wino43s, 1: s2, 2: h
+size_t wino43_splitk_workspace_bytes(const ConvShape &c, bool pool);
+int launch_wino43_splitk(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool);
 double wino43_split2_issued_flops(const ConvShape &c, bool pool);
 int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
