@@ -454,60 +454,55 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
             if (e_ < W43_V / 4) vo_[e_] = vs_[e_];                                                       \
         }                                                                                                \
     }
-// V16: V(k) -> f16 halves.  Chunk kc = 4 channels c = 4 kc .. 4 kc + 3 of the 16-channel group (c % 32) / 16 of super-step c / 32;
-// position p = 9 pg + q sits in slab 9 (c / 32) + e / 2, slot 2 pg + e % 2 with e = 9 ((c % 32) / 16) + q (the order in which
-// k_conv_wino43s walks a wave's nine blocks twice per 32 channels); inside a slot [hi | lo][(c % 16) / 8][tile][c % 8].
-#define W43_STORE_V16(K_, CUR)                                                                           \
+// V16 / V16B: V(k) -> scaled f16 halves hi + lo in the slab order of k_conv_wino43s / k_conv_wino43s2.  Two consecutive chunks
+// (channels 8 m .. 8 m + 7: one 16-byte group of an operand row) leave together: the even chunk's values wait in registers
+// (v16_h) for the odd one, so that every store is a whole 16-byte group and a half-wave writes 512 contiguous bytes
+// (8-byte stores of single chunks: 3.4 TB/s for the transform pass; measured).  c_base and the chunk count are even.
+//   V16:  position p = 9 pg + q sits in slab 9 (c / 32) + e / 2, slot 2 pg + e % 2 with e = 9 ((c % 32) / 16) + q (the order in
+//         which k_conv_wino43s walks a wave's nine blocks twice per 32 channels); inside a slot [hi | lo][(c % 16) / 8][tile][c % 8];
+//   V16B: 64-tile workgroups = pixel-block pairs, two sweeps over 18 positions each.  Position row i = p / 6 belongs to sweep
+//         i >= 3 and is that sweep's local row [1, 2, 0][i] resp. i - 3 (rows {1, 2} and {3, 4} -- the pairs whose
+//         contributions share sums and differences -- are local rows 0, 1); slab 3 (c / 16) + local row, position column
+//         j = p % 6 at 4 KB each: [hi | lo][(c % 16) / 8][64 tiles][c % 8].
+#define W43_STORE_V16X(K_, CUR, B_)                                                                      \
     {                                                                                                    \
         const int kc_ = c_base + (K_);                                                                   \
-        const int kg_ = (kc_ >> 2) & 1;                                                                  \
-        char *vo_ = (char *)out + ((int64_t)m_blk * n_slabs16 + 9 * (kc_ >> 3)) * S43_VPART +            \
-                    (((kc_ >> 1) & 1) * 32 + v16_tile) * 16 + (kc_ & 1) * 8;                             \
         const float *vs_ = smem + (CUR) + W43_U;                                                         \
+        char *vo_ = (B_) ? (char *)out + ((int64_t)(m_blk >> 1) * 2 * n_slabs16 + 3 * (kc_ >> 2)) * S43B_PART + \
+                               (((kc_ >> 1) & 1) * 64 + (m_blk & 1) * 32 + v16_tile) * 16                 \
+                         : (char *)out + ((int64_t)m_blk * n_slabs16 + 9 * (kc_ >> 3)) * S43_VPART +     \
+                               (((kc_ >> 1) & 1) * 32 + v16_tile) * 16;                                  \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
             const int p_ = (tid >> 5) + 16 * j;                                                          \
             if (p_ < 36) {                                                                               \
-                const int pg_ = p_ / 9, e_ = kg_ * 9 + p_ - 9 * pg_;                                     \
                 const f32x2 x01 = *(const f32x2 *)(vs_ + p_ * 128 + v16_tile * 2) * v16_s;               \
                 const f32x2 x23 = *(const f32x2 *)(vs_ + p_ * 128 + 64 + ((v16_tile + 16) & 31) * 2) * v16_s; \
-                h4 hi_, lo_;                                                                             \
-                hi_[0] = (_Float16)x01[0]; hi_[1] = (_Float16)x01[1]; hi_[2] = (_Float16)x23[0]; hi_[3] = (_Float16)x23[1]; \
-                lo_[0] = (_Float16)(x01[0] - (float)hi_[0]); lo_[1] = (_Float16)(x01[1] - (float)hi_[1]); \
-                lo_[2] = (_Float16)(x23[0] - (float)hi_[2]); lo_[3] = (_Float16)(x23[1] - (float)hi_[3]); \
-                char *d_ = vo_ + (int64_t)(e_ >> 1) * S43_VPART + (pg_ * 2 + (e_ & 1)) * 2048;           \
-                *(h4 *)d_ = hi_;                                                                         \
-                *(h4 *)(d_ + 1024) = lo_;                                                                \
+                if (!(kc_ & 1)) {                                                                        \
+                    v16_h[j][0] = x01; v16_h[j][1] = x23;                                                \
+                } else {                                                                                 \
+                    const float x_[8] = {v16_h[j][0][0], v16_h[j][0][1], v16_h[j][1][0], v16_h[j][1][1], x01[0], x01[1], x23[0], x23[1]}; \
+                    h8 hi_, lo_;                                                                         \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) { hi_[e_] = (_Float16)x_[e_]; lo_[e_] = (_Float16)(x_[e_] - (float)hi_[e_]); } \
+                    char *d_;                                                                            \
+                    int lo_off_;                                                                         \
+                    if (B_) {                                                                            \
+                        const int i_ = p_ / 6, j_ = p_ - 6 * i_;                                         \
+                        const int sw_ = i_ >= 3, lr_ = sw_ ? i_ - 3 : (i_ == 0 ? 2 : i_ - 1);            \
+                        d_ = vo_ + ((int64_t)sw_ * n_slabs16 + lr_) * S43B_PART + j_ * 4096;             \
+                        lo_off_ = 2048;                                                                  \
+                    } else {                                                                             \
+                        const int pg_ = p_ / 9, e_ = ((kc_ >> 2) & 1) * 9 + p_ - 9 * pg_;                \
+                        d_ = vo_ + (int64_t)(e_ >> 1) * S43_VPART + (pg_ * 2 + (e_ & 1)) * 2048;         \
+                        lo_off_ = 1024;                                                                  \
+                    }                                                                                    \
+                    *(h8 *)d_ = hi_;                                                                     \
+                    *(h8 *)(d_ + lo_off_) = lo_;                                                         \
+                }                                                                                        \
             }                                                                                            \
         }                                                                                                \
     }
-// V16B: the slab order of k_conv_wino43s2 (64-tile workgroups = pixel-block pairs, two sweeps over 18 positions each).
-// Position row i = p / 6 belongs to sweep i >= 3 ? 1 : 0 and is that sweep's local row [1, 2, 0][i] resp. i - 3 (so that rows
-// {1, 2} and {3, 4} -- the pairs whose contributions share sums and differences -- are local rows 0, 1); a slab holds one
-// local row x 16 channels: slab 3 (c / 16) + local row, position column j = p % 6 at 4 KB each:
-// [hi | lo][(c % 16) / 8][64 tiles][c % 8].
-#define W43_STORE_V16B(K_, CUR)                                                                          \
-    {                                                                                                    \
-        const int kc_ = c_base + (K_);                                                                   \
-        char *vo_ = (char *)out + ((int64_t)(m_blk >> 1) * 2 * n_slabs16 + 3 * (kc_ >> 2)) * S43B_PART +  \
-                    (((kc_ >> 1) & 1) * 64 + (m_blk & 1) * 32 + v16_tile) * 16 + (kc_ & 1) * 8;          \
-        const float *vs_ = smem + (CUR) + W43_U;                                                         \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
-            const int p_ = (tid >> 5) + 16 * j;                                                          \
-            if (p_ < 36) {                                                                               \
-                const int i_ = p_ / 6, j_ = p_ - 6 * i_;                                                 \
-                const int sw_ = i_ >= 3, lr_ = sw_ ? i_ - 3 : (i_ == 0 ? 2 : i_ - 1);                    \
-                const f32x2 x01 = *(const f32x2 *)(vs_ + p_ * 128 + v16_tile * 2) * v16_s;               \
-                const f32x2 x23 = *(const f32x2 *)(vs_ + p_ * 128 + 64 + ((v16_tile + 16) & 31) * 2) * v16_s; \
-                h4 hi_, lo_;                                                                             \
-                hi_[0] = (_Float16)x01[0]; hi_[1] = (_Float16)x01[1]; hi_[2] = (_Float16)x23[0]; hi_[3] = (_Float16)x23[1]; \
-                lo_[0] = (_Float16)(x01[0] - (float)hi_[0]); lo_[1] = (_Float16)(x01[1] - (float)hi_[1]); \
-                lo_[2] = (_Float16)(x23[0] - (float)hi_[2]); lo_[3] = (_Float16)(x23[1] - (float)hi_[3]); \
-                char *d_ = vo_ + ((int64_t)sw_ * n_slabs16 + lr_) * S43B_PART + j_ * 4096;               \
-                *(h4 *)d_ = hi_;                                                                         \
-                *(h4 *)(d_ + 2048) = lo_;                                                                \
-            }                                                                                            \
-        }                                                                                                \
-    }
+#define W43_STORE_V16(K_, CUR) W43_STORE_V16X(K_, CUR, false)
+#define W43_STORE_V16B(K_, CUR) W43_STORE_V16X(K_, CUR, true)
 // patch(CH) -> patch buffer PB (0, 1): two masked LDS-DMA instructions per wave (pixels wv*64 + 512 j + lane)
 #define W43_COPY_P(CH, PB)                                                                              \
     {                                                                                                   \
@@ -578,6 +573,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     f32x2 tT[6], rX[4], rY[4];
+    f32x2 v16_h[3][2];  // V16 / V16B: the even chunk's values of this thread's items, waiting for the odd chunk
     f32x2 xa[3], xb[3], ya[3], yb[3], za[3], zb[3];  // z: PREV only
 
     // ---- prologue: patch(0), patch(1), U(0) by LDS-DMA, issued first; meanwhile every thread zeroes the slots of both patch
