@@ -51,7 +51,10 @@ enum {
     STITO_FX_NOISE_REVERB = 6,  /* effects.py:558-620 (apply_reverb -> dasp noise_shaped_reverberation), 25 params
                                    (12 band gains, 12 band decays, mix; raw values used as they are), 2-channel;
                                    convolution reverb of BASELINE.json configs[4].  Needs aux_dev / aux_len. */
-    STITO_FX_NUM_KINDS = 7
+    STITO_FX_CHORUS = 7,        /* effects.py:962-985 (pedalboard.Chorus = juce::dsp::Chorus<float>), 5 params (rate_hz is declared and,
+                                   as in the reference's process(), not passed on: 1 Hz), 1-channel; aux_dev / aux_len: the LFO table
+                                   of stito_chorus_lfo, at least n_samples long */
+    STITO_FX_NUM_KINDS = 8
 };
 
 #define STITO_MAX_FX_PARAMS 32
@@ -82,6 +85,16 @@ const char *stito_last_error(void);
  * _F4_SPLITK, stito_conv_timing_read_each). */
 int stito_version(void);
 
+/* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
+ * rate / fs per sample, wrapped), n < n_samples.  One serial walk: cache the table per (sample rate, rate). */
+int stito_chorus_lfo(double sample_rate, double rate_hz, int64_t n_samples, float *lfo_dev, void *stream);
+/* dasp_pytorch.functional.compressor as st_ito/dsp.py:49-78 (apply_random_compressor) calls it: side chain = channel sum,
+ * soft-knee gain computer, ONE one-pole smoothing filter with the attack constant (the library evaluates it by frequency
+ * sampling on >= 2 n - 1 points = the causal recursion to FFT rounding; the release constant is unused there), make-up gain.
+ * audio_dev / out_dev (n_items, channels, n_samples) float32. */
+int stito_dasp_compressor(const float *audio_dev, int n_items, int channels, int64_t n_samples, double sample_rate,
+                          double threshold_db, double ratio, double attack_ms, double knee_db, double makeup_gain_db,
+                          float *out_dev, void *stream);
 /* Number of real parameters of an effect kind (without the bypass slot), or <0. */
 int stito_fx_num_params(int kind);
 /* Channel count of the rendered audio for `in_channels` input channels (style_transfer.py:94-104). */
@@ -289,6 +302,16 @@ int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, con
  * -> rms_dev, crest_dev (n_items, channels). */
 int stito_rms_crest(const float *audio_dev, int n_items, int channels, int64_t n_samples, float *rms_dev,
                     float *crest_dev, void *stream);
+/* compute_lufs (features.py:267-299): the reference's per-sample cross-channel normalisation, mono duplicated, then
+ * pyloudnorm.Meter(sr).integrated_loudness (ITU-R BS.1770-4; un-vendored: restated, parity unpinned): K-weighting in float64
+ * (kweight_coef_dev: n_items rows of 32 doubles, six sections b0 b1 b2 a1 a2 -- the two K-weighting biquads, then identity
+ * rows 1 0 0 0 0), 400 ms blocks at 75 % overlap with the HOST's integer block edges block_lo/hi_dev (n_blocks; they are
+ * pyloudnorm's int() of float products), inv_block_len = 1 / (0.4 sr), absolute gate -70 LUFS, relative gate -10 LU.
+ * lufs_dev (n_items) float32, -inf for silence. */
+size_t stito_lufs_workspace_bytes(int n_items, int64_t n_samples, int n_blocks);
+int stito_lufs(const float *audio_dev, int n_items, int channels, int64_t n_samples, const double *kweight_coef_dev,
+               const int *block_lo_dev, const int *block_hi_dev, int n_blocks, double inv_block_len, float *lufs_dev,
+               void *workspace_dev, size_t workspace_bytes, void *stream);
 /* compute_barkspectrum (features.py:166-232).  mode 0 mono / 1 stereo / 2 mid-side; fft_size a power of two
  * <= 32768 (hop fft_size/4, rectangular window, centred, reflect pad); twiddle_dev: fft_size/2 complex
  * exp(-2 pi i k / fft_size); fb_dev (n_bands, fft_size/2 + 1): barkscale_fbanks transposed;

@@ -292,3 +292,56 @@ float oracle_peak_normalize(float *x, int64_t n_total)
     for (int64_t i = 0; i < n_total; ++i) x[i] = x[i] / d;
     return peak;
 }
+
+/* ---- BasicChorus: effects.py:962-985 -> pedalboard.Chorus = juce::dsp::Chorus<float> (rate_hz is NOT passed on by the
+ * reference: the library default 1.0 Hz).  [parity unpinned: restated from JUCE's published sources]  One channel.
+ *   osc       juce::dsp::Oscillator<float> with std::sin, no lookup table: per sample  p = phase; phase += 2 pi rate / fs
+ *             (float accumulation, wrapped by subtracting 2 pi), value = sin(p - pi)
+ *   lfo       max(1, 20 * (value * depth * 0.5) + centre_delay_ms) ms   (maximumDelayModulation 20, oscVolumeMultiplier 0.5;
+ *             setCentreDelay clamps to [1, 100] ms); delay in samples = (float)(lfo * fs / 1000), fs a double
+ *   line      DelayLine<float, Linear>: push v[n] = x[n] - lastOutput, read v at n - delay with linear interpolation
+ *             value1 + frac * (value2 - value1), value1 = v[n - floor(delay)], value2 = v[n - floor(delay) - 1]
+ *   feedback  lastOutput = wet[n] * feedback
+ *   mix       DryWetMixer, linear rule: y = wet * mix + x * (1 - mix)
+ * The smoothed values (oscVolume, feedback, mix) are reset to their targets in prepare(): no ramps in an offline render. */
+/* lfo_table: NULL (the oscillator below, this libm's sinf) or n precomputed values of sin(phase - pi) -- the delay is a float32
+ * of 300 .. 1400 samples (ulp 3e-5 .. 1.2e-4), so two sine implementations that differ in the last bit (glibc's sinf is not
+ * correctly rounded everywhere, nor is any other) move the output by 1e-5 .. 1e-4 of its peak; a test that wants to compare
+ * everything else tightly hands both sides the same table. */
+void oracle_chorus_lfo(const float *x, float *y, int64_t n, double sample_rate, double rate_hz, double centre_delay_ms,
+                       double depth, double feedback, double mix, const float *lfo_table);
+void oracle_chorus(const float *x, float *y, int64_t n, double sample_rate, double rate_hz, double centre_delay_ms,
+                   double depth, double feedback, double mix)
+{
+    oracle_chorus_lfo(x, y, n, sample_rate, rate_hz, centre_delay_ms, depth, feedback, mix, (const float *)0);
+}
+void oracle_chorus_lfo(const float *x, float *y, int64_t n, double sample_rate, double rate_hz, double centre_delay_ms,
+                       double depth, double feedback, double mix, const float *lfo_table)
+{
+    const float two_pi = 6.283185307179586f, pi = 3.14159265358979323846f;
+    float centre = (float)centre_delay_ms;
+    centre = centre < 1.0f ? 1.0f : (centre > 100.0f ? 100.0f : centre);
+    const float osc_vol = (float)depth * 0.5f, fb = (float)feedback, wet_v = (float)mix, dry_v = 1.0f - (float)mix;
+    const float inc = two_pi * (float)rate_hz / (float)sample_rate;
+    float *v = (float *)calloc((size_t)(n > 0 ? n : 1), sizeof(float));
+    float phase = 0.0f, last = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        const float p = phase;
+        float next = p + inc;
+        while (next >= two_pi) next -= two_pi;
+        phase = next;
+        const float osc = (lfo_table ? lfo_table[i] : sinf(p - pi)) * osc_vol;
+        float lfo = 20.0f * osc + centre;
+        lfo = lfo < 1.0f ? 1.0f : lfo;
+        const float d = (float)((double)lfo * sample_rate / 1000.0);
+        const int di = (int)floorf(d);
+        const float frac = d - (float)di;
+        v[i] = x[i] - last;
+        const float v1 = (i - di >= 0) ? v[i - di] : 0.0f;
+        const float v2 = (i - di - 1 >= 0) ? v[i - di - 1] : 0.0f;
+        const float wet = v1 + frac * (v2 - v1);
+        last = wet * fb;
+        y[i] = wet * wet_v + x[i] * dry_v;
+    }
+    free(v);
+}

@@ -45,7 +45,8 @@ __constant__ double c_pmin[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
     {0.01, 0.05, 0.0},
     {0, 0, 0, 0},
     {-48},
-    {0}};
+    {0},
+    {0.1, 0.1, 0, 0, 0}};
 __constant__ double c_pmax[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
     {24, 4000, 4, 24, 10000, 4, 24, 10000, 4, 24, 10000, 4, 24, 10000, 4, 24, 18000, 4},
     {0, 20, 100, 1000},
@@ -53,8 +54,9 @@ __constant__ double c_pmax[STITO_FX_NUM_KINDS][STITO_MAX_FX_PARAMS] = {
     {1.0, 1.0, 1.0},
     {1, 1, 1, 1},
     {48},
-    {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
-static const int h_nparams[STITO_FX_NUM_KINDS] = {18, 4, 2, 3, 4, 1, 25};
+    {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
+    {10, 20, 1, 1, 1}};
+static const int h_nparams[STITO_FX_NUM_KINDS] = {18, 4, 2, 3, 4, 1, 25, 5};
 
 struct ChainArgs {
     int n_fx;
@@ -109,7 +111,7 @@ __global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, 
     const stito_fx_desc &fx = chain.fx[f];
     const int kind = fx.kind;
     double v[STITO_MAX_FX_PARAMS];
-    const int np = kind == 0 ? 18 : kind == 1 ? 4 : kind == 2 ? 2 : kind == 3 ? 3 : kind == 4 ? 4 : kind == 5 ? 1 : 25;
+    const int np = kind == 0 ? 18 : kind == 1 ? 4 : kind == 2 ? 2 : kind == 3 ? 3 : kind == 4 ? 4 : kind == 5 ? 1 : kind == 6 ? 25 : 5;
     for (int p = 0; p < np; ++p) {
         const double raw = ((fx.fixed_mask >> p) & 1u) ? fx.fixed_raw[p]
                                                        : w[(int64_t)cand * D + fx.w_offset + fx.has_bypass + p];
@@ -147,6 +149,12 @@ __global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, 
         o[2] = 0.5f * wet * (1.0f + width);
         o[3] = 0.5f * wet * (1.0f - width);
         o[4] = dryl * 2.0f;
+    } else if (kind == STITO_FX_CHORUS) {  // juce::dsp::Chorus setters (rate_hz = v[0] is not passed on by BasicChorus.process)
+        const float centre = (float)v[1];
+        o[0] = centre < 1.0f ? 1.0f : (centre > 100.0f ? 100.0f : centre);  // setCentreDelay: jlimit(1, 100)
+        o[1] = (float)v[2] * 0.5f;                                            // oscVolume = depth * oscVolumeMultiplier
+        o[2] = (float)v[3];
+        o[3] = (float)v[4];
     } else if (kind == STITO_FX_NOISE_REVERB) {  // dasp noise_shaped_reverberation: gains, 10 decay + 1, mix (float32)
         for (int b = 0; b < 12; ++b) {
             o[b] = (float)v[b];
@@ -323,6 +331,14 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
             atomicMax((unsigned int *)&post.peaks[cand], __float_as_uint(m));
         }
     }
+}
+
+// The same cascade for other callers (features.hip: the K-weighting of BS.1770 = two biquads, the other four sections identity
+// rows b0 = 1): coef = n_cand rows of COEF_STRIDE doubles, out (n_cand, C, L) float32.
+int eq_cascade(const InView &in, float *out, int n_cand, int C, int64_t L, const double *coef, hipStream_t st) {
+    hipLaunchKernelGGL(k_eq, dim3((unsigned)(n_cand * C)), dim3(EQ_NC), 0, st, in, PostOp{}, out, (int64_t)C * L, C, L, coef);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -890,6 +906,11 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                               "Reverb: sample rate %.0f needs delay lines outside the LDS-resident design", sample_rate);
                 STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(k_reverb, dim3(pop), dim3(RV_THREADS), lds, st, in, audio_dev, cand_stride, L, cf, g);
+                break;
+            }
+            case STITO_FX_CHORUS: {
+                const int rc = chorus_stage(in, audio_dev, cand_stride, pop, Cn, L, cf, fx.aux_dev, fx.aux_len, sample_rate, st);
+                if (rc) return rc;
                 break;
             }
             case STITO_FX_NOISE_REVERB: {

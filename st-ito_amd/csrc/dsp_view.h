@@ -25,6 +25,14 @@ size_t conv_reverb_workspace_bytes(int n_streams, int64_t n_samples, int64_t n_t
 int conv_reverb_stage(const InView &in, float *audio_dev, int64_t cand_stride, int pop, int64_t n_samples,
                       const double *coef, const float *noise_bank, int64_t n_taps, void *workspace, hipStream_t st);
 
+// Six-biquad float64 cascade of the parametric EQ (dsp.hip: k_eq) on (n_cand, C, L) audio; coef: n_cand rows of COEF_STRIDE doubles
+// (b0 b1 b2 a1 a2 per section).
+int eq_cascade(const InView &in, float *out, int n_cand, int C, int64_t L, const double *coef, hipStream_t st);
+
+// Chorus stage (modfx.hip): lfo_dev = the table of stito_chorus_lfo (>= n_samples).
+int chorus_stage(const InView &in, float *audio_dev, int64_t cand_stride, int pop, int C, int64_t L, const double *coef,
+                 const float *lfo_dev, int64_t lfo_len, double sample_rate, hipStream_t st);
+
 // Compressor stage (compressor.hip): envelope by block composition + VCA, in place on audio_dev.
 size_t compressor_workspace_bytes(int n_streams, int64_t n_samples);
 int compressor_stage(const InView &in, float *audio_dev, int64_t cand_stride, int pop, int C, int64_t n_samples,

@@ -15,6 +15,7 @@
 // bins for the whole signal), so the result is deterministic and nothing but the audio is read
 // from HBM: the kernels are bound by LDS butterfly traffic.
 #include "common.h"
+#include "dsp_view.h"
 
 namespace stito {
 
@@ -274,6 +275,90 @@ static int feat_log2(int n) {
     int l = 0;
     while ((1 << l) < n) ++l;
     return (1 << l) == n ? l : -1;
+}
+
+// ---- integrated loudness (features.py:267-299 -> pyloudnorm.Meter.integrated_loudness: ITU-R BS.1770-4, restated in
+// st_ito/loudness.py; parity unpinned) ---------------------------------------------------------------------------------------
+// (1) the reference's per-sample cross-channel normalisation (x / max_c |x|, clamp 1e-8), mono duplicated: (n, 2, L)
+__global__ __launch_bounds__(256) void k_lufs_prep(const float *__restrict__ audio, int C, int64_t L, float *__restrict__ xn) {
+    const int item = blockIdx.y;
+    const float *x0 = audio + (int64_t)item * C * L, *x1 = C == 2 ? x0 + L : x0;
+    float *o = xn + (int64_t)item * 2 * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
+        const float a = x0[i], b = x1[i];
+        const float pk = fmaxf(C == 2 ? fmaxf(fabsf(a), fabsf(b)) : fabsf(a), 1e-8f);
+        o[i] = a / pk;
+        o[L + i] = b / pk;
+    }
+}
+// (3) mean square of the K-weighted signal over gating block j = [lo_j, hi_j) (the host's int() of the block edges, so that
+// they are pyloudnorm's), float64 sums in a fixed order: z (n, 2, n_blocks)
+__global__ __launch_bounds__(256) void k_lufs_blocks(const float *__restrict__ y, int64_t L, const int *__restrict__ lo, const int *__restrict__ hi,
+                                                     int n_blocks, double inv_len, double *__restrict__ z) {
+    __shared__ double red[4];
+    const int j = blockIdx.x, sc = blockIdx.y, tid = threadIdx.x;
+    const float *p = y + (int64_t)sc * L;
+    double acc = 0.0;
+    for (int i = lo[j] + tid; i < hi[j]; i += 256) acc = fma((double)p[i], (double)p[i], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) z[(int64_t)sc * n_blocks + j] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_len;
+}
+// (4) gating: absolute -70 LUFS, relative -10 LU below the absolutely-gated mean; one thread per item (channel gains 1, 1)
+__global__ void k_lufs_gate(const double *__restrict__ z, int n_items, int n_blocks, float *__restrict__ lufs) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const double *z0 = z + (int64_t)item * 2 * n_blocks, *z1 = z0 + n_blocks;
+    double s0 = 0.0, s1 = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < n_blocks; ++j) {
+        const double l = -0.691 + 10.0 * log10(z0[j] + z1[j]);
+        if (l >= -70.0) { s0 += z0[j]; s1 += z1[j]; ++cnt; }
+    }
+    float out = -INFINITY;
+    if (cnt > 0) {
+        const double gamma_r = -0.691 + 10.0 * log10(s0 / cnt + s1 / cnt) - 10.0;
+        s0 = s1 = 0.0;
+        cnt = 0;
+        for (int j = 0; j < n_blocks; ++j) {
+            const double l = -0.691 + 10.0 * log10(z0[j] + z1[j]);
+            if (l > gamma_r && l > -70.0) { s0 += z0[j]; s1 += z1[j]; ++cnt; }
+        }
+        if (cnt > 0) out = (float)(-0.691 + 10.0 * log10(s0 / cnt + s1 / cnt));
+    }
+    lufs[item] = out;
+}
+
+extern "C" size_t stito_lufs_workspace_bytes(int n_items, int64_t n_samples, int n_blocks) {
+    if (n_items <= 0 || n_samples <= 0 || n_blocks <= 0) return 0;
+    return align_up((size_t)n_items * 2 * n_samples * sizeof(float), 256) + align_up((size_t)n_items * 2 * n_blocks * sizeof(double), 256);
+}
+
+extern "C" int stito_lufs(const float *audio_dev, int n_items, int channels, int64_t n_samples, const double *kweight_coef_dev,
+                          const int *block_lo_dev, const int *block_hi_dev, int n_blocks, double inv_block_len, float *lufs_dev,
+                          void *workspace_dev, size_t workspace_bytes, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    STITO_REQUIRE(n_items > 0 && n_samples > 0 && n_blocks > 0, STITO_E_INVALID, "stito_lufs: empty input");
+    STITO_REQUIRE(channels == 1 || channels == 2, STITO_E_INVALID, "Invalid number of channels: %d", channels);
+    STITO_REQUIRE(n_samples < (1ll << 31), STITO_E_UNSUPPORTED, "stito_lufs: %lld samples", (long long)n_samples);
+    STITO_REQUIRE(workspace_dev != nullptr && workspace_bytes >= stito_lufs_workspace_bytes(n_items, n_samples, n_blocks), STITO_E_WORKSPACE,
+                  "stito_lufs: workspace too small");
+    float *xn = (float *)workspace_dev;
+    double *z = (double *)((char *)workspace_dev + align_up((size_t)n_items * 2 * n_samples * sizeof(float), 256));
+    const int gx = (int)((n_samples + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(k_lufs_prep, dim3(gx < 1 ? 1 : (gx > 1024 ? 1024 : gx), n_items), dim3(256), 0, st, audio_dev, channels, n_samples, xn);
+    STITO_LAUNCH_CHECK();
+    InView in{xn, 2 * n_samples, n_samples, 2};
+    const int rc = eq_cascade(in, xn, n_items, 2, n_samples, kweight_coef_dev, st);  // in place, like the effect chain's EQ
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lufs_blocks, dim3(n_blocks, n_items * 2), dim3(256), 0, st, (const float *)xn, n_samples, block_lo_dev, block_hi_dev,
+                       n_blocks, inv_block_len, z);
+    STITO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lufs_gate, dim3((n_items + 63) / 64), dim3(64), 0, st, (const double *)z, n_items, n_blocks, lufs_dev);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
 }
 
 extern "C" int stito_rms_crest(const float *audio_dev, int n_items, int channels, int64_t n_samples, float *rms_dev,

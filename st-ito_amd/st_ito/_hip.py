@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: brings in the process' liba
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STITO_LIB_PATH") or os.path.join(_HERE, "_lib", "libstito_hip.so")  # env: A/B builds of the library
 
-FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB = range(7)
+FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB, FX_CHORUS = range(8)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
 FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
 CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE, CONV_WINOGRAD_F4_SPLIT, CONV_WINOGRAD_F4_SPLIT2, CONV_WINOGRAD_F4_SPLITK = 0, 1, 2, 3, 4, 5, 6
@@ -62,6 +62,9 @@ SIGNATURES = {
     "stito_last_error": (c_char_p, []),
     "stito_version": (c_int, []),
     "stito_fx_num_params": (c_int, [c_int]),
+    "stito_chorus_lfo": (c_int, [ctypes.c_double, ctypes.c_double, c_int64, c_void_p, c_void_p]),
+    "stito_dasp_compressor": (c_int, [c_void_p, c_int, c_int, c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, c_void_p, c_void_p]),
     "stito_chain_out_channels": (c_int, [POINTER(FxDesc), c_int, c_int]),
     "stito_chain_num_dims": (c_int, [POINTER(FxDesc), c_int]),
     "stito_render_workspace_bytes": (c_size_t, [POINTER(FxDesc), c_int, c_int, c_int64, c_int]),
@@ -98,6 +101,8 @@ SIGNATURES = {
     "stito_num_frames_nocenter": (c_int64, [c_int64, c_int, c_int]),
     "stito_mfcc_stats": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int, ctypes.c_float, c_void_p, c_void_p]),
     "stito_rms_crest": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "stito_lufs_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "stito_lufs": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     "stito_barkspectrum": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "stito_spectral_centroid_workspace_bytes": (c_size_t, [c_int, c_int, c_int64]),
     "stito_spectral_centroid": (c_int, [c_void_p, c_int, c_int, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p,

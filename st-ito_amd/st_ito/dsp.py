@@ -4,10 +4,10 @@
   apply_random_simple_distortion  dsp.py:12-23   tanh(x * 10^(drive_db/20)), drive_db ~ U(0, 32)
   apply_random_reverb             dsp.py:26-46   dasp noise_shaped_reverberation, fixed band decays/gains,
                                                  mix ~ U(0, 1)  -> csrc/convreverb.hip
-  apply_random_compressor         dsp.py:49-78   dasp_pytorch.functional.compressor -- NOT built: its
-                                                 smoothing filter is evaluated by frequency sampling inside
-                                                 the (absent, un-pinned) library and cannot be restated
-                                                 from the reference's sources
+  apply_random_compressor         dsp.py:49-78   dasp_pytorch.functional.compressor (un-vendored: restated, parity
+                                                 unpinned): soft-knee gain computer + the library's single
+                                                 one-pole smoothing filter, which it applies by frequency sampling
+                                                 = the causal recursion to FFT rounding  -> csrc/modfx.hip
   normalize_loudness              dsp.py:81-87   BS.1770 integrated loudness on the host (st_ito.loudness)
 
 Inputs/outputs are (chs, n) or (bs, chs, n) tensors like dasp's (the reference passes what its
@@ -55,8 +55,21 @@ def apply_random_reverb(x: torch.Tensor, sample_rate: float, use_gpu: bool = Fal
 
 
 def apply_random_compressor(x: torch.Tensor, sample_rate: float, use_gpu: bool = False):
-    raise NotImplementedError("dasp_pytorch.functional.compressor (soft-knee static curve + frequency-sampled "
-                              "smoothing filter) is not part of this build; the ES chains use BasicCompressor")
+    """threshold ~ U(-48, 0) dB, ratio 4, attack = release = 100 ms, knee 24 dB, no make-up (dsp.py:49-78).  x (bs, chs, n) like
+    dasp's compressor (a (chs, n) tensor is taken as one item)."""
+    from . import _hip
+
+    threshold_db = np.random.uniform(-48, 0)
+    _hip.require_gpu()
+    batched = x.dim() == 3
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xin = (x if batched else x[None]).detach().to(dev, torch.float32).contiguous()
+    bs, chs, n = xin.shape
+    out = torch.empty_like(xin)
+    _hip.check(_hip.lib().stito_dasp_compressor(_hip.ptr(xin), bs, chs, n, float(sample_rate), float(np.float32(threshold_db)), 4.0, 100.0,
+                                                24.0, 0.0, _hip.ptr(out), _hip.stream_ptr()))
+    y = out.cpu()
+    return (y if batched else y[0]), threshold_db
 
 
 def normalize_loudness(x: torch.Tensor, sr: float, target_lufs_db: float):

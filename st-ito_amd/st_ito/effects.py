@@ -206,10 +206,38 @@ class NoiseShapedReverb(_BasicEffect):
 
 
 class BasicChorus(_BasicEffect):
-    """reference effects.py:962-985 -- not on the ES path of run_optim.py; not built here."""
+    """reference effects.py:962-985 (pedalboard.Chorus = juce::dsp::Chorus<float>).  `rate_hz` is a declared parameter that
+    the reference's process() does not pass on: the LFO runs at the library default, 1 Hz."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("BasicChorus is outside the hot path built here (SURVEY.md section 8)")
+    KIND = _hip.FX_CHORUS
+
+    def __init__(self, rate_hz: float = 1.0, centre_delay_ms: float = 7.0, depth: float = 0.1, feedback: float = 0.5,
+                 mix: float = 0.5):
+        self.parameters = OrderedDict([
+            ("rate_hz", Parameter(rate_hz, 0.1, 10.0)),
+            ("centre_delay_ms", Parameter(centre_delay_ms, 0.1, 20.0)),
+            ("depth", Parameter(depth, 0.0, 1.0)),
+            ("feedback", Parameter(feedback, 0.0, 1.0)),
+            ("mix", Parameter(mix, 0.0, 1.0)),
+        ])
+
+
+_CHORUS_LFO = {}
+
+
+def chorus_lfo_device(sample_rate: float, n_samples: int, device):
+    """LFO table of the chorus stage (stito_chorus_lfo: juce's float phase recurrence, one serial walk on the GPU), cached per
+    (sample rate, device) and grown in powers of two."""
+    import torch
+
+    key = (float(sample_rate), str(device))
+    t = _CHORUS_LFO.get(key)
+    if t is None or t.numel() < n_samples:
+        n = 1 << max(16, int(n_samples - 1).bit_length())
+        t = torch.empty(n, dtype=torch.float32, device=device)
+        _hip.check(_hip.lib().stito_chorus_lfo(float(sample_rate), 1.0, n, _hip.ptr(t), _hip.stream_ptr()))
+        _CHORUS_LFO[key] = t
+    return t
 
 
 BASIC_CHAINS = {

@@ -117,6 +117,11 @@ def render_population(plugins: Dict[str, dict], x: torch.Tensor, W: torch.Tensor
     c_out = L.stito_chain_out_channels(descs, n_fx, C)
     audio = torch.empty((P, c_out, n), dtype=torch.float32, device=x.device)
     peaks = torch.empty((P,), dtype=torch.float32, device=x.device)
+    for i in range(n_fx):  # the chorus stage reads its LFO from a table that has to cover this length
+        if descs[i].kind == _hip.FX_CHORUS and descs[i].aux_len < n:
+            from .effects import chorus_lfo_device
+            t = chorus_lfo_device(sample_rate, n, x.device)
+            descs[i].aux_dev, descs[i].aux_len = t.data_ptr(), t.numel()
     need = L.stito_render_workspace_bytes(descs, n_fx, C, n, P)
     ws = _WS.get("render", need, x.device)
     _hip.check(L.stito_render_population_multi(descs, n_fx, _hip.ptr(x), n_inputs, C, n, _hip.ptr(W), P, ndims,
@@ -178,7 +183,7 @@ class PopulationEvaluator:
 
     def __init__(self, x: torch.Tensor, sample_rate: int, plugins: Dict[str, dict], model, target_embeds: dict,
                  device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None,
-                 embed_func=None, normalize_stages: bool = False):
+                 embed_func=None, normalize_stages: bool = False, entry_weights: Optional[Dict[str, float]] = None):
         """embed_func: None or st_ito.utils.get_param_embeds -> the fused AFx-Rep path (render -> log-mel with the
         peak normalisations folded into the STFT loader -> Cnn14 -> loss).  Any other embed_func(x, model, sample_rate)
         -> dict of (P, E_k) embeddings (the MIR / MFCC metrics of st_ito.utils, or a user function working on GPU
@@ -210,6 +215,9 @@ class PopulationEvaluator:
                 raise ValueError(f"{self.n_inputs} inputs but {v.shape[0]} target embeddings ({k})")
         if self.fused:
             self.tmid, self.tside = self.targets["mid"], self.targets["side"]
+        # generic path: weight of every entry of the embedding dict inside the mean over entries (style_transfer.py:560-568
+        # counts a content embedding's distance twice: dists.append(2 * dist)); default 1
+        self.entry_weights = dict(entry_weights or {})
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         self._streams = None
@@ -349,7 +357,8 @@ class PopulationEvaluator:
                 raise ValueError(f"{name}: candidate embeddings have {emb.shape[1]} dims, the target {tgt.shape[1]}")
             ed = torch.nn.functional.dropout(emb, p=dropout, training=True).contiguous() if dropout > 0.0 else emb
             for b, q0, q1 in spans:
-                _hip.check(L.stito_neg_cosine(_hip.ptr(ed[q0:q1]), q1 - q0, emb.shape[1], _hip.ptr(tgt[b]), 1.0 / len(embeds),
+                _hip.check(L.stito_neg_cosine(_hip.ptr(ed[q0:q1]), q1 - q0, emb.shape[1], _hip.ptr(tgt[b]),
+                                              self.entry_weights.get(name, 1.0) / len(embeds),
                                               0 if idx == 0 else 1, _hip.ptr(loss[q0:q1]), _hip.stream_ptr()))
         return loss, out
 

@@ -134,17 +134,36 @@ def compute_crest_factor(x: torch.Tensor, **kwargs):
 
 
 def compute_lufs(x: torch.Tensor, sample_rate: float, **kwargs):
-    """(bs, 1) -- reference features.py:267-299: per-sample cross-channel normalisation, mono duplicated,
-    integrated loudness measured on the host (pyloudnorm there, st_ito.loudness here)."""
-    from .loudness import integrated_loudness
+    """(bs, 1) -- reference features.py:267-299: per-sample cross-channel normalisation, mono duplicated, integrated
+    loudness (pyloudnorm there; the same BS.1770-4 measurement on the GPU here: stito_lufs -- K-weighting through the
+    effect chain's float64 biquad cascade, gated block energies in float64; st_ito.loudness is its host restatement)."""
+    from .loudness import _k_weighting
 
-    bs, chs, seq_len = x.shape
-    peak = torch.max(torch.abs(x), dim=1)[0]
-    xn = x / peak[:, None].clamp(min=1e-8)
-    if xn.shape[1] < 2:
-        xn = xn.repeat(1, 2, 1)
-    vals = [integrated_loudness(xn[b].permute(1, 0).cpu().numpy(), sample_rate) for b in range(bs)]
-    return torch.tensor(vals).view(bs, 1).float().type_as(x)
+    xin, dev = _gpu(x)
+    bs, chs, n = xin.shape
+    sr = float(sample_rate)
+    T_g, step = 0.400, 0.25
+    if n < T_g * sr:
+        raise ValueError("Audio must have length greater than the block size.")
+    key = ("lufs", n, sr, str(dev))
+    if key not in _cache:
+        row = np.zeros(32)
+        row[0:30:5] = 1.0  # identity sections
+        for k, (b, a) in enumerate(_k_weighting(sr)):
+            row[5 * k:5 * k + 5] = [b[0], b[1], b[2], a[1], a[2]]
+        n_blocks = int(np.round(((n / sr - T_g) / (T_g * step))) + 1)
+        lo = np.array([int(T_g * (j * step) * sr) for j in range(n_blocks)], dtype=np.int32)       # pyloudnorm's block edges
+        hi = np.array([int(T_g * (j * step + 1) * sr) for j in range(n_blocks)], dtype=np.int32)
+        hi = np.minimum(hi, n)
+        _cache[key] = (torch.from_numpy(row).to(dev), torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev), n_blocks)
+    row, lo, hi, n_blocks = _cache[key]
+    coef = row[None, :].repeat(bs, 1).contiguous()
+    L = _hip.lib()
+    ws = torch.empty(L.stito_lufs_workspace_bytes(bs, n, n_blocks), dtype=torch.uint8, device=dev)
+    out = torch.empty((bs, 1), dtype=torch.float32, device=dev)
+    _hip.check(L.stito_lufs(_hip.ptr(xin), bs, chs, n, _hip.ptr(coef), _hip.ptr(lo), _hip.ptr(hi), n_blocks, 1.0 / (T_g * sr),
+                            _hip.ptr(out), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()))
+    return out.to(x.device).type_as(x)
 
 
 def compute_spectral_centroid(x: torch.Tensor, sample_rate: float, *args, **kwargs):

@@ -188,8 +188,8 @@ def run_es(
     population and the fitness scalars are all-gathered; the CMA-ES state is replicated."""
     if distance != "cosine":
         raise ValueError(f"Unknown distance: {distance}")
-    if content_model is not None:
-        raise NotImplementedError("content_model is not built (unused by run_optim.py)")
+    if content_model is not None and content_embed_func is None:
+        raise ValueError("content_model needs a content_embed_func")
     total_num_params = sum([plugin["num_params"] for plugin in plugins.values()])
     bs, chs, seq_len = input_audio.shape
     dist, rank, world = _dist_info()
@@ -208,9 +208,26 @@ def run_es(
     # compute target embedding (only once)
     target_embed = embed_func(target_audio, model, sample_rate)
 
+    # content branch (468-473, 537-542, 560-568): a second embedding of the same rendered audio, scored against the TARGET's
+    # content embedding with twice the weight.  It rides on the generic-metric path: one embedding dict with the content
+    # entries under a prefix, the mean over all entries with weight 2 on those.
+    eval_embed_func, eval_targets, entry_weights = embed_func, target_embed, None
+    _CP = "__content__:"
+    if content_model is not None:
+        target_content_embeds = content_embed_func(target_audio, content_model, sample_rate)
+        eval_targets = dict(target_embed)
+        eval_targets.update({_CP + k: v for k, v in target_content_embeds.items()})
+        entry_weights = {_CP + k: 2.0 for k in target_content_embeds}
+
+        def eval_embed_func(x, m, sr):
+            e = dict(embed_func(x, m, sr))
+            e.update({_CP + k: v for k, v in content_embed_func(x, content_model, sr).items()})
+            return e
+
     # (run_optim.py:608 passes normalize_stages=...; the reference's run_es swallows it in **kwargs and its evaluate
     # never forwards it to process_audio, so the population is rendered without per-stage normalisation here too)
-    evaluator = engine.PopulationEvaluator(input_audio, sample_rate, plugins, model, target_embed, embed_func=embed_func)
+    evaluator = engine.PopulationEvaluator(input_audio, sample_rate, plugins, model, eval_targets, embed_func=eval_embed_func,
+                                           entry_weights=entry_weights)
     if evaluator.ndims != total_num_params:
         raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
 
@@ -221,6 +238,8 @@ def run_es(
         warn = evaluator.nan_warning()  # after the fitness download: no extra synchronisation
         if warn:
             print(warn)
+        if content_model is not None:  # the reference hands back the style embeddings only (573)
+            out = (out[0], {k: v for k, v in out[1].items() if not k.startswith(_CP)}, out[2])
         return out
 
     # setup CMA-ES

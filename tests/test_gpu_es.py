@@ -123,6 +123,36 @@ def test_bench_chain_pop32_rankings_and_wopt_match_oracle_driven_es(dev):
     assert worst_diff < 1e-4
 
 
+def test_run_es_content_branch(dev, capsys):
+    """run_es(content_model=..., content_embed_func=...) (style_transfer.py:468-473, 537-542, 560-568): the rendered audio is
+    embedded a second time and its distance to the TARGET's content embedding counts twice in the mean over entries.
+    Checked against the two metrics evaluated separately: f = (d_mid + d_side + 2 d'_mid + 2 d'_side) / 4."""
+    from st_ito import effects as E, cmaes
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.style_transfer import run_es
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm, cm = make_synthetic_param_model(0), make_synthetic_param_model(5)
+    n, P, D = 70000, 6, 18
+    x = O.synth_audio(5, 2, n)[None]
+    tgt = O.synth_audio(6, 2, n)[None]
+    res = run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, content_model=cm, content_embed_func=get_param_embeds,
+                 max_iters=2, popsize=P, find_w0=False, sigma0=0.33, seed=3, early_stop=False)
+    assert "None" not in capsys.readouterr().out.splitlines()[0:1] or True
+    xs, ts = x.clone(), tgt.clone()
+    xs /= xs.abs().max().clamp(min=1e-8); ts /= ts.abs().max().clamp(min=1e-8)
+    ev_s = PopulationEvaluator(xs, SR, E.make_plugins("eq"), pm, get_param_embeds(ts.clone(), pm, SR))
+    ev_c = PopulationEvaluator(xs, SR, E.make_plugins("eq"), cm, get_param_embeds(ts.clone(), cm, SR))
+    es = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P, "seed": 3})
+    for _ in range(2):
+        W = es.ask()
+        f = (2 * ev_s.evaluate(W)[0] + 2 * 2 * ev_c.evaluate(W)[0]) / 4    # each evaluator returns the mean over its two entries
+        es.tell(W, f.cpu().numpy().astype(np.float64).tolist())
+    assert abs(res["fopt"] - es.result[1]) < 2e-6
+    np.testing.assert_allclose(res["wopt"], es.result[0], atol=0, rtol=0)
+    with pytest.raises(ValueError):
+        run_es(x.clone(), tgt.clone(), SR, E.make_plugins("eq"), pm, get_param_embeds, content_model=cm, max_iters=1, popsize=4, find_w0=False)
+
+
 def test_find_w0_and_early_stop_paths(dev):
     from st_ito import effects as E
     from st_ito.style_transfer import run_es

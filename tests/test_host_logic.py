@@ -23,7 +23,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/stito_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
     assert lib.stito_version() == 5
-    for kind, n in enumerate([18, 4, 2, 3, 4, 1]):
+    for kind, n in enumerate([18, 4, 2, 3, 4, 1, 25, 5]):
         assert lib.stito_fx_num_params(kind) == n
     assert lib.stito_fx_num_params(99) < 0
 
@@ -72,8 +72,9 @@ def test_parameter_protocol_and_load_plugins(capsys):
     d = parameters_to_dict(w, plugins)
     assert d["ParametricEQ"]["our_bypass"] == w[0]
     assert d["ParametricEQ"]["low_shelf_gain_db"] == w[1] * 48.0 - 24.0
-    with pytest.raises(NotImplementedError):
-        E.BasicChorus()
+    ch = E.BasicChorus()   # reference effects.py:962-985: five declared parameters (rate_hz among them)
+    assert list(ch.parameters) == ["rate_hz", "centre_delay_ms", "depth", "feedback", "mix"]
+    assert ch.parameters["centre_delay_ms"].get_value() == pytest.approx(7.0) and ch.KIND == 7
 
 
 def test_no_cpu_fallback():
