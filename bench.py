@@ -75,7 +75,7 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round2_conv_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round3_conv_pmc_traffic.json")
 
 
 def kernel_source_hash():
@@ -90,7 +90,8 @@ def kernel_source_hash():
 
 def pmc_traffic_per_launch(n_streams):
     """HBM bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the same 11 launches
-    at the same stream count).  -> (bytes or None, note).  Refused when the committed file was taken on other sources."""
+    at the same stream count, taken on this bench process: profiles/summarize_pmc_bench.py).  -> (bytes or None, note).
+    Refused when the committed file was taken on other sources."""
     try:
         d = json.load(open(PMC_TRAFFIC_JSON))
     except OSError:

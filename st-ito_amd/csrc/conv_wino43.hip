@@ -784,6 +784,9 @@ __global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, fl
 //            six outputs to hi + lo (the stream's scale folded into the row coefficients: a power of two) and stores 12 x 4 bytes;
 //   the two waves of a SIMD (w, w + 4) run the period's two halves in opposite order -- matrix products of chunk k first or
 //   transform of chunk k + 1 first -- so that one is on the matrix pipe while the other is on the VALU.
+#ifndef H43_SCHED
+#define H43_SCHED 0  // timing experiment: 1 = no scheduling fences inside a period (the compiler interleaves products and transform)
+#endif
 #ifndef H43_ABL
 #define H43_ABL 0  // timing-experiment bit mask (1 no transform, 2 no products, 4 no copies); 0 in every build that ships
 #endif
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
             const u32x4 bx_ = *(const u32x4 *)(pb_ + q_ * 1024);                                         \
             const u32x4 a4_ = {ax_[0], ax_[1], ax_[0] & a_mask, ax_[1] & a_mask};                        \
             acc[q_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a4_), __builtin_bit_cast(h8, bx_), acc[q_], 0, 0, 0); \
-            if (q_ % 3 == 2) __builtin_amdgcn_sched_barrier(0);  /* operands of at most three blocks in flight */ \
+            if (q_ % 3 == 2 && !(H43_SCHED & 1)) __builtin_amdgcn_sched_barrier(0);  /* operands of at most three blocks in flight */ \
         }                                                                                                \
     }
 
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
             H43_COPY_U1(k + 1, nxt, 0) H43_COPY_U1(k + 1, nxt, 1) H43_COPY_U1(k + 1, nxt, 2) H43_COPY_U1(k + 1, nxt, 3) H43_COPY_U1(k + 1, nxt, 4) \
         }                                                                                                \
         FIRST                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (!(H43_SCHED & 1)) __builtin_amdgcn_sched_barrier(0);                                         \
         SECOND                                                                                           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
         W43_BARRIER()                                                                                    \
