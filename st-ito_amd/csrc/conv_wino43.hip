@@ -782,11 +782,10 @@ __global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, fl
 //   V        [pos][hi | lo][32 tiles][4 halfs]: the A operand is one ds_read_b64 (hi for lanes 0..31, lo for 32..63) and two
 //            v_and_b32 (the upper 8 bytes: a copy of hi resp. zero); the transform item (row i, tile, channel pair) rounds its
 //            six outputs to hi + lo (the stream's scale folded into the row coefficients: a power of two) and stores 12 x 4 bytes;
-//   the two waves of a SIMD (w, w + 4) run the period's two halves in opposite order -- matrix products of chunk k first or
-//   transform of chunk k + 1 first -- so that one is on the matrix pipe while the other is on the VALU.
-#ifndef H43_SCHED
-#define H43_SCHED 0  // timing experiment: 1 = no scheduling fences inside a period (the compiler interleaves products and transform)
-#endif
+//   the period's work (~1 300 cycles) is shorter than the HBM latency of a patch copy, so the patches are fetched two periods
+//   ahead into three buffers by alternating wave sets (see the main loop), and every LDS read is issued a stage ahead of its
+//   consumer (the first version, one period of prefetch and reads next to their consumers, sat at 2 500 cycles per period
+//   whatever was ablated).  Halo patches of tile widths 8 and 4 only (three patch buffers have to fit).
 #ifndef H43_ABL
 #define H43_ABL 0  // timing-experiment bit mask (1 no transform, 2 no products, 4 no copies); 0 in every build that ships
 #endif
@@ -801,10 +800,12 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
     constexpr int TTH = 32 / TTW;
     constexpr int PWC = 4 * TTW + 2;
     using PL = W43Patch<TTW>;
-    constexpr int NPL = PL::NPL, PFL = PL::PFL, BUF = W43_BUF;
+    constexpr int PFL = PL::PFL, BUF = W43_BUF;
+    constexpr int NP2 = (PL::SLOTS + 255) / 256;  // patch copies per wave of the issuing set (4 waves cover all slots)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int set = wv >> 2, w4 = wv & 3, t256 = tid & 255;  // waves w and w + 4 share a SIMD: one of each set per SIMD
     int ct_;
     const int m_blk = fdiv((int)blockIdx.x, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
     const int n0 = ct_ * 64;
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
     const int rb = fdiv(m_blk, g.fNCB, cb);
     const int vtr0 = rb * TTH, tc0 = cb * TTW;
     const int n_chunks = g.Cin / W43_K;
-    float *patch0 = smem + 2 * BUF;
+    float *patch0 = smem + 2 * BUF;  // three patch buffers
     int tr0_;
     const int s0_ = fdiv(vtr0, g.fTR, tr0_);
     const int iv_lo = s0_ * g.H + 4 * tr0_ - 1;
@@ -835,11 +836,12 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
     const int s_first = fdiv(iv_lo < 0 ? 0 : iv_lo, g.fH, h_first);
     const int64_t plane8 = (int64_t)g.H * g.W * 8;
     const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W);
-    unsigned p_off[NPL];
-    uint64_t p_mask[NPL];
+    unsigned p_off[NP2];
+    uint64_t p_mask[NP2];
+    unsigned p_own = 0;  // bit j: slot t256 + 256 j exists and is never loaded (= padding: zeroed once)
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const int q = tid + W43_THREADS * j;
+    for (int j = 0; j < NP2; ++j) {
+        const int q = t256 + 256 * j;
         const int plane = q / PL::PLANE, pos = q % PL::PLANE;
         const int pr4 = PL::ROWMAJOR ? pos / PL::CW : pos % PL::RH, pc4 = PL::ROWMAJOR ? pos % PL::CW : pos / PL::RH;
         const int pr = 4 * pr4 + (plane >> 2), pc = 4 * pc4 + (plane & 3);
@@ -851,14 +853,27 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
         const int s_ = ok ? sq_ : s_first, h_ = ok ? hq_ : 0, w_ = ok ? w : 0;
         p_off[j] = (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
         p_mask[j] = __builtin_amdgcn_ballot_w64(ok);
+        if (q < PL::SLOTS && !ok) p_own |= 1u << j;
     }
     const unsigned lds_patch = lds0 + (unsigned)(2 * BUF) * 4u;
 
-#define H43_COPY_U1(CH, BOFF, J_)                                                                        \
+// U slab of chunk CH -> buffer BOFF, piece II (one position: 64 channels x 16 B = 1 KB)
+#define H43_COPY_U(CH, BOFF, II)                                                                         \
+    glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + (II) * u_pos_stride, u_voff, lds0 + (unsigned)((BOFF) + (II) * 64 * W43_K) * 4u);
+// patch(CH) -> patch buffer PB (0..2): NP2 masked LDS-DMA instructions per wave of the issuing set (pixels w4 * 64 + 256 j + lane)
+#define H43_COPY_P2(CH, PB)                                                                              \
     {                                                                                                    \
-        const int ii = wv + 8 * (J_) < 36 ? wv + 8 * (J_) : wv + 8 * (J_) - 8;                           \
-        glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + ii * u_pos_stride, u_voff,                   \
-                  lds0 + (unsigned)((BOFF) + ii * 64 * W43_K) * 4u);                                     \
+        const int cc_ = (CH);                                                                            \
+        const float *pb_ = p_base + (int64_t)(cc_ >> 1) * plane8 + (cc_ & 1) * 4;                        \
+        _Pragma("unroll") for (int j = 0; j < NP2; ++j) {                                                \
+            uint64_t keep_;                                                                              \
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"  \
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                          \
+                         : "=&s"(keep_)                                                                  \
+                         : "v"(p_off[j]), "s"(pb_), "s"(lds_patch + (unsigned)((PB) * PFL + (w4 * 64 + 256 * j) * W43_K) * 4u), \
+                           "s"(p_mask[j])                                                                \
+                         : "memory");                                                                    \
+        }                                                                                                \
     }
 // one output pair of the transform -> scaled f16 halves hi + lo at position column J of the item's row
 #define H43_PUT(J, VAL)                                                                                  \
@@ -882,48 +897,49 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
         H43_PUT(4, pk_fma(cm2, u_, s_))                                                                  \
         H43_PUT(5, pk_fma(c4, tT[1], pk_fma(cm5, tT[3], tT[5])))                                         \
     }
-#define H43_TRANSFORM(PBUF, VBOFF)                                                                       \
-    {                                                                                                    \
-        W43_T_RD(PBUF, 0, rX) W43_T_RD(PBUF, 1, rY)                                                      \
-        W43_T_ROW(0, rX) W43_T_RD(PBUF, 2, rX)                                                           \
-        W43_T_ROW(1, rY) W43_T_RD(PBUF, 3, rY)                                                           \
-        W43_T_ROW(2, rX) W43_T_RD(PBUF, 4, rX)                                                           \
-        W43_T_ROW(3, rY) W43_T_RD(PBUF, 5, rY)                                                           \
-        W43_T_ROW(4, rX) W43_T_ROW(5, rY)                                                                \
-        H43_COLS(VBOFF)                                                                                  \
+// operands of block group G (blocks 3 G .. 3 G + 2): A = 8 bytes of V (hi for lanes 0..31, lo for 32..63), B = 16 bytes of U
+#define H43_OPS_RD(CUR, G)                                                                               \
+    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                                   \
+        ax[t_] = *(const u32x2 *)(a_rd + (CUR) * 4 + (3 * (G) + t_) * 512);                              \
+        bx[t_] = *(const u32x4 *)(b_rd + (CUR) * 4 + (3 * (G) + t_) * 1024);                             \
     }
-// the nine blocks of chunk CUR: A = [x | x & mask] from 8 bytes of V, B = 16 bytes of U
-#define H43_PRODUCTS(CUR)                                                                                \
-    {                                                                                                    \
-        const char *pa_ = a_rd + (CUR) * 4, *pb_ = b_rd + (CUR) * 4;                                     \
-        _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) {                                               \
-            const u32x2 ax_ = *(const u32x2 *)(pa_ + q_ * 512);                                          \
-            const u32x4 bx_ = *(const u32x4 *)(pb_ + q_ * 1024);                                         \
-            const u32x4 a4_ = {ax_[0], ax_[1], ax_[0] & a_mask, ax_[1] & a_mask};                        \
-            acc[q_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a4_), __builtin_bit_cast(h8, bx_), acc[q_], 0, 0, 0); \
-            if (q_ % 3 == 2 && !(H43_SCHED & 1)) __builtin_amdgcn_sched_barrier(0);  /* operands of at most three blocks in flight */ \
-        }                                                                                                \
+#define H43_MFMA(G)                                                                                      \
+    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                                   \
+        const u32x4 a4_ = {ax[t_][0], ax[t_][1], ax[t_][0] & a_mask, ax[t_][1] & a_mask};                \
+        acc[3 * (G) + t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a4_), __builtin_bit_cast(h8, bx[t_]), acc[3 * (G) + t_], 0, 0, 0); \
     }
+#define H43_FENCE() __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
-    f32x2 tT[6], rX[4], rY[4];
+    f32x2 tT[6], rA[3][4];
+    u32x2 ax[3];
+    u32x4 bx[3];
 
-    // ---- prologue: patch(0), U(0), patch(1) by LDS-DMA; zero fill of the padding slots; transform item geometry
-    W43_COPY_P(0, 0)
-    H43_COPY_U1(0, 0, 0) H43_COPY_U1(0, 0, 1) H43_COPY_U1(0, 0, 2) H43_COPY_U1(0, 0, 3) H43_COPY_U1(0, 0, 4)
-    W43_COPY_P(1, 1)
+    // ---- prologue: patch(0), patch(2) (set 0) / patch(1) (set 1) and U(0) by LDS-DMA; zero fill of the padding slots of all
+    // three patch buffers; transform item geometry; V(0)
+    if (set == 0) {
+        H43_COPY_P2(0, 0)
+        if (n_chunks > 2) H43_COPY_P2(2, 2)
+    } else {
+        H43_COPY_P2(1, 1)
+    }
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const int q = tid + W43_THREADS * j;
-        if (q < PL::SLOTS && !((p_mask[j] >> lane) & 1)) {
+    for (int j = 0; j < 5; ++j) {
+        const int ii = wv + 8 * j < 36 ? wv + 8 * j : wv + 8 * j - 8;
+        H43_COPY_U(0, 0, ii)
+    }
+#pragma unroll
+    for (int j = 0; j < NP2; ++j)
+        if ((p_own >> j) & 1) {
+            const int q = t256 + 256 * j;
             *(f32x4 *)(patch0 + q * W43_K) = (f32x4)(0.0f);
             *(f32x4 *)(patch0 + PFL + q * W43_K) = (f32x4)(0.0f);
+            *(f32x4 *)(patch0 + 2 * PFL + q * W43_K) = (f32x4)(0.0f);
         }
-    }
     {
         int ti, tile, cp;
         if (lane < 32) {
@@ -962,32 +978,56 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__res
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
-    H43_TRANSFORM(patch0, 0)
+    W43_T_RD(patch0, 0, rA[0]) W43_T_RD(patch0, 1, rA[1]) W43_T_RD(patch0, 2, rA[2])
+    W43_T_ROW(0, rA[0]) W43_T_ROW(1, rA[1]) W43_T_ROW(2, rA[2])
+    W43_T_RD(patch0, 3, rA[0]) W43_T_RD(patch0, 4, rA[1]) W43_T_RD(patch0, 5, rA[2])
+    W43_T_ROW(3, rA[0]) W43_T_ROW(4, rA[1]) W43_T_ROW(5, rA[2])
+    H43_COLS(0)
     W43_BARRIER()  // V(0), U(0) complete
 
-    // ---- main loop: period k multiplies chunk k and produces chunk k + 1 ------------------------------------------------
-    // two copies of the loop, one per order of the period's halves (waves w and w + 4 share a SIMD); every wave passes
-    // n_chunks barriers either way
-#define H43_PERIOD(FIRST, SECOND)                                                                        \
-    {                                                                                                    \
-        const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
-        const bool more = k + 1 < n_chunks;                                                              \
-        const float *pb_r = patch0 + ((k + 1) & 1) * PFL;  /* patch(k+1); patch(k+2) goes where patch(k) was */ \
-        if (more && !(H43_ABL & 4)) {                                                                    \
-            W43_COPY_P(k + 2, k & 1)                                                                     \
-            H43_COPY_U1(k + 1, nxt, 0) H43_COPY_U1(k + 1, nxt, 1) H43_COPY_U1(k + 1, nxt, 2) H43_COPY_U1(k + 1, nxt, 3) H43_COPY_U1(k + 1, nxt, 4) \
-        }                                                                                                \
-        FIRST                                                                                            \
-        if (!(H43_SCHED & 1)) __builtin_amdgcn_sched_barrier(0);                                         \
-        SECOND                                                                                           \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
-        W43_BARRIER()                                                                                    \
+    // ---- main loop: period k multiplies chunk k, transforms patch(k + 1) into V(k + 1), copies U(k + 1) and patch(k + 3).
+    // The sets alternate roles: set k % 2 issues the patch copies (HBM latency: they get two periods, nobody waits for them
+    // before barrier(k + 1)); the other set issues the U copies (L2 hits) and waits vmcnt(0) at the end of the period, which
+    // also covers the patch copies it issued in period k - 1.  Inside the period every LDS read is issued one stage ahead of
+    // its consumer: three transform columns and three blocks' operands are in flight at a time.
+    int r1 = 1, r3 = 0;  // (k + 1) % 3, (k + 3) % 3
+    for (int k = 0; k < n_chunks; ++k) {
+        const int cur = (k & 1) * BUF, nxt = BUF - cur;
+        const bool more = k + 1 < n_chunks;
+        const bool p_role = (k & 1) == set;
+        const float *pb_r = patch0 + r1 * PFL;
+        if (!(H43_ABL & 4)) {
+            if (p_role) {
+                if (k + 3 < n_chunks) H43_COPY_P2(k + 3, r3)
+            } else if (more) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) H43_COPY_U(k + 1, nxt, w4 + 4 * j)
+            }
+        }
+        H43_FENCE()
+        if (more && !(H43_ABL & 1)) { W43_T_RD(pb_r, 0, rA[0]) W43_T_RD(pb_r, 1, rA[1]) W43_T_RD(pb_r, 2, rA[2]) }
+        if (!(H43_ABL & 2)) H43_OPS_RD(cur, 0)
+        H43_FENCE()
+        if (more && !(H43_ABL & 1)) {
+            W43_T_ROW(0, rA[0]) W43_T_ROW(1, rA[1]) W43_T_ROW(2, rA[2])
+            W43_T_RD(pb_r, 3, rA[0]) W43_T_RD(pb_r, 4, rA[1]) W43_T_RD(pb_r, 5, rA[2])
+        }
+        H43_FENCE()
+        if (!(H43_ABL & 2)) { H43_MFMA(0) H43_OPS_RD(cur, 1) }
+        H43_FENCE()
+        if (more && !(H43_ABL & 1)) { W43_T_ROW(3, rA[0]) W43_T_ROW(4, rA[1]) W43_T_ROW(5, rA[2]) }
+        H43_FENCE()
+        if (!(H43_ABL & 2)) { H43_MFMA(1) H43_OPS_RD(cur, 2) }
+        H43_FENCE()
+        if (more && !(H43_ABL & 1)) H43_COLS(nxt)
+        H43_FENCE()
+        if (!(H43_ABL & 2)) H43_MFMA(2)
+        if (!p_role) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W43_BARRIER()
+        r1 = r1 == 2 ? 0 : r1 + 1;
+        r3 = r3 == 2 ? 0 : r3 + 1;
     }
-    if (wv < 4) {
-        for (int k = 0; k < n_chunks; ++k) H43_PERIOD(if (!(H43_ABL & 2)) H43_PRODUCTS(cur), if (more && !(H43_ABL & 1)) H43_TRANSFORM(pb_r, nxt))
-    } else {
-        for (int k = 0; k < n_chunks; ++k) H43_PERIOD(if (more && !(H43_ABL & 1)) H43_TRANSFORM(pb_r, nxt), if (!(H43_ABL & 2)) H43_PRODUCTS(cur))
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
 }
 
@@ -1692,6 +1732,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
 // not report its per-stream maxima.
 size_t wino43_splitk_workspace_bytes(const ConvShape &c, bool pool) {
     if (!wino43_supported(c, pool) || ((int64_t)c.Cin * c.H * c.W) % 8 != 0) return 0;
+    if (w43_ttw(c, pool) < 4) return 0;  // three patch buffers of the narrow-tile layouts do not fit next to the operand buffers
     return align_up((size_t)c.S * sizeof(unsigned), 256);
 }
 
@@ -1717,6 +1758,8 @@ static int launch_w43_splitk(const float *in, const float *upk, const float *sca
     }
     g.amax_out = amax_out;
     auto kern = k_conv_wino43h<TTW, POOL>;
+    lds = ((size_t)2 * W43_BUF + 3 * W43Patch<TTW>::PFL) * sizeof(float);  // two operand buffers, three patch buffers
+    STITO_REQUIRE(lds <= 160 * 1024, STITO_E_UNSUPPORTED, "conv (split-precision winograd, in-kernel transform): tile width %d", TTW);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g, amax, u_inv);
@@ -1733,8 +1776,7 @@ int launch_wino43_splitk(const float *in, const float *upk, const float *scale, 
     switch (w43_ttw(c, pool)) {
         case 8: return pool ? launch_w43_splitk<8, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_splitk<8, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
         case 4: return pool ? launch_w43_splitk<4, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_splitk<4, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
-        case 2: return pool ? launch_w43_splitk<2, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_splitk<2, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
-        default: return pool ? launch_w43_splitk<1, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_splitk<1, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        default: set_error("conv (split-precision winograd, in-kernel transform): maps narrower than 4 tiles are not covered"); return STITO_E_UNSUPPORTED;
     }
 }
 

@@ -392,6 +392,8 @@ def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
     overflow, no loss on the quiet streams), and bitwise independent of what else is in the batch."""
     from st_ito import _hip
     L = _hip.lib()
+    if algo == 6 and not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
+        pytest.skip("the in-kernel-transform split kernel only stages maps at least 4 tiles wide")
     assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)
     g = torch.Generator().manual_seed(H * 7 + cin)
     x = torch.relu(torch.randn((n, cin, H, W), generator=g))

@@ -19,7 +19,7 @@ bad = ran = 0
 for case in range(a.cases):
     n = int(rng.choice([1, 2, 3, 5, 8, 13, 40, 97]))
     H = int(rng.integers(2, 72)); W = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 100, 128]))
-    cin = int(rng.choice([8, 16, 24, 64, 128, 264])); cout = int(rng.choice([64, 128, 256, 512, 768]))
+    cin = int(rng.choice([8, 16, 24, 64, 128, 192, 264, 512])); cout = int(rng.choice([64, 128, 256, 512, 768, 1024]))
     pool = int(rng.integers(0, 2))
     g = torch.Generator().manual_seed(case)
     x = torch.randn((n, cin // 8, H, W, 8), generator=g).to(dev)
@@ -27,7 +27,7 @@ for case in range(a.cases):
     sc = (0.5 + torch.rand(cout, generator=g)).to(dev); sh = (0.1 * torch.randn(cout, generator=g)).to(dev)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     ref = None
-    for m in (0, 1, 2, 3):
+    for m in (0, 1, 2, 3, 4, 5, 6):
         if not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, m):
             continue
         packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, m), device=dev)
