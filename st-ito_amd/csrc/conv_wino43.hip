@@ -294,7 +294,7 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
 // workgroup per pixel block, no weights, no MFMAs) and writes every chunk's V slab -- in exactly the LDS layout -- to HBM,
 // MODE 1 is the convolution with `in` = those slabs: V(k) arrives by LDS-DMA like U(k), nothing is transformed.
 template <int TTW, bool POOL, bool TRACE, bool FUSE1 = false, int MODE = 0>
-__global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__restrict__ in, const float *__restrict__ upk,
+__global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(const float *__restrict__ in, const float *__restrict__ upk,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, float *__restrict__ out,
                                                               Wino43Geom g) {
@@ -303,8 +303,10 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
     using PL = W43Patch<TTW>;
     constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
     constexpr int PFL = PL::PFL;      // floats per patch buffer
-    constexpr int BUF = W43_BUF;
     constexpr bool PREV = MODE == 1, VOUT = MODE >= 2, V16 = MODE == 3, V16B = MODE == 4;  // 3 / 4: f16 slabs of k_conv_wino43s / s2
+    // the transform passes (MODE >= 2) have no weights: their two buffers hold V only (36 KB + patches = 64 KB of LDS, and with
+    // <= 128 VGPRs two workgroups share a CU: twice the HBM requests in flight of a pass that does nothing but move data)
+    constexpr int BUF = VOUT ? W43_V : W43_BUF, UO = VOUT ? 0 : W43_U;
     static_assert(!(FUSE1 && MODE != 0), "the fused first conv only exists for MODE 0");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 #define W43_STORE_V(K_, CUR)                                                                             \
     {                                                                                                    \
         f32x4 *vo_ = (f32x4 *)(out + ((int64_t)m_blk * n_chunks_all + c_base + (K_)) * W43_V);                        \
-        const f32x4 *vs_ = (const f32x4 *)(smem + (CUR) + W43_U);                                        \
+        const f32x4 *vs_ = (const f32x4 *)(smem + (CUR) + UO);                                           \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
             const int e_ = tid + W43_THREADS * j;                                                        \
             if (e_ < W43_V / 4) vo_[e_] = vs_[e_];                                                       \
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
 #define W43_STORE_V16X(K_, CUR, B_)                                                                      \
     {                                                                                                    \
         const int kc_ = c_base + (K_);                                                                   \
-        const float *vs_ = smem + (CUR) + W43_U;                                                         \
+        const float *vs_ = smem + (CUR) + UO;                                                            \
         char *vo_ = (B_) ? (char *)out + ((int64_t)(m_blk >> 1) * 2 * n_slabs16 + 3 * (kc_ >> 2)) * S43B_PART + \
                                (((kc_ >> 1) & 1) * 64 + (m_blk & 1) * 32 + v16_tile) * 16                 \
                          : (char *)out + ((int64_t)m_blk * n_slabs16 + 9 * (kc_ >> 3)) * S43_VPART +     \
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43(const float *__rest
         }
         cab = (f32x2){cf[0], cf[1]};
         ccd = (f32x2){cf[2], cf[3]};
-        vdst = W43_U + (ti * 6) * 32 * W43_K + cp * 64 + ((tile + 16 * cp) & 31) * 2;  // V[6 ti + j][cp][(tile + 16 cp) % 32]
+        vdst = UO + (ti * 6) * 32 * W43_K + cp * 64 + ((tile + 16 * cp) & 31) * 2;  // V[6 ti + j][cp][(tile + 16 cp) % 32]
     }
     if (FUSE1) {
         W43_BARRIER()  // window complete
@@ -1055,6 +1057,9 @@ __global__ void k_pack_wino43h(const float *__restrict__ w, int Cout, int Cin, c
         }
 }
 
+#ifndef S43B_ABL
+#define S43B_ABL 0  // timing experiment: 1 = no main loop in k_conv_wino43s / s2 (prologue + epilogue(s) only); 0 in every build that ships
+#endif
 // ---- split-precision streaming convolution ----------------------------------------------------------------------------
 // The same convolution as MODE 1 (transformed input and weights both streamed), on the f16 matrix pipe: every f32 operand x
 // is carried as two f16 halves  hi = rn16(s x), lo = rn16(s x - hi)  (s a power of two: per layer for the weights, per
@@ -1138,7 +1143,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
-    for (int sl = 0; sl < n_slabs; sl += 18) {  // Cin % 64 == 0
+    for (int sl = 0; sl < ((S43B_ABL & 1) ? 0 : n_slabs); sl += 18) {  // Cin % 64 == 0
         S43_PERIOD(0, sl) S43_PERIOD(1, sl + 1) S43_PERIOD(2, sl + 2) S43_PERIOD(3, sl + 3) S43_PERIOD(4, sl + 4) S43_PERIOD(5, sl + 5)
         S43_PERIOD(6, sl + 6) S43_PERIOD(7, sl + 7) S43_PERIOD(8, sl + 8) S43_PERIOD(9, sl + 9) S43_PERIOD(10, sl + 10) S43_PERIOD(11, sl + 11)
         S43_PERIOD(12, sl + 12) S43_PERIOD(13, sl + 13) S43_PERIOD(14, sl + 14) S43_PERIOD(15, sl + 15) S43_PERIOD(16, sl + 16) S43_PERIOD(17, sl + 17)
@@ -1252,7 +1257,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
         if (set == 0) { S43B_ISSUE(0, 0) } else { S43B_ISSUE(1, 1) }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W43_BARRIER()
-        for (int sl = 0; sl < n_slabs; sl += 6) {  // Cin % 32 == 0
+        for (int sl = 0; sl < ((S43B_ABL & 1) ? 0 : n_slabs); sl += 6) {  // Cin % 32 == 0
             S43B_PERIOD(0, sl) S43B_PERIOD(1, sl + 1) S43B_PERIOD(2, sl + 2)
             S43B_PERIOD(3, sl + 3) S43B_PERIOD(4, sl + 4) S43B_PERIOD(5, sl + 5)
         }
@@ -1622,8 +1627,9 @@ static int launch_w43_pre(const float *in, const float *upk, const float *scale,
         while (m_blocks * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;  // even share, >= 4 chunks
         gv.n_cgroups = ncg;
         auto kern = k_conv_wino43<TTW, POOL, false, false, 2>;
-        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds, st, in, (const float *)nullptr,
+        const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, vbuf, gv);
         STITO_LAUNCH_CHECK();
     }
@@ -1701,8 +1707,9 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
         while (m_blocks * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
         gv.n_cgroups = ncg;
         auto kern = k_conv_wino43<TTW, POOL, false, false, 3>;
-        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds, st, in, (const float *)nullptr,
+        const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
@@ -1713,7 +1720,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     g.n_mblocks = (int)m_blocks;
     const int n_tiles = c.Cout / 64;
     int a = n_tiles >= 16 ? 8 : 4;
-    if (const char *e = getenv("STITO_W43S_CTG")) a = atoi(e);  // tuning aid (tools/conv_bench.py): channel tiles per XCD round
+    if (const char *e = getenv("STITO_W43S_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }  // tuning aid (tools/conv_bench.py)
     STITO_REQUIRE(a >= 1 && a <= 32 && (a & (a - 1)) == 0 && n_tiles % a == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cout %d", c.Cout);
     g.ct_group = a;
     const int bm = 32 / a;
@@ -1791,7 +1798,7 @@ static int64_t w43_split2_grid(const ConvShape &c, bool pool, int64_t &m_pairs, 
     m_pairs = (m_blocks + 1) / 2;
     const int n_tiles = c.Cout / 64;
     int a = n_tiles >= 16 ? 8 : 4;
-    if (const char *e = getenv("STITO_W43S_CTG")) a = atoi(e);
+    if (const char *e = getenv("STITO_W43S_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }
     if (a < 1 || a > 32 || (a & (a - 1)) != 0 || n_tiles % a != 0) return 0;
     ct_group = a;
     const int bm = 32 / a;
@@ -1860,8 +1867,9 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
         while (m_blocks2 * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
         gv.n_cgroups = ncg;
         auto kern = k_conv_wino43<TTW, POOL, false, false, 4>;
-        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks2 * ncg)), dim3(W43_THREADS), lds, st, in, (const float *)nullptr,
+        const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks2 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
