@@ -338,6 +338,7 @@ def main():
         W = es.ask()
         lo, hi = shard_bounds(P_total, rank, world)
         loss, _, _ = ev.evaluate(W[lo:hi])
+        es.prefetch()  # the next generation's normal deviates, drawn while the GPU works (as run_es does)
         f = gather_fitness(loss, P_total)
         es.tell(W, f.tolist())  # .tolist() = the device->host sync the optimiser needs anyway
 
@@ -378,6 +379,7 @@ def main():
             W = es512.ask()
             lo, hi = shard_bounds(P512, rank, world)
             loss, _, _ = ev.evaluate(W[lo:hi])
+            es512.prefetch()
             es512.tell(W, gather_fitness(loss, P512).tolist())
         step512()
         fence()

@@ -709,38 +709,50 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ x, float
 }
 
 // fc_mid / fc_side (panns.py:271-279).  feat (n_cand*channels, K); stream parity picks the layer.
-// One workgroup = 8 streams of one kind x 256 outputs; weights are (K, E) so lanes read coalesced.
+// One workgroup = 8 streams of one kind x 64 outputs; each of its four waves walks a quarter of K (weights are (K, E): a wave
+// reads 256 contiguous bytes per k, the 8 stream values of a k are two broadcast 16-byte LDS reads), the quarters are added
+// in a fixed order.  (The first version gave a thread all of K for 256 outputs: 128 workgroups, 2 048 dependent steps, 250 us.)
 static constexpr int FC_SB = 8;
 __global__ __launch_bounds__(256) void k_fc(const float *__restrict__ feat, const float *__restrict__ wt_mid,
                                              const float *__restrict__ b_mid, const float *__restrict__ wt_side,
                                              const float *__restrict__ b_side, float *__restrict__ mid,
                                              float *__restrict__ side, int n_cand, int channels, int K, int E) {
-    extern __shared__ float sf[];  // [FC_SB][K]
+    extern __shared__ __attribute__((aligned(16))) float sf[];  // [K][FC_SB]; afterwards the partial sums [4][64][FC_SB]
     const int kind = blockIdx.z;   // 0 mid, 1 side
     const int c0 = blockIdx.y * FC_SB;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     const float *wt = kind == 0 ? wt_mid : wt_side;
     const float *bb = kind == 0 ? b_mid : b_side;
     float *dst = kind == 0 ? mid : side;
     for (int i = threadIdx.x; i < FC_SB * K; i += 256) {
         const int sb = i / K, k = i % K;
         const int cand = c0 + sb;
-        sf[i] = cand < n_cand ? feat[((int64_t)cand * channels + kind) * K + k] : 0.0f;
+        sf[k * FC_SB + sb] = cand < n_cand ? feat[((int64_t)cand * channels + kind) * K + k] : 0.0f;
     }
     __syncthreads();
-    if (e >= E) return;
-    float acc[FC_SB];
-#pragma unroll
-    for (int sb = 0; sb < FC_SB; ++sb) acc[sb] = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const float wv = wt[(int64_t)k * E + e];
-#pragma unroll
-        for (int sb = 0; sb < FC_SB; ++sb) acc[sb] = fmaf(sf[sb * K + k], wv, acc[sb]);
+    const int kq = (K + 3) / 4, k0 = ks * kq, k1 = min(K, k0 + kq);
+    const int ee = e < E ? e : E - 1;
+    f32x4 a0 = (f32x4)(0.0f), a1 = (f32x4)(0.0f);
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const float wv = wt[(int64_t)k * E + ee];
+        a0 += *(const f32x4 *)(sf + k * FC_SB) * wv;
+        a1 += *(const f32x4 *)(sf + k * FC_SB + 4) * wv;
     }
+    __syncthreads();
+    *(f32x4 *)(sf + (ks * 64 + lane) * FC_SB) = a0;
+    *(f32x4 *)(sf + (ks * 64 + lane) * FC_SB + 4) = a1;
+    __syncthreads();
+    if (e >= E) return;
     const float bias = bb[e];
 #pragma unroll
-    for (int sb = 0; sb < FC_SB; ++sb)
-        if (c0 + sb < n_cand) dst[(int64_t)(c0 + sb) * E + e] = acc[sb] + bias;
+    for (int h = 0; h < 2; ++h) {  // thread (lane, ks) finishes streams 2 ks, 2 ks + 1
+        const int sb = 2 * ks + h;
+        const float v = ((sf[(0 * 64 + lane) * FC_SB + sb] + sf[(1 * 64 + lane) * FC_SB + sb]) + sf[(2 * 64 + lane) * FC_SB + sb]) +
+                        sf[(3 * 64 + lane) * FC_SB + sb];
+        if (c0 + sb < n_cand) dst[(int64_t)(c0 + sb) * E + e] = v + bias;
+    }
 }
 
 __global__ void k_copy(const float *__restrict__ a, float *__restrict__ b, int64_t n) {
@@ -1410,9 +1422,9 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     const int C6 = w->channels[6], E = w->embed_dim;
     hipLaunchKernelGGL(k_head, dim3((C6 + 255) / 256, S), dim3(256), 0, st, actB, feat, H[6], W[6], C6);
     STITO_LAUNCH_CHECK();
-    const size_t lds = (size_t)FC_SB * C6 * sizeof(float);
+    const size_t lds = (size_t)FC_SB * (C6 > 256 ? C6 : 256) * sizeof(float);  // the features of 8 streams; reused for 4 x 64 x 8 partial sums
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_fc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_fc, dim3((E + 255) / 256, (n_cand + FC_SB - 1) / FC_SB, channels), dim3(256), lds, st, feat,
+    hipLaunchKernelGGL(k_fc, dim3((E + 63) / 64, (n_cand + FC_SB - 1) / FC_SB, channels), dim3(256), lds, st, feat,
                        w->fc_mid_wt_dev, w->fc_mid_b_dev, w->fc_side_wt_dev, w->fc_side_b_dev, mid_dev, side_dev, n_cand,
                        channels, C6, E);
     STITO_LAUNCH_CHECK();

@@ -223,6 +223,255 @@ __global__ __launch_bounds__(FE_THREADS) void k_logmel(FrontendDev fe, const flo
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The AFx-Rep front end (n_fft = 2048, hop = 1024) without workgroup barriers: one WAVE per frame.
+// k_logmel above spends its time waiting (eight __syncthreads per frame around one butterfly per thread, every sample loaded
+// twice).  Here a wave owns FW_F consecutive frames of a candidate: a hop of 1 024 samples is loaded once (lane l holds the
+// sample pairs 2 l + 128 j of both channels, already normalised and turned into mid / side) and serves as the second half
+// of one frame and the first half of the next; the 1 024-point complex FFT of a stream is 16 x 16 x 4 in registers --
+//   z[l + 64 j] --16-point DFT over j--> y[l][k1], x w1024^(l k1) --LDS transpose--> lane (k1, a): l = a + 4 b
+//   --16-point DFT over b--> u[a][k1][k2a], x w64^(a k2a) --LDS transpose--> lane l'': 4-point DFT over a
+//   --> X[k1 + 16 k2a + 256 k2b] = X[l'' + 64 m], m = 0..15: sixteen bins per lane, in order --
+// the conjugate partner X[1024 - k] of the real-transform unpack sits in lane 64 - l (one cross-lane read per bin), the power
+// spectrum goes to the wave's LDS buffer and the mel / log / norm stage is the one of k_logmel (same order of sums).  Nothing
+// is shared between waves: LDS operations of one wave execute in order, so no barrier is needed anywhere.
+// ------------------------------------------------------------------------------------------------------------------------
+#ifndef FW_ABL
+#define FW_ABL 0  // timing experiment (1 no mel stage, 2 no FFT passes, 4 no unpack); 0 in every build that ships
+#endif
+#ifndef FW_FRAMES
+#define FW_FRAMES 4
+#endif
+static constexpr int FW_F = FW_FRAMES;               // consecutive frames per wave
+static constexpr int FW_ROW = 66;                    // float2 per row of the first transpose (64 + 2: lanes (k1, a) of a half-wave on 32 distinct bank pairs)
+static constexpr int FW_WAVE_F2 = 16 * FW_ROW + 64;  // float2 per wave: transpose buffer (>= 1 024 + 1 floats of power spectrum), w64 twiddles
+static constexpr int FW_MAX_MELS = 256;
+static constexpr int FW_LDS_BYTES = (16 * 64 + (FE_THREADS / 64) * FW_WAVE_F2) * 8 + 4 * FW_MAX_MELS * 8;  // + pass-A twiddles and mel tasks, shared
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// forward radix-4 butterfly in place: a_k <- sum_n a_n (-i)^(n k)
+__device__ __forceinline__ void fw_r4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+    const float2 b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), b3 = csub(a1, a3);
+    a0 = cadd(b0, b2);
+    a1 = make_float2(b1.x + b3.y, b1.y - b3.x);  // b1 - i b3
+    a2 = csub(b0, b2);
+    a3 = make_float2(b1.x - b3.y, b1.y + b3.x);  // b1 + i b3
+}
+// forward 16-point DFT in place; X[k] ends up in x[4 (k & 3) + (k >> 2)] (FW_K)
+#define FW_K(k) (4 * ((k) & 3) + ((k) >> 2))
+__device__ __forceinline__ void fw_dft16(float2 (&x)[16]) {
+    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) fw_r4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);  // A[n2][k1] in x[4 k1 + n2]
+    // x[4 k1 + n2] *= w16^(n2 k1)
+    x[5] = cmul(x[5], make_float2(c1, -s1));     // 1
+    x[6] = cmul(x[6], make_float2(h, -h));       // 2
+    x[7] = cmul(x[7], make_float2(s1, -c1));     // 3
+    x[9] = cmul(x[9], make_float2(h, -h));       // 2
+    x[10] = make_float2(x[10].y, -x[10].x);      // 4: -i
+    x[11] = cmul(x[11], make_float2(-h, -h));    // 6
+    x[13] = cmul(x[13], make_float2(s1, -c1));   // 3
+    x[14] = cmul(x[14], make_float2(-h, -h));    // 6
+    x[15] = cmul(x[15], make_float2(-c1, s1));   // 9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) fw_r4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);  // X[k1 + 4 k2] in x[4 k1 + k2]
+}
+// exp(-2 pi i t / 2048) for t < 2048 from the half table
+__device__ __forceinline__ float2 fw_tw(const float2 *__restrict__ table, int t) {
+    const float2 v = table[t & 1023];
+    return t >= 1024 ? make_float2(-v.x, -v.y) : v;
+}
+#define FW_LDS_SYNC() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+#ifndef FW_OCC
+#define FW_OCC 3
+#endif
+__global__ __launch_bounds__(FE_THREADS, FW_OCC) void k_logmel_wave(FrontendDev fe, const float *__restrict__ audio,
+                                                             const float *__restrict__ peaks, int norm_passes, int C,
+                                                             int64_t L, int64_t T, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int N2 = 1024, HOP = 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *tw1s = (float2 *)smem_raw;                                   // [k1][l]: w1024^(l k1), shared by the waves
+    float2 *buf = tw1s + 16 * 64 + wave * FW_WAVE_F2;
+    float2 *tw2s = buf + 16 * FW_ROW;                                   // [a][k2a]: w64^(a k2a)
+    for (int i = threadIdx.x; i < 16 * 64; i += FE_THREADS) tw1s[i] = fw_tw(fe.twiddle, 2 * (i & 63) * (i >> 6));
+    // mel tasks (band, quarter of the band's run of bins), the same for every frame and stream: (first bin | bins << 16,
+    // offset of the first weight)
+    uint2 *mtask = (uint2 *)(tw1s + 16 * 64 + (FE_THREADS / 64) * FW_WAVE_F2);
+    const int M = fe.n_mels;
+    for (int q = threadIdx.x; q < 4 * M; q += FE_THREADS) {
+        const int part = q & 3, m = q >> 2;
+        const int st = fe.mel_start[m], ln = fe.mel_len[m];
+        const int lq = (ln + 3) >> 2;
+        const int beg = part * lq < ln ? part * lq : ln, end = beg + lq < ln ? beg + lq : ln;
+        mtask[q] = make_uint2((unsigned)(st + beg) | (unsigned)(end - beg) << 16, (unsigned)(fe.mel_off[m] + beg * fe.mel_stride));
+    }
+    __syncthreads();  // the only one: tables that are the same for every wave, frame and stream
+    const int cand = blockIdx.y;
+    const int64_t t0 = ((int64_t)blockIdx.x * (FE_THREADS / 64) + wave) * FW_F;
+    if (t0 >= T) return;
+    const int nf = (int)(T - t0 < FW_F ? T - t0 : FW_F);
+
+    float d1 = 1.0f, d2 = 1.0f;
+    if (peaks != nullptr && norm_passes > 0) {
+        const float pk = peaks[cand];
+        d1 = fmaxf(pk, 1e-8f);
+        if (norm_passes > 1) d2 = fmaxf(pk / d1, 1e-8f);
+    }
+    const bool second = norm_passes > 1 && d2 != 1.0f;
+    const float r1 = 1.0f / d1, r2 = 1.0f / d2;  // (as k_logmel: x * (1 / d))
+    const float *xl = audio + (int64_t)cand * C * L;
+    const float *xr = xl + L;
+    const bool al8 = (((uintptr_t)xl | (uintptr_t)xr) & 7) == 0;
+
+    tw2s[lane] = fw_tw(fe.twiddle, 32 * (lane >> 4) * (lane & 15));  // w64^(a k2a)
+
+    // hop h = samples [1024 h, 1024 h + 1024) (reflected outside the signal), lane l: pairs 2 l + 128 j, j < 8 -> mid / side
+    float2 hm0[8], hs0[8], hm1[8], hs1[8];
+    auto load_hop = [&](int64_t h, float2 (&hm)[8], float2 (&hs)[8]) {
+        const int64_t b = h * HOP;
+        const bool fast = al8 && b >= 0 && b + HOP <= L;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = b + 2 * lane + 128 * j;
+            float a0, a1, b0 = 0.0f, b1 = 0.0f;
+            if (fast) {
+                const float2 a = *(const float2 *)(xl + i);
+                a0 = a.x; a1 = a.y;
+                if (C == 2) { const float2 bb = *(const float2 *)(xr + i); b0 = bb.x; b1 = bb.y; }
+            } else {
+                const int64_t i0 = reflect_idx(i, L), i1 = reflect_idx(i + 1, L);
+                a0 = xl[i0]; a1 = xl[i1];
+                if (C == 2) { b0 = xr[i0]; b1 = xr[i1]; }
+            }
+            a0 = a0 * r1; a1 = a1 * r1;
+            if (second) { a0 = a0 * r2; a1 = a1 * r2; }
+            if (C == 2) {
+                b0 = b0 * r1; b1 = b1 * r1;
+                if (second) { b0 = b0 * r2; b1 = b1 * r2; }
+                hm[j] = make_float2((a0 + b0) * 0.5f, (a1 + b1) * 0.5f);
+                hs[j] = make_float2((a0 - b0) * 0.5f, (a1 - b1) * 0.5f);
+            } else {
+                hm[j] = make_float2(a0, a1);
+                hs[j] = hm[j];
+            }
+        }
+    };
+    const int64_t h_first = fe.no_center ? t0 : t0 - 1;  // frame t covers hops (t - 1, t) when centred, (t, t + 1) otherwise
+    load_hop(h_first, hm0, hs0);
+    load_hop(h_first + 1, hm1, hs1);
+
+    for (int f = 0; f < nf; ++f) {
+        const int64_t t = t0 + f;
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            // ---- window, pass A: 16-point DFT over j of z[l + 64 j] ------------------------------------------------
+            float2 x[16];
+            // (the window and the unpack twiddles are the same for every frame: reloaded per stream from L1 / L2 through
+            // pointers the compiler cannot see through, or it keeps all 64 values in registers across the loops and spills)
+            const float *win = fe.window;
+            const float2 *twt = fe.twiddle;
+            asm volatile("" : "+s"(win), "+s"(twt));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 w = *(const float2 *)(win + 2 * lane + 128 * j);
+                const float2 v = j < 8 ? (c == 0 ? hm0[j] : hs0[j]) : (c == 0 ? hm1[j - 8] : hs1[j - 8]);
+                x[j] = make_float2(v.x * w.x, v.y * w.y);
+            }
+            if (!(FW_ABL & 2)) {
+            fw_dft16(x);
+            buf[lane] = x[FW_K(0)];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) buf[k1 * FW_ROW + lane] = cmul(x[FW_K(k1)], tw1s[k1 * 64 + lane]);
+            FW_LDS_SYNC()
+            // ---- pass B: lane (k1, a), 16-point DFT over b of y[a + 4 b][k1] ------------------------------------------
+            {
+                const int k1 = lane & 15, a = lane >> 4;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) x[b] = buf[k1 * FW_ROW + a + 4 * b];
+                fw_dft16(x);
+                FW_LDS_SYNC()  // (all reads of the first layout are back before the second one is written)
+                buf[(k1 + 0) * 4 + a] = x[FW_K(0)];
+#pragma unroll
+                for (int k2a = 1; k2a < 16; ++k2a) buf[(k1 + 16 * k2a) * 4 + a] = cmul(x[FW_K(k2a)], tw2s[a * 16 + k2a]);
+            }
+            FW_LDS_SYNC()
+            // ---- pass C: 4-point DFT over a; x[q + 4 k2b] = X[lane + 64 (q + 4 k2b)] -----------------------------------
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 p01 = *(const float4 *)(buf + (lane + 64 * q) * 4), p23 = *(const float4 *)(buf + (lane + 64 * q) * 4 + 2);
+                float2 a0 = make_float2(p01.x, p01.y), a1 = make_float2(p01.z, p01.w), a2 = make_float2(p23.x, p23.y), a3 = make_float2(p23.z, p23.w);
+                fw_r4(a0, a1, a2, a3);
+                x[q] = a0; x[q + 4] = a1; x[q + 8] = a2; x[q + 12] = a3;
+            }
+            FW_LDS_SYNC()
+            }
+            // ---- unpack the real transform (as k_logmel), power spectrum into the wave's buffer ---------------------------
+            float *pw = (float *)buf;
+            const int pl = (64 - lane) & 63;
+            if (FW_ABL & 4) { for (int m = 0; m < 16; ++m) pw[lane + 64 * m] = x[m].x; }
+            else
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int k = lane + 64 * m;
+                const float2 zk = x[m];
+                const float px = __shfl(x[15 - m].x, pl, 64), py = __shfl(x[15 - m].y, pl, 64);
+                const float2 zo = x[(16 - m) & 15];  // lane 0: X[1024 - 64 m] is its own bin 16 - m (X[1024] = X[0])
+                const float2 zn = lane == 0 ? zo : make_float2(px, py);
+                const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+                const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+                const float2 wo = cmul(twt[k], O);
+                const float re = E.x + wo.x, im = E.y + wo.y;
+                pw[k] = re * re + im * im;
+            }
+            if (lane == 0) {  // k = 1024: zk = zn = X[0], w = -1
+                const float2 z = x[0];
+                const float2 E = make_float2(0.5f * (z.x + z.x), 0.5f * (z.y - z.y));
+                const float2 O = make_float2(0.5f * (z.y + z.y), -0.5f * (z.x - z.x));
+                const float2 wo = cmul(make_float2(-1.0f, 0.0f), O);
+                const float re = E.x + wo.x, im = E.y + wo.y;
+                pw[N2] = re * re + im * im;
+            }
+            FW_LDS_SYNC()
+            // ---- mel bands, 10 log10(clamp(., 1e-10)), input norm: four lanes per band (k_logmel's order of sums) ---------
+            if (FW_ABL & 1) { if (lane < M) out[((int64_t)(cand * C + c) * T + t) * M + lane] = pw[lane * 8]; if (lane + 64 < M) out[((int64_t)(cand * C + c) * T + t) * M + lane + 64] = pw[lane * 8 + 4]; }
+            else
+            for (int q0 = 0; q0 < 4 * M; q0 += 64) {
+                const int q = q0 + lane;
+                const bool live = q < 4 * M;
+                const int part = q & 3, m = live ? q >> 2 : 0;
+                const uint2 mt = live ? mtask[q] : make_uint2(0u, 0u);
+                const float *w = fe.mel_w + mt.y;
+                const int ws = fe.mel_stride, n = (int)(mt.x >> 16);
+                const float *p = pw + (mt.x & 0xffffu);
+                float acc = 0.0f;
+                for (int i = 0; i < n; ++i) acc = fmaf(p[i], w[i * ws], acc);
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (!live || part) continue;
+                float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
+                if (fe.norm_mode == STITO_NORM_MINMAX) {
+                    v = fminf(fmaxf(v, -80.0f), 40.0f);
+                    v = (v + 80.0f) / 120.0f;
+                    v = (v * 2.0f) - 1.0f;
+                } else if (fe.norm_mode == STITO_NORM_BATCHNORM) {
+                    v = v * fe.bn_scale[m] + fe.bn_shift[m];
+                }
+                out[((int64_t)(cand * C + c) * T + t) * M + m] = v;
+            }
+            FW_LDS_SYNC()  // the power spectrum has been read before the next stream's pass A overwrites it
+        }
+        if (f + 1 < nf) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hm0[j] = hm1[j]; hs0[j] = hs1[j]; }
+            load_hop(h_first + f + 2, hm1, hs1);
+        }
+    }
+}
+
 }  // namespace stito
 
 using namespace stito;
@@ -254,6 +503,18 @@ extern "C" int stito_logmel(const stito_frontend *fe, const float *audio_dev, co
     d.bn_scale = fe->bn0_scale_dev; d.bn_shift = fe->bn0_shift_dev;
     STITO_REQUIRE(fe->norm_mode != STITO_NORM_BATCHNORM || (d.bn_scale && d.bn_shift), STITO_E_INVALID, "batchnorm input norm needs bn0 scale/shift");
     const int64_t T = fe->no_center ? stito_num_frames_nocenter(n_samples, N, fe->hop) : stito_num_frames(n_samples, fe->hop);
+    // the AFx-Rep front end runs one wave per frame (k_logmel_wave); STITO_LOGMEL_GENERIC=1 keeps the general kernel (tests)
+    const char *gen_env = getenv("STITO_LOGMEL_GENERIC");  // (read per call: the parity test switches inside one process)
+    const bool generic_only = gen_env != nullptr && atoi(gen_env) != 0;
+    if (N == 2048 && fe->hop == 1024 && !generic_only && n_samples >= 2048 && fe->n_mels <= FW_MAX_MELS) {
+        const int wpb = FE_THREADS / 64;
+        const int64_t tasks = (T + FW_F - 1) / FW_F;
+        const size_t lds_w = FW_LDS_BYTES;
+        hipLaunchKernelGGL(k_logmel_wave, dim3((unsigned)((tasks + wpb - 1) / wpb), pop), dim3(FE_THREADS), lds_w, st, d, audio_dev,
+                           peaks_dev, norm_passes, channels, n_samples, T, logmel_dev);
+        STITO_LAUNCH_CHECK();
+        return STITO_OK;
+    }
     const size_t lds = (size_t)channels * (N / 2) * sizeof(float2) * 2;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_logmel, dim3((unsigned)T, pop), dim3(FE_THREADS), lds, st, d, audio_dev, peaks_dev, norm_passes,

@@ -41,14 +41,10 @@ class BoundTransform:
             period = 2.0 * (hi - lo)
             v = lo + np.mod(y[out] - lo, period)
             y[out] = np.where(v > hi, 2.0 * hi - v, v)
-        x = y.copy()
-        low = y < lb + al
-        if low.any():
-            x[low] = lb + (y[low] - (lb - al)) ** 2 / (4.0 * al)
-        up = y > ub - au
-        if up.any():
-            x[up] = ub - (y[up] - (ub + au)) ** 2 / (4.0 * au)
-        return x
+        # (both quadratic branches evaluated everywhere and selected: the same arithmetic per element as assigning through
+        # boolean masks, a third of the time for a 256 x 45 population -- this runs on the host between two GPU passes)
+        return np.where(y < lb + al, lb + (y - (lb - al)) ** 2 / (4.0 * al),
+                        np.where(y > ub - au, ub - (y - (ub + au)) ** 2 / (4.0 * au), y))
 
     def inverse(self, x: np.ndarray) -> np.ndarray:
         """Genotype in [lb - al, ub + au] whose image is x (x is clipped into [lb, ub] first), as pycma
@@ -123,6 +119,7 @@ class CMAEvolutionStrategy:
         self.best_f = float("inf")
         self.best_evals = 0
         self._geno: Optional[np.ndarray] = None
+        self._z_next: Optional[np.ndarray] = None
         self._stop = {}
         self.maxiter = opts.get("maxiter", None)
 
@@ -133,11 +130,19 @@ class CMAEvolutionStrategy:
 
     def ask(self) -> List[np.ndarray]:
         """lambda candidate solutions (phenotypes, inside the bounds)."""
-        z = self.rng.standard_normal((self.lam, self.N))
+        z = self._z_next if self._z_next is not None else self.rng.standard_normal((self.lam, self.N))
+        self._z_next = None
         y = z * self.D[None, :] @ self.B.T
         self._geno = self.mean[None, :] + self.sigma * y
         ph = self._geno.copy() if self.boundary is None else self.boundary(self._geno)
         return list(ph)  # rows of a fresh array (boundary() copies; without bounds _geno is not handed out: see below)
+
+    def prefetch(self):
+        """Draw the NEXT generation's standard normals now (0.2 ms for 256 x 45 on the host): they do not depend on tell(),
+        so a caller whose fitness evaluation runs asynchronously on the GPU calls this between launching it and waiting
+        for it.  The generator is used by ask() only, in the same order: runs with and without prefetch() are identical."""
+        if self._z_next is None:
+            self._z_next = self.rng.standard_normal((self.lam, self.N))
 
     def tell(self, solutions: Sequence[np.ndarray], function_values: Sequence[float]):
         f = np.asarray(function_values, dtype=np.float64)

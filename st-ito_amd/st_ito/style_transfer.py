@@ -140,16 +140,19 @@ def gather_fitness(local: torch.Tensor, popsize: int) -> torch.Tensor:
     return torch.cat(parts)
 
 
-def sharded_evaluate(W, eval_local):
+def sharded_evaluate(W, eval_local, while_waiting=None):
     """Evaluate a population across the ranks of the default process group.
 
     `eval_local(W_shard) -> (loss tensor (n_local,), embeds, audios)` is called with this rank's
     contiguous shard of W; the per-rank fitness vectors are all-gathered into candidate order, so
-    every rank returns the same full fitness list (and its own shard's embeds/audios)."""
+    every rank returns the same full fitness list (and its own shard's embeds/audios).  `while_waiting()` runs on the host
+    after the shard's GPU work has been queued and before the fitness download waits for it."""
     _, rank, world = _dist_info()
     P = len(W)
     lo, hi = shard_bounds(P, rank, world)
     loss, embeds, audios = eval_local(W[lo:hi])
+    if while_waiting is not None:
+        while_waiting()
     return gather_fitness(loss, P).tolist(), embeds, audios
 
 
@@ -231,10 +234,11 @@ def run_es(
     if evaluator.ndims != total_num_params:
         raise ValueError(f"plugins declare {total_num_params} params, chain consumes {evaluator.ndims}")
 
-    def evaluate(W, dropout: float = 0.0, want_audio: bool = False):
+    def evaluate(W, dropout: float = 0.0, want_audio: bool = False, while_waiting=None):
         """GPU replacement of the reference's evaluate closure (474-573)."""
         out = sharded_evaluate(W, lambda Ws: evaluator.evaluate(Ws, random_crop=random_crop, rng=rng,
-                                                                want_audio=want_audio, dropout=dropout, parallel=parallel))
+                                                                want_audio=want_audio, dropout=dropout, parallel=parallel),
+                               while_waiting)
         warn = evaluator.nan_warning()  # after the fitness download: no extra synchronisation
         if warn:
             print(warn)
@@ -273,8 +277,10 @@ def run_es(
 
     for iteration in range(max_iters):
         W = es.ask()
+        # (the next generation's normal deviates are drawn on the host while the GPU evaluates this one)
         fvals, output_embeds, output_audios = evaluate(
-            W, dropout=(dropout if (iteration + 1) < max_iters else 0.0), want_audio=savepop)
+            W, dropout=(dropout if (iteration + 1) < max_iters else 0.0), want_audio=savepop,
+            while_waiting=getattr(es, "prefetch", None))
         n_evals += len(W)
 
         # save best (pre-tell result, like the reference: index 0 is (None, inf))

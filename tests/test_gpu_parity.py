@@ -298,6 +298,23 @@ def test_logmel_vs_oracle_and_golden(dev, golden_dir, norm):
     assert np.abs(lmm - ref).max() < tol
 
 
+@pytest.mark.parametrize("n,chan", [(480000, 2), (262144, 2), (48001, 2), (30001, 1), (2048, 2)])
+def test_logmel_wave_kernel_vs_general_kernel(dev, n, chan, monkeypatch):
+    """The AFx-Rep front end runs k_logmel_wave (one wave per frame, FFT in registers, hops shared between frames); the
+    general kernel (any n_fft, one workgroup per frame) stays behind STITO_LOGMEL_GENERIC=1.  Same windowed samples, same
+    unpack and mel sums, different butterfly order: equal to float32 FFT rounding (1e-5 of the [-1, 1] scale except
+    where the power is at the clamp), on lengths that are / are not multiples of the hop, odd lengths (unaligned right
+    channel: the scalar load path), mono, and the shortest input (every hop reflected)."""
+    om, pm = _models(dev, "minmax")
+    x = torch.stack([O.synth_audio(11 + i, chan, n) * (0.9 if i == 0 else 0.05) for i in range(3)]).to(dev)
+    monkeypatch.setenv("STITO_LOGMEL_GENERIC", "1")
+    ref = pm.logmel(x).cpu().numpy()
+    monkeypatch.setenv("STITO_LOGMEL_GENERIC", "0")
+    got = pm.logmel(x).cpu().numpy()
+    assert got.shape == ref.shape == (3 * chan, n // 1024 + 1, 128) and np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-5
+
+
 @pytest.mark.parametrize("n_fft,hop,mels", [(1024, 512, 64), (512, 128, 40), (4096, 2048, 128)])
 def test_logmel_other_window_sizes(dev, n_fft, hop, mels):
     """Front ends other than the AFx-Rep one: log2(n_fft/2) odd (a radix-2 stage in front of the radix-4 ones)

@@ -539,3 +539,22 @@ def test_compressor_scan_ring_registers_are_out_of_the_compilers_reach(tmp_path)
             highest = max(highest, int(a or b))
     assert n_asm >= 3, "the ring's asm statements are gone: update this check"
     assert 0 <= highest < 100, f"compiler-allocated code of k_comp_blockscan reaches v{highest}: it would clobber the ring (v100+)"
+
+
+def test_cmaes_prefetch_does_not_change_the_run():
+    """prefetch() only moves the draw of the next generation's normals ahead of tell(): same generator, same order."""
+    from st_ito.cmaes import CMAEvolutionStrategy
+
+    def run(prefetch):
+        es = CMAEvolutionStrategy(np.full(7, 0.5), 0.3, {"bounds": [0, 1], "popsize": 12, "seed": 5})
+        for _ in range(6):
+            W = es.ask()
+            if prefetch:
+                es.prefetch()
+                es.prefetch()  # idempotent until the next ask()
+            es.tell(W, [float(np.sum((w - 0.3) ** 2)) for w in W])
+        return np.asarray(es.ask()), es.result[0]
+
+    a, ra = run(False)
+    b, rb = run(True)
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
