@@ -83,7 +83,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "st-ito_amd", "csrc")
-    for name in ("cnn14.hip", "conv_wino43.hip", "conv_layout.h", "common.h"):
+    for name in ("cnn14.hip", "conv_wino43.hip", "conv_direct_split.hip", "conv_layout.h", "common.h"):
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 

@@ -79,10 +79,10 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 5 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+/* ABI version: 6 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
- * _F4_SPLITK, stito_conv_timing_read_each). */
+ * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -207,7 +207,13 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * input): for the layers below 256 output channels, whose activations are large and whose channel loops are short.
         * A chunk of 4 input channels fills one f16 MFMA of depth 16 with hi hi' + hi lo' + lo hi'.  cin % 8 == 0,
         * cout % 64 == 0; own packing; workspace = one word per stream. */
-       STITO_CONV_WINOGRAD_F4_SPLITK = 6 };
+       STITO_CONV_WINOGRAD_F4_SPLITK = 6,
+       /* DIRECT implicit GEMM on the f16 matrix pipe with the same split operands (f16 hi + lo, three products, f32 accumulate):
+        * 9 MACs per output at 3 / 16 of the f32 pipe's price are 1.7 f32-pipe equivalents against F(4x4,3x3)'s 2.25, with no
+        * transform, no 36-position exchange and 576 MACs per input element copied into LDS -- for the layers whose maps are
+        * large and whose channel loops are short (conv_block1 - conv_block4.conv1).  cin % 16 == 0, cout % 64 == 0, maps at
+        * least 16 wide; own packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 6). */
+       STITO_CONV_DIRECT_SPLIT = 7 };
 
 typedef struct {
     int32_t embed_dim;
@@ -219,7 +225,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2 or _F4_SPLITK */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2, _F4_SPLITK or STITO_CONV_DIRECT_SPLIT */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */

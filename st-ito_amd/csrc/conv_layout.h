@@ -100,6 +100,14 @@ int launch_wino43_split2(const float *in, const float *upk, const float *scale, 
                          bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+// conv_direct_split.hip: direct implicit GEMM on the f16 matrix pipe, f32 operands as f16 hi + lo (the layers up to conv_block4.conv1)
+bool dsplit_supported(const ConvShape &c, bool pool);
+double dsplit_issued_flops(const ConvShape &c, bool pool);
+size_t dsplit_workspace_bytes(const ConvShape &c, bool pool);  // per-stream maxima of the input when the caller has none
+size_t dsplit_packed_floats(int cout, int cin);
+int pack_dsplit(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
+int launch_dsplit(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c, bool pool,
+                  void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv
 int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st);
 int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,

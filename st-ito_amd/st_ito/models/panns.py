@@ -138,6 +138,10 @@ class Cnn14(nn.Module):
         # kernel today: with the matrix pipe out of the way its period (~1 300 cycles of work) is shorter than the HBM latency
         # of the halo-patch copies, which the one-period prefetch of the f32 schedule no longer hides
         self.conv_splitk_max_cout = int(os.environ.get("STITO_CONV_SPLITK_MAX_COUT", "0"))
+        # layers with at most this many INPUT channels (and cin % 16 == 0) run the DIRECT form on the f16 pipe with the same split
+        # operands (CONV_DIRECT_SPLIT): 9 MACs per output at 3 / 16 of the f32 pipe's price, no transform, no exchange epilogue,
+        # 576 MACs per input element copied into LDS -- the large maps with short channel loops (0 = never)
+        self.conv_dsplit_max_cin = int(os.environ.get("STITO_CONV_DSPLIT_MAX_CIN", "0"))
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -190,6 +194,8 @@ class Cnn14(nn.Module):
                         algo = _hip.CONV_WINOGRAD_F4_SPLIT2
                     if not split and not pre and self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cout <= self.conv_splitk_max_cout:
                         algo = _hip.CONV_WINOGRAD_F4_SPLITK
+                    if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cin % 16 == 0 and cin <= self.conv_dsplit_max_cin:
+                        algo = _hip.CONV_DIRECT_SPLIT
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)
                     _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()

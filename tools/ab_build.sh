@@ -6,10 +6,10 @@ cd "$(dirname "$0")/../st-ito_amd/csrc"
 make -j4 > /dev/null
 tag=$1; shift
 mkdir -p build/ab ../st_ito/_lib/ab
-for f in conv_wino43 cnn14 frontend; do
+for f in conv_wino43 conv_direct_split cnn14 frontend; do
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $f.hip -o build/ab/${f}_$tag.o &
 done
 wait
-objs=$(ls build/*.o | grep -v -e conv_wino43.o -e cnn14.o -e frontend.o)
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../st_ito/_lib/ab/libstito_hip_$tag.so $objs build/ab/conv_wino43_$tag.o build/ab/cnn14_$tag.o build/ab/frontend_$tag.o
+objs=$(ls build/*.o | grep -v -e conv_wino43.o -e conv_direct_split.o -e cnn14.o -e frontend.o)
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../st_ito/_lib/ab/libstito_hip_$tag.so $objs build/ab/conv_wino43_$tag.o build/ab/conv_direct_split_$tag.o build/ab/cnn14_$tag.o build/ab/frontend_$tag.o
 echo built ../st_ito/_lib/ab/libstito_hip_$tag.so
