@@ -28,7 +28,10 @@ __device__ __forceinline__ void one(int i, f32x4 &a, f32x4 &b, f32x2 &p, f32x2 &
     }
 }
 
-template <int K, int TYPE, int MW>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+// F16 = true: the same experiment around v_mfma_f32_32x32x16_f16 (8 passes = 32 cycles of matrix pipe): what may a wave issue in
+// the shadow of the split-precision kernels' MFMAs?
+template <int K, int TYPE, int MW, bool F16 = false>
 __global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -38,6 +41,8 @@ __global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res
     for (int j = 0; j < 8; ++j)
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float av = 1.0f + lane * 1e-3f, bv = 0.5f;
+    h8 ah, bh;
+    for (int i = 0; i < 8; ++i) { ah[i] = (_Float16)(1.0f + lane * 1e-3f); bh[i] = (_Float16)0.5f; }
     f32x4 a = {1.f, 2.f, 3.f, 4.f}, b = {1e-3f, 1.f, 1e-3f, 1.f};
     f32x2 p = {1.f, 2.f}, q = {1e-3f, 1.f};
     const unsigned addr = wv * 1024 + lane * 16;
@@ -45,7 +50,8 @@ __global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res
     for (int it = 0; it < nm / 8; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(av), "v"(bv));
+            if (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(ah), "v"(bh));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(av), "v"(bv));
 #pragma unroll
             for (int i = 0; i < K; ++i) one<TYPE>(j * K + i, a, b, p, q, addr);
         }
@@ -59,19 +65,30 @@ __global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res
     if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; }
 }
 
-template <int K, int TYPE, int MW>
+template <int K, int TYPE, int MW, bool F16 = false>
 static void run(int nm, float *out, long long *res_d) {
-    hipFuncSetAttribute((const void *)k<K, TYPE, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipFuncSetAttribute((const void *)k<K, TYPE, MW, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     long long res[16];
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL((k<K, TYPE, MW>), dim3(256), dim3(256 * MW), 64 * 1024, 0, nm, out, res_d);
+        hipLaunchKernelGGL((k<K, TYPE, MW, F16>), dim3(256), dim3(256 * MW), 64 * 1024, 0, nm, out, res_d);
         hipDeviceSynchronize();
     }
     hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
     long long lo = res[0], hi = res[1];
     for (int w = 0; w < 4 * MW; ++w) { lo = res[2 * w] < lo ? res[2 * w] : lo; hi = res[2 * w + 1] > hi ? res[2 * w + 1] : hi; }
     static const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "ds_read_b128", "ds_write_b128", "v_add_f32", "mix rd/add/sub/wr"};
-    printf("%-18s K=%2d waves/SIMD=%d : %7.1f cyc per MFMA slot (64 = pipe-bound)\n", names[TYPE], K, MW, (double)(hi - lo) / ((double)nm * MW));
+    printf("%-18s K=%2d waves/SIMD=%d : %7.1f cyc per MFMA slot (%s)\n", names[TYPE], K, MW, (double)(hi - lo) / ((double)nm * MW),
+           F16 ? "f16 32x32x16: 32 = pipe-bound" : "64 = pipe-bound");
+}
+template <int TYPE, int MW>
+static void sweep16(int nm, float *out, long long *res_d) {
+    run<0, TYPE, MW, true>(nm, out, res_d);
+    run<1, TYPE, MW, true>(nm, out, res_d);
+    run<2, TYPE, MW, true>(nm, out, res_d);
+    run<3, TYPE, MW, true>(nm, out, res_d);
+    run<4, TYPE, MW, true>(nm, out, res_d);
+    run<6, TYPE, MW, true>(nm, out, res_d);
+    run<8, TYPE, MW, true>(nm, out, res_d);
 }
 
 template <int TYPE, int MW>
@@ -101,5 +118,13 @@ int main() {
     sweep<3, 2>(nm, out, res_d);
     sweep<5, 1>(nm, out, res_d);
     sweep<5, 2>(nm, out, res_d);
+    printf("---- around v_mfma_f32_32x32x16_f16 ----\n");
+    sweep16<0, 1>(nm, out, res_d);
+    sweep16<0, 2>(nm, out, res_d);
+    sweep16<1, 2>(nm, out, res_d);
+    sweep16<2, 1>(nm, out, res_d);
+    sweep16<2, 2>(nm, out, res_d);
+    sweep16<3, 2>(nm, out, res_d);
+    sweep16<5, 2>(nm, out, res_d);
     return 0;
 }
