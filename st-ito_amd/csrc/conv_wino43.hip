@@ -1063,7 +1063,7 @@ __global__ void k_pack_wino43h(const float *__restrict__ w, int Cout, int Cin, c
 }
 
 #ifndef S43B_ABL
-#define S43B_ABL 0  // timing experiment: 1 = no main loop in k_conv_wino43s / s2 (prologue + epilogue(s) only); 0 in every build that ships
+#define S43B_ABL 0  // timing experiment (k_conv_wino43s / s2): 1 = no main loop (prologue + epilogue(s) only), 2 = no slab copies in the loop, 4 = no operand reads / MFMAs; 0 in every build that ships
 #endif
 // ---- split-precision streaming convolution ----------------------------------------------------------------------------
 // The same convolution as MODE 1 (transformed input and weights both streamed), on the f16 matrix pipe: every f32 operand x
@@ -1132,15 +1132,17 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         constexpr int BUF_ = (K18) % 3, NB_ = ((K18) + 2) % 3;                                            \
         constexpr int Q0_ = (2 * ((K18) % 9)) % 9, Q1_ = (2 * ((K18) % 9) + 1) % 9;                       \
         const bool mine_ = set == ((K18) & 1);                                                            \
-        if (mine_ && (SL) + 2 < n_slabs) { S43_ISSUE((SL) + 2, NB_) }                                     \
+        if (!(S43B_ABL & 2) && mine_ && (SL) + 2 < n_slabs) { S43_ISSUE((SL) + 2, NB_) }                  \
         const char *pa_ = a_rd + BUF_ * S43_SLAB, *pb_ = b_rd + BUF_ * S43_SLAB;                          \
         const h8 ah0 = *(const h8 *)(pa_), al0 = *(const h8 *)(pa_ + 1024);                               \
         const h8 bh0 = *(const h8 *)(pb_), bl0 = *(const h8 *)(pb_ + 2048);                               \
         const h8 ah1 = *(const h8 *)(pa_ + 2048), al1 = *(const h8 *)(pa_ + 3072);                        \
         const h8 bh1 = *(const h8 *)(pb_ + 4096), bl1 = *(const h8 *)(pb_ + 6144);                        \
+        if (!(S43B_ABL & 4)) {                                                                            \
         S43_MFMA(Q0_, al0, bh0) S43_MFMA(Q1_, al1, bh1)                                                   \
         S43_MFMA(Q0_, ah0, bl0) S43_MFMA(Q1_, ah1, bl1)                                                   \
         S43_MFMA(Q0_, ah0, bh0) S43_MFMA(Q1_, ah1, bh1)                                                   \
+        }                                                                                                 \
         if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
         W43_BARRIER()                                                                                     \
     }
@@ -1213,9 +1215,9 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
     {                                                                                                    \
         constexpr int BUF_ = (K6) % 3, NB_ = ((K6) + 2) % 3, SUB_ = (K6) % 3;                             \
         const bool mine_ = set == ((K6) & 1);                                                             \
-        if (mine_ && (SL) + 2 < n_slabs) { S43B_ISSUE((SL) + 2, NB_) }                                    \
+        if (!(S43B_ABL & 2) && mine_ && (SL) + 2 < n_slabs) { S43B_ISSUE((SL) + 2, NB_) }                 \
         const char *pa_ = a_rd + BUF_ * S43B_SLAB, *pb_ = b_rd + BUF_ * S43B_SLAB;                        \
-        S43B_BLOCK(0, 3 * SUB_) S43B_BLOCK(1, 3 * SUB_ + 1) S43B_BLOCK(2, 3 * SUB_ + 2)                   \
+        if (!(S43B_ABL & 4)) { S43B_BLOCK(0, 3 * SUB_) S43B_BLOCK(1, 3 * SUB_ + 1) S43B_BLOCK(2, 3 * SUB_ + 2) } \
         if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
         W43_BARRIER()                                                                                     \
     }

@@ -156,8 +156,12 @@ __device__ __forceinline__ void glds16(const char *sbase, unsigned voff, unsigne
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 // WORK bit 0: ds_read_b128 of the operands, bit 1: MFMAs (3 per block, SLAB / 24 KB blocks per period and wave)
+// pd > 0 (pattern 3 only): L2 prefetch by touch -- in the period in which it issues slab k + NSETS, a workgroup also touches (one
+// dword per 128-byte line, result discarded) ITS SHARE of the lines of slab k + NSETS + pd: 1 / 8 of the input part (the 8
+// workgroups of the XCD round that stream the same input) and 1 / 4 of the weight part, so that every line of the round's
+// streams is requested from the fabric once, pd periods before the LDS-DMA copies want it.
 template <int WORK, int SLAB, int NRING>
-__global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc, int pattern, int n_periods, float *out, long long *res) {
+__global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc, int pattern, int n_periods, float *out, long long *res, int pd) {
     constexpr int NSETS = NRING - 1, WPS = 8 / NSETS, PIECES = SLAB / 1024, PPW = PIECES / WPS, VPART = SLAB / 3, NBLK = SLAB / (24 * 1024);
     static_assert(PIECES % WPS == 0 && VPART % 1024 == 0, "");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,6 +190,19 @@ __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc
                                                : ubase + (long long)(S) * (SLAB - VPART) + (piece - VPART / 1024) * 1024; \
         glds16(src, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * SLAB + piece * 1024));                 \
     }
+    unsigned touched = 0;
+    constexpr int VL = VPART / 128 / 8, UL = (SLAB - VPART) / 128 / 4, TPW = (VL + UL + WPS - 1) / WPS;  // lines per workgroup, per wave
+    static_assert(TPW <= 64, "");
+    const int tl = ws * TPW + lane;  // this lane's line of the workgroup's share
+    const bool t_on = pd > 0 && lane < TPW && tl < VL + UL;
+    const long long t_off = tl < VL ? ((r & 7) * VL + tl) * 128ll : ((r >> 3) * UL + (tl - VL)) * 128ll;
+    const char *t_base = tl < VL ? vbase : ubase;
+    const long long t_stride = tl < VL ? VPART : SLAB - VPART;
+#define TOUCH(S)                                                                                           \
+    if (t_on && (S) < n_periods) {                                                                         \
+        const char *p_ = t_base + (long long)(S) * t_stride + t_off;                                       \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(p_) : "memory");               \
+    }
     for (int s0 = 0; s0 < NSETS; ++s0)
         if (set == s0) { ISSUE(s0, s0) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc
     for (int k = 0; k < n_periods; ++k) {
         const bool mine = turn == set;
         int nb = buf + NSETS; nb = nb >= NRING ? nb - NRING : nb;
-        if (mine && k + NSETS < n_periods) { ISSUE(k + NSETS, nb) }
+        if (mine && k + NSETS < n_periods) { ISSUE(k + NSETS, nb) TOUCH(k + NSETS + pd) }
         if (WORK & 1) {
 #pragma unroll
             for (int q = 0; q < NBLK; ++q) {
@@ -215,13 +232,18 @@ __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc
         }
         // the set that issues next period must have its previous slab landed
         int nt = turn + 1; nt = nt == NSETS ? 0 : nt;
-        if (nt == set) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nt == set) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(touched));  // the touch's destination register stays reserved until it has landed
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         buf = buf == NRING - 1 ? 0 : buf + 1;
         turn = nt;
     }
     const long long t1 = __builtin_readcyclecounter();
-    float s = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(touched));
+    float s = (float)(touched & 1);
     for (int q = 0; q < 2; ++q)
         for (int i = 0; i < 16; ++i) s += acc[q][i];
     out[(size_t)blockIdx.x * 512 + tid] = s;
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(512) void k_fill(const char *vsrc, const char *usrc
 }
 
 template <int WORK, int SLAB, int NRING>
-static void fill(const char *vsrc, const char *usrc, int pattern, long long bytes_per_wg, int blocks, float *out, long long *res_d) {
+static void fill(const char *vsrc, const char *usrc, int pattern, long long bytes_per_wg, int blocks, float *out, long long *res_d, int pd = 0) {
     const int n_periods = (int)(bytes_per_wg / SLAB);
     hipFuncSetAttribute((const void *)k_fill<WORK, SLAB, NRING>, hipFuncAttributeMaxDynamicSharedMemorySize, NRING * SLAB);
     std::vector<long long> res(2 * blocks);
@@ -238,7 +260,7 @@ static void fill(const char *vsrc, const char *usrc, int pattern, long long byte
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_fill<WORK, SLAB, NRING>), dim3(blocks), dim3(512), NRING * SLAB, 0, vsrc, usrc, pattern, n_periods, out, res_d);
+        hipLaunchKernelGGL((k_fill<WORK, SLAB, NRING>), dim3(blocks), dim3(512), NRING * SLAB, 0, vsrc, usrc, pattern, n_periods, out, res_d, pd);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1);
@@ -253,6 +275,7 @@ static void fill(const char *vsrc, const char *usrc, int pattern, long long byte
     }
     static const char *pn[] = {"own streams", "XCD round 4 x 8 (same)", "one stream", "XCD round 4 x 8 (fresh)"};
     const double bytes = (double)blocks * n_periods * SLAB;
+    if (pd) printf("[touch-prefetch %d periods ahead] ", pd);
     printf("fill work=%d slab %2d KB x %d %-24s: %7.1f cycles per period (max %7.1f) = %5.1f B/clk/CU;  %.3f ms, %.2f TB/s into LDS\n", WORK,
            SLAB / 1024, NRING, pn[pattern], sum / blocks, mx, SLAB / (sum / blocks), ms, bytes / ms / 1e9);
 }
@@ -283,6 +306,18 @@ int main(int argc, char **argv) {
             fill<3, 24 * 1024, 3>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
             fill<3, 24 * 1024, 5>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
             fill<0, 24 * 1024, 5>(vsrc, usrc, pattern, bytes_per_wg, blocks, out, res_d);
+        }
+    }
+    if (what & 8) {  // L2 prefetch by touch under the real kernel's sharing pattern
+        const long long bytes_per_wg = 288ll * 48 * 1024;
+        const int blocks = 1024;
+        char *vsrc, *usrc;
+        const size_t vbytes = (size_t)256 * bytes_per_wg / 3, ubytes = (size_t)256 * bytes_per_wg * 2 / 3;
+        hipMalloc(&vsrc, vbytes); hipMalloc(&usrc, ubytes);
+        hipMemset(vsrc, 0, vbytes); hipMemset(usrc, 0, ubytes);
+        for (int pd : {0, 1, 2, 3, 4, 6, 8}) {
+            fill<3, 48 * 1024, 3>(vsrc, usrc, 3, bytes_per_wg, blocks, out, res_d, pd);
+            fill<0, 48 * 1024, 3>(vsrc, usrc, 3, bytes_per_wg, blocks, out, res_d, pd);
         }
     }
     return 0;
