@@ -1127,22 +1127,56 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43_SLAB + piece_ * 1024)); \
     }
 #define S43_MFMA(Q, A_, B_) acc[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc[Q], 0, 0, 0);
+// S43_ILV (default): the period as a fixed interleave, one piece per MFMA gap (sched_barrier between gaps, every MFMA pinned:
+// DESIGN.md 4.1(4)): at most two operand reads between two MFMAs (the rate at which tools/ubench/mfma_interleave.hip shows
+// them free) instead of the whole period's reads at its top behind the barrier, the last block of a slab multiplied at the top
+// of the NEXT period from registers (ahP ..) while that period's first reads are in flight, and the issuing set's copies in
+// three groups between products instead of ahead of them.  Measured (conv_bench, 512 streams): the five two-sweep layers
+// 13.07 -> 12.64 ms, profiles/README.md.
+#ifndef S43_ILV
+#define S43_ILV 1
+#endif
+#define S43_MFMA_P(Q, A_, B_) asm volatile("" : "+v"(acc[Q])); S43_MFMA(Q, A_, B_) asm volatile("" : "+v"(acc[Q]));
+#define S43_GAP() __builtin_amdgcn_sched_barrier(0);
+#define S43_ISSUE_R(SL, BUF, C0_, C1_)                                                                   \
+    _Pragma("unroll") for (int c_ = (C0_); c_ < (C1_); ++c_) {                                            \
+        const int piece_ = w4 * 12 + c_;                                                                  \
+        const char *src_ = piece_ < 16 ? vbase + (int64_t)(SL) * S43_VPART + piece_ * 1024                \
+                                       : ubase + (int64_t)(SL) * S43_UPART + (piece_ - 16) * 1024;        \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43_SLAB + piece_ * 1024)); \
+    }
 #define S43_PERIOD(K18, SL)                                                                              \
     {                                                                                                    \
         constexpr int BUF_ = (K18) % 3, NB_ = ((K18) + 2) % 3;                                            \
         constexpr int Q0_ = (2 * ((K18) % 9)) % 9, Q1_ = (2 * ((K18) % 9) + 1) % 9;                       \
+        constexpr int QP_ = (2 * (((K18) + 8) % 9) + 1) % 9;   /* block 1 of the period before */         \
         const bool mine_ = set == ((K18) & 1);                                                            \
-        if (!(S43B_ABL & 2) && mine_ && (SL) + 2 < n_slabs) { S43_ISSUE((SL) + 2, NB_) }                  \
+        const bool iss_ = !(S43B_ABL & 2) && mine_ && (SL) + 2 < n_slabs;                                 \
         const char *pa_ = a_rd + BUF_ * S43_SLAB, *pb_ = b_rd + BUF_ * S43_SLAB;                          \
-        const h8 ah0 = *(const h8 *)(pa_), al0 = *(const h8 *)(pa_ + 1024);                               \
-        const h8 bh0 = *(const h8 *)(pb_), bl0 = *(const h8 *)(pb_ + 2048);                               \
-        const h8 ah1 = *(const h8 *)(pa_ + 2048), al1 = *(const h8 *)(pa_ + 3072);                        \
-        const h8 bh1 = *(const h8 *)(pb_ + 4096), bl1 = *(const h8 *)(pb_ + 6144);                        \
-        if (!(S43B_ABL & 4)) {                                                                            \
-        S43_MFMA(Q0_, al0, bh0) S43_MFMA(Q1_, al1, bh1)                                                   \
-        S43_MFMA(Q0_, ah0, bl0) S43_MFMA(Q1_, ah1, bl1)                                                   \
-        S43_MFMA(Q0_, ah0, bh0) S43_MFMA(Q1_, ah1, bh1)                                                   \
-        }                                                                                                 \
+        if (!S43_ILV) {                                                                                   \
+            if (iss_) { S43_ISSUE((SL) + 2, NB_) }                                                        \
+            const h8 ah0 = *(const h8 *)(pa_), al0 = *(const h8 *)(pa_ + 1024);                           \
+            const h8 bh0 = *(const h8 *)(pb_), bl0 = *(const h8 *)(pb_ + 2048);                           \
+            const h8 ah1 = *(const h8 *)(pa_ + 2048), al1 = *(const h8 *)(pa_ + 3072);                    \
+            const h8 bh1 = *(const h8 *)(pb_ + 4096), bl1 = *(const h8 *)(pb_ + 6144);                    \
+            if (!(S43B_ABL & 4)) {                                                                        \
+            S43_MFMA(Q0_, al0, bh0) S43_MFMA(Q1_, al1, bh1)                                               \
+            S43_MFMA(Q0_, ah0, bl0) S43_MFMA(Q1_, ah1, bl1)                                               \
+            S43_MFMA(Q0_, ah0, bh0) S43_MFMA(Q1_, ah1, bh1)                                               \
+            }                                                                                             \
+        } else if (!(S43B_ABL & 4)) {                                                                     \
+            h8 ah0, al0, bh0, bl0;                                                                        \
+            const bool prev_ = (SL) > 0;                                                                  \
+            S43_GAP()                                                                                     \
+            if (prev_) { S43_MFMA_P(QP_, alP, bhP) } ah0 = *(const h8 *)(pa_); al0 = *(const h8 *)(pa_ + 1024); S43_GAP() \
+            if (prev_) { S43_MFMA_P(QP_, ahP, blP) } bh0 = *(const h8 *)(pb_); bl0 = *(const h8 *)(pb_ + 2048); \
+                if (iss_) { S43_ISSUE_R((SL) + 2, NB_, 0, 4) } S43_GAP()                                  \
+            if (prev_) { S43_MFMA_P(QP_, ahP, bhP) } ahP = *(const h8 *)(pa_ + 2048); alP = *(const h8 *)(pa_ + 3072); S43_GAP() \
+            S43_MFMA_P(Q0_, al0, bh0) bhP = *(const h8 *)(pb_ + 4096); blP = *(const h8 *)(pb_ + 6144);   \
+                if (iss_) { S43_ISSUE_R((SL) + 2, NB_, 4, 8) } S43_GAP()                                  \
+            S43_MFMA_P(Q0_, ah0, bl0) if (iss_) { S43_ISSUE_R((SL) + 2, NB_, 8, 12) } S43_GAP()           \
+            S43_MFMA_P(Q0_, ah0, bh0) S43_GAP()                                                           \
+        } else if (iss_) { S43_ISSUE((SL) + 2, NB_) }                                                     \
         if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
         W43_BARRIER()                                                                                     \
     }
@@ -1150,10 +1184,14 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
+    h8 ahP, alP, bhP, blP;  // S43_ILV: operands of the previous period's second block
     for (int sl = 0; sl < ((S43B_ABL & 1) ? 0 : n_slabs); sl += 18) {  // Cin % 64 == 0
         S43_PERIOD(0, sl) S43_PERIOD(1, sl + 1) S43_PERIOD(2, sl + 2) S43_PERIOD(3, sl + 3) S43_PERIOD(4, sl + 4) S43_PERIOD(5, sl + 5)
         S43_PERIOD(6, sl + 6) S43_PERIOD(7, sl + 7) S43_PERIOD(8, sl + 8) S43_PERIOD(9, sl + 9) S43_PERIOD(10, sl + 10) S43_PERIOD(11, sl + 11)
         S43_PERIOD(12, sl + 12) S43_PERIOD(13, sl + 13) S43_PERIOD(14, sl + 14) S43_PERIOD(15, sl + 15) S43_PERIOD(16, sl + 16) S43_PERIOD(17, sl + 17)
+    }
+    if (S43_ILV && !(S43B_ABL & 5)) {  // the last period's second block (n_slabs % 18 == 0: accumulator 8)
+        S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
     }
     w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
 }
@@ -1211,13 +1249,39 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
         const h8 bh_ = *(const h8 *)(pb_ + (T_) * 8192), bl_ = *(const h8 *)(pb_ + (T_) * 8192 + 2048);   \
         S43_MFMA(Q_, al_, bh_) S43_MFMA(Q_, ah_, bl_) S43_MFMA(Q_, ah_, bh_)                              \
     }
+// S43_ILV as in k_conv_wino43s: block 2 of a slab waits in registers for the next period
+#define S43B_ISSUE_R(SL, BUF, C0_, C1_)                                                                  \
+    _Pragma("unroll") for (int c_ = (C0_); c_ < (C1_); ++c_) {                                            \
+        const int piece_ = w4 * 12 + c_;                                                                  \
+        const char *src_ = piece_ < 24 ? vbase + (int64_t)(SL) * S43B_PART + piece_ * 1024                \
+                                       : ubase + (int64_t)(SL) * S43B_PART + (piece_ - 24) * 1024;        \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43B_SLAB + piece_ * 1024)); \
+    }
+#define S43B_LDA(T_, H_, L_) H_ = *(const h8 *)(pa_ + (T_) * 8192); L_ = *(const h8 *)(pa_ + (T_) * 8192 + 2048);
+#define S43B_LDB(T_, H_, L_) H_ = *(const h8 *)(pb_ + (T_) * 8192); L_ = *(const h8 *)(pb_ + (T_) * 8192 + 2048);
 #define S43B_PERIOD(K6, SL)                                                                              \
     {                                                                                                    \
-        constexpr int BUF_ = (K6) % 3, NB_ = ((K6) + 2) % 3, SUB_ = (K6) % 3;                             \
+        constexpr int BUF_ = (K6) % 3, NB_ = ((K6) + 2) % 3, SUB_ = (K6) % 3, QP_ = 3 * (((K6) + 2) % 3) + 2; \
         const bool mine_ = set == ((K6) & 1);                                                             \
-        if (!(S43B_ABL & 2) && mine_ && (SL) + 2 < n_slabs) { S43B_ISSUE((SL) + 2, NB_) }                 \
+        const bool iss_ = !(S43B_ABL & 2) && mine_ && (SL) + 2 < n_slabs;                                 \
         const char *pa_ = a_rd + BUF_ * S43B_SLAB, *pb_ = b_rd + BUF_ * S43B_SLAB;                        \
-        if (!(S43B_ABL & 4)) { S43B_BLOCK(0, 3 * SUB_) S43B_BLOCK(1, 3 * SUB_ + 1) S43B_BLOCK(2, 3 * SUB_ + 2) } \
+        if (!S43_ILV) {                                                                                   \
+            if (iss_) { S43B_ISSUE((SL) + 2, NB_) }                                                       \
+            if (!(S43B_ABL & 4)) { S43B_BLOCK(0, 3 * SUB_) S43B_BLOCK(1, 3 * SUB_ + 1) S43B_BLOCK(2, 3 * SUB_ + 2) } \
+        } else if (!(S43B_ABL & 4)) {                                                                     \
+            h8 ah0, al0, bh0, bl0, ah1, al1, bh1, bl1;                                                    \
+            const bool prev_ = (SL) > 0;                                                                  \
+            S43_GAP()                                                                                     \
+            if (prev_) { S43_MFMA_P(QP_, alP, bhP) } S43B_LDA(0, ah0, al0) S43_GAP()                       \
+            if (prev_) { S43_MFMA_P(QP_, ahP, blP) } S43B_LDB(0, bh0, bl0) S43_GAP()                       \
+            if (prev_) { S43_MFMA_P(QP_, ahP, bhP) } S43B_LDA(1, ah1, al1) if (iss_) { S43B_ISSUE_R((SL) + 2, NB_, 0, 4) } S43_GAP() \
+            S43_MFMA_P(3 * SUB_, al0, bh0) S43B_LDB(1, bh1, bl1) S43_GAP()                                \
+            S43_MFMA_P(3 * SUB_, ah0, bl0) S43B_LDA(2, ahP, alP) if (iss_) { S43B_ISSUE_R((SL) + 2, NB_, 4, 8) } S43_GAP() \
+            S43_MFMA_P(3 * SUB_, ah0, bh0) S43B_LDB(2, bhP, blP) S43_GAP()                                \
+            S43_MFMA_P(3 * SUB_ + 1, al1, bh1) if (iss_) { S43B_ISSUE_R((SL) + 2, NB_, 8, 12) } S43_GAP()  \
+            S43_MFMA_P(3 * SUB_ + 1, ah1, bl1) S43_GAP()                                                  \
+            S43_MFMA_P(3 * SUB_ + 1, ah1, bh1) S43_GAP()                                                  \
+        } else if (iss_) { S43B_ISSUE((SL) + 2, NB_) }                                                    \
         if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
         W43_BARRIER()                                                                                     \
     }
@@ -1264,9 +1328,13 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
         if (set == 0) { S43B_ISSUE(0, 0) } else { S43B_ISSUE(1, 1) }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W43_BARRIER()
+        h8 ahP, alP, bhP, blP;  // S43_ILV: operands of the previous slab's block 2
         for (int sl = 0; sl < ((S43B_ABL & 1) ? 0 : n_slabs); sl += 6) {  // Cin % 32 == 0
             S43B_PERIOD(0, sl) S43B_PERIOD(1, sl + 1) S43B_PERIOD(2, sl + 2)
             S43B_PERIOD(3, sl + 3) S43B_PERIOD(4, sl + 4) S43B_PERIOD(5, sl + 5)
+        }
+        if (S43_ILV && !(S43B_ABL & 5)) {  // the last slab's block 2 (n_slabs % 6 == 0: local row 2 -> accumulator 8)
+            S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
         }
         // ---- this sweep's rows of Y = A^T M A, one tile half (= one 32-tile pixel block) at a time --------------------
 #pragma unroll 1
