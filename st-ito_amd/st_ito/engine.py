@@ -96,9 +96,11 @@ _WS = _Workspace()
 
 
 def render_population(plugins: Dict[str, dict], x: torch.Tensor, W: torch.Tensor, sample_rate: float,
-                      chain=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                      chain=None, out=None, ws_key: str = "render") -> Tuple[torch.Tensor, torch.Tensor]:
     """x (C, L) float32 on the GPU -- or (B, C, L): B inputs, candidate p reads input p // (P // B) --
-    W (P, D) float64 on the GPU -> (audio (P, C', L) before peak normalisation, peaks (P,))."""
+    W (P, D) float64 on the GPU -> (audio (P, C', L) before peak normalisation, peaks (P,)).
+    out: (audio, peaks) to render into (contiguous slices of a larger population's buffers); ws_key: name of the
+    workspace this call uses (two renders in flight on different streams need different ones)."""
     _hip.require_gpu()
     L = _hip.lib()
     descs, ndims = chain if chain is not None else compile_chain(plugins)
@@ -115,15 +117,19 @@ def render_population(plugins: Dict[str, dict], x: torch.Tensor, W: torch.Tensor
     if P % n_inputs:
         raise ValueError(f"population {P} is not a multiple of the number of inputs {n_inputs}")
     c_out = L.stito_chain_out_channels(descs, n_fx, C)
-    audio = torch.empty((P, c_out, n), dtype=torch.float32, device=x.device)
-    peaks = torch.empty((P,), dtype=torch.float32, device=x.device)
+    if out is None:
+        audio = torch.empty((P, c_out, n), dtype=torch.float32, device=x.device)
+        peaks = torch.empty((P,), dtype=torch.float32, device=x.device)
+    else:
+        audio, peaks = out
+        assert audio.shape == (P, c_out, n) and audio.is_contiguous() and audio.dtype == torch.float32 and peaks.shape == (P,)
     for i in range(n_fx):  # the chorus stage reads its LFO from a table that has to cover this length
         if descs[i].kind == _hip.FX_CHORUS and descs[i].aux_len < n:
             from .effects import chorus_lfo_device
             t = chorus_lfo_device(sample_rate, n, x.device)
             descs[i].aux_dev, descs[i].aux_len = t.data_ptr(), t.numel()
     need = L.stito_render_workspace_bytes(descs, n_fx, C, n, P)
-    ws = _WS.get("render", need, x.device)
+    ws = _WS.get(ws_key, need, x.device)
     _hip.check(L.stito_render_population_multi(descs, n_fx, _hip.ptr(x), n_inputs, C, n, _hip.ptr(W), P, ndims,
                                                float(sample_rate), _hip.ptr(audio), _hip.ptr(peaks), _hip.ptr(ws),
                                                ws.numel(), _hip.stream_ptr()))
