@@ -55,6 +55,30 @@ def test_error_paths(dev, pm):
         engine.render_population(bad, x[:1], torch.rand(1, 4, dtype=torch.float64, device=dev), SR)
 
 
+def test_part_populations_into_one_buffer_on_two_streams_are_the_single_call(dev):
+    """render_population(out=, ws_key=): two half populations rendered into slices of one buffer, each on its own HIP stream with its
+    own workspace (what tools/render_split_bench.py times), give bitwise the audio and peaks of one call."""
+    from st_ito import effects as E, engine
+    pp = E.make_plugins("bench5")
+    chain = engine.compile_chain(pp, False)
+    x = O.synth_audio(5, 2, 70001).to(dev)
+    W = torch.from_numpy(np.random.default_rng(3).random((6, chain[1]))).to(dev)
+    ref_a, ref_p = engine.render_population(pp, x, W, SR, chain=chain)
+    audio, peaks = torch.zeros_like(ref_a), torch.zeros_like(ref_p)
+    main = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for i, (p0, p1) in enumerate(((0, 2), (2, 6))):
+        streams[i].wait_stream(main)
+        with torch.cuda.stream(streams[i]):
+            engine.render_population(pp, x, W[p0:p1], SR, chain=chain, out=(audio[p0:p1], peaks[p0:p1]), ws_key=f"render_part{i}")
+    for s in streams:
+        main.wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(audio, ref_a) and torch.equal(peaks, ref_p)
+    with pytest.raises(AssertionError):                  # a buffer of the wrong shape is refused
+        engine.render_population(pp, x, W, SR, chain=chain, out=(audio[:3], peaks[:3]))
+
+
 def test_short_and_ragged_lengths(dev):
     """Lengths that are not multiples of any tile (scalar fallbacks), shorter than one reverb tile,
     and a single sample."""
