@@ -1109,6 +1109,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     const char *ubase = usl + (int64_t)ct * n_slabs * S43_UPART;
     const int set = wv >> 2, w4 = wv & 3, pg = wv >> 1, nh = wv & 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const char *vw = vbase + w4 * 1024, *uw = ubase + w4 * 1024;
+    const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
     const char *a_rd = (const char *)smem + pg * 2 * 2048 + lane * 16;
     const char *b_rd = (const char *)smem + S43_VPART + pg * 2 * 4096 + ((lane >> 5) * 64 + nh * 32 + (lane & 31)) * 16;
 
@@ -1119,13 +1121,11 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
 
 // slab SL -> ring buffer BUF: 48 pieces of 1 KB (0..15 transformed input, 16..47 weights), 12 per wave of the issuing set
-#define S43_ISSUE(SL, BUF)                                                                               \
-    _Pragma("unroll") for (int c_ = 0; c_ < 12; ++c_) {                                                   \
-        const int piece_ = w4 * 12 + c_;                                                                  \
-        const char *src_ = piece_ < 16 ? vbase + (int64_t)(SL) * S43_VPART + piece_ * 1024                \
-                                       : ubase + (int64_t)(SL) * S43_UPART + (piece_ - 16) * 1024;        \
-        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43_SLAB + piece_ * 1024)); \
-    }
+// slab SL -> ring buffer BUF: 48 pieces of 1 KB (0..15 transformed input, 16..47 weights), dealt round-robin to the four waves of
+// the issuing set (piece = 4 c + w4), so that WHICH stream a copy reads is a compile-time property of c: with twelve consecutive
+// pieces per wave it depended on the wave, and every copy carried ten scalar instructions of address selection in front of it --
+// issued in order, in the way of the wave's own MFMAs.  vw / uw = the wave's first piece of either part.
+#define S43_ISSUE(SL, BUF) S43_ISSUE_R(SL, BUF, 0, 12)
 #define S43_MFMA(Q, A_, B_) acc[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc[Q], 0, 0, 0);
 // S43_ILV (default): the period as a fixed interleave, one piece per MFMA gap (sched_barrier between gaps, every MFMA pinned:
 // DESIGN.md 4.1(4)): at most two operand reads between two MFMAs (the rate at which tools/ubench/mfma_interleave.hip shows
@@ -1140,10 +1140,9 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
 #define S43_GAP() __builtin_amdgcn_sched_barrier(0);
 #define S43_ISSUE_R(SL, BUF, C0_, C1_)                                                                   \
     _Pragma("unroll") for (int c_ = (C0_); c_ < (C1_); ++c_) {                                            \
-        const int piece_ = w4 * 12 + c_;                                                                  \
-        const char *src_ = piece_ < 16 ? vbase + (int64_t)(SL) * S43_VPART + piece_ * 1024                \
-                                       : ubase + (int64_t)(SL) * S43_UPART + (piece_ - 16) * 1024;        \
-        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43_SLAB + piece_ * 1024)); \
+        const char *src_ = c_ < 4 ? vw + (int64_t)(SL) * S43_VPART + c_ * 4096                            \
+                                  : uw + (int64_t)(SL) * S43_UPART + (c_ - 4) * 4096;                     \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, ldsw + (unsigned)((BUF) * S43_SLAB + c_ * 4096)); \
     }
 #define S43_PERIOD(K18, SL)                                                                              \
     {                                                                                                    \
@@ -1230,19 +1229,14 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
     const int set = wv >> 2, w4 = wv & 3, th = wv >> 2, nh = (wv >> 1) & 1, pp = wv & 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     const int l31 = lane & 31, half = lane >> 5;
+    const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
     const char *a_rd = (const char *)smem + pp * 4096 + (half * 64 + th * 32 + l31) * 16;
     const char *b_rd = (const char *)smem + S43B_PART + pp * 4096 + (half * 64 + nh * 32 + l31) * 16;
     f32x4 *my_partial = partial + (int64_t)blockIdx.x * (2 * 16 * W43_THREADS) + tid;  // [tile half][r * 4 + c][thread]
     const float u_inv = u_inv_p[0];
 
     f32x16 acc[9];
-#define S43B_ISSUE(SL, BUF)                                                                              \
-    _Pragma("unroll") for (int c_ = 0; c_ < 12; ++c_) {                                                   \
-        const int piece_ = w4 * 12 + c_;                                                                  \
-        const char *src_ = piece_ < 24 ? vbase + (int64_t)(SL) * S43B_PART + piece_ * 1024                \
-                                       : ubase + (int64_t)(SL) * S43B_PART + (piece_ - 24) * 1024;        \
-        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43B_SLAB + piece_ * 1024)); \
-    }
+#define S43B_ISSUE(SL, BUF) S43B_ISSUE_R(SL, BUF, 0, 12)
 #define S43B_BLOCK(T_, Q_)                                                                               \
     {                                                                                                    \
         const h8 ah_ = *(const h8 *)(pa_ + (T_) * 8192), al_ = *(const h8 *)(pa_ + (T_) * 8192 + 2048);   \
@@ -1250,12 +1244,11 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
         S43_MFMA(Q_, al_, bh_) S43_MFMA(Q_, ah_, bl_) S43_MFMA(Q_, ah_, bh_)                              \
     }
 // S43_ILV as in k_conv_wino43s: block 2 of a slab waits in registers for the next period
-#define S43B_ISSUE_R(SL, BUF, C0_, C1_)                                                                  \
+#define S43B_ISSUE_R(SL, BUF, C0_, C1_) /* piece = 4 c + w4 as in k_conv_wino43s: c < 6 input, else weights */ \
     _Pragma("unroll") for (int c_ = (C0_); c_ < (C1_); ++c_) {                                            \
-        const int piece_ = w4 * 12 + c_;                                                                  \
-        const char *src_ = piece_ < 24 ? vbase + (int64_t)(SL) * S43B_PART + piece_ * 1024                \
-                                       : ubase + (int64_t)(SL) * S43B_PART + (piece_ - 24) * 1024;        \
-        glds16_m0((const float *)src_, (unsigned)lane * 16u, lds0 + (unsigned)((BUF) * S43B_SLAB + piece_ * 1024)); \
+        const char *src_ = c_ < 6 ? vw + (int64_t)(SL) * S43B_PART + c_ * 4096                            \
+                                  : uw + (int64_t)(SL) * S43B_PART + (c_ - 6) * 4096;                     \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, ldsw + (unsigned)((BUF) * S43B_SLAB + c_ * 4096)); \
     }
 #define S43B_LDA(T_, H_, L_) H_ = *(const h8 *)(pa_ + (T_) * 8192); L_ = *(const h8 *)(pa_ + (T_) * 8192 + 2048);
 #define S43B_LDB(T_, H_, L_) H_ = *(const h8 *)(pb_ + (T_) * 8192); L_ = *(const h8 *)(pb_ + (T_) * 8192 + 2048);
@@ -1318,8 +1311,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 
 #pragma unroll
     for (int sweep = 0; sweep < 2; ++sweep) {
-        const char *vbase = vsl + ((int64_t)m_pair * 2 + sweep) * n_slabs * S43B_PART;
-        const char *ubase = usl + ((int64_t)ct * 2 + sweep) * n_slabs * S43B_PART;
+        const char *vw = vsl + ((int64_t)m_pair * 2 + sweep) * n_slabs * S43B_PART + w4 * 1024;
+        const char *uw = usl + ((int64_t)ct * 2 + sweep) * n_slabs * S43B_PART + w4 * 1024;
 #pragma unroll
         for (int q = 0; q < 9; ++q)
 #pragma unroll

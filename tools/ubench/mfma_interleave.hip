@@ -102,12 +102,112 @@ static void sweep(int nm, float *out, long long *res_d) {
     run<16, TYPE, MW>(nm, out, res_d);
 }
 
-int main() {
+// FED: the same density of ds_read_b128 beside v_mfma_f32_32x32x16_f16, but the reads FEED the products as in the streaming
+// convolutions: MFMA j multiplies the operand pair that was read D slots earlier (R reads per slot into a ring of D + 1 pairs;
+// R = 2: a fresh A and a fresh B per MFMA, R = 1: a fresh A, B stays), s_waitcnt lgkmcnt(R (D - 1)) in front of every MFMA.
+// Question (profiles/README.md, "What bounds the streaming convolutions' main loop"): are reads that feed MFMAs dearer than
+// independent ones?
+template <int D, int R, int MW, int DEP = 1, int PAT = 0>
+__global__ __launch_bounds__(256 * MW) void kfed(int nm, float *out, long long *res) {
+    // DEP: consecutive MFMAs that accumulate into the same registers (3 in the streaming convolutions: hi hi' + hi lo' + lo hi');
+    // PAT 1: the kernels' operand address pattern (lanes 0..31 512 contiguous bytes, lanes 32..63 1 KB behind them, the waves of
+    // a workgroup spread over a 48 KB slab) instead of lane * 16
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 16384; i += 256 * MW) lds[i] = 1e-3f * (float)(i & 255);
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    constexpr int NB = 12, SLOTS = 12;  // ring of operand pairs = slots per loop trip (compile-time indices)
+    h8 A[NB], B[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { A[b][i] = (_Float16)(1.0f + lane * 1e-3f); B[b][i] = (_Float16)0.5f; }
+    const unsigned addr = PAT == 0 ? wv * 2048 + lane * 16
+                                   : (wv & 1) * 4096 + ((lane >> 5) * 64 + ((wv >> 2) & 1) * 32 + (lane & 31)) * 16 + ((wv >> 1) & 1) * 24576;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(A[j % NB]) : "v"(addr) : "memory");
+        if (R == 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(B[j % NB]) : "v"(addr) : "memory");
+    }
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < nm / SLOTS; ++it) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            if (R * (D - 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (R * (D - 1) == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            else if (R * (D - 1) == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (R * (D - 1) == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else if (R * (D - 1) == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (R * (D - 1) == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else if (R * (D - 1) == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[(j / DEP) & 3]) : "v"(A[j % NB]), "v"(B[j % NB]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(A[(j + D) % NB]) : "v"(addr) : "memory");
+            if (R == 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(B[(j + D) % NB]) : "v"(addr) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s += (float)A[b][0] + (float)B[b][1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * 512 + tid] = s;
+    if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; }
+}
+
+template <int D, int R, int MW, int DEP = 1, int PAT = 0>
+static void run_fed(int nm, float *out, long long *res_d) {
+    nm = nm / 12 * 12;
+    hipFuncSetAttribute((const void *)kfed<D, R, MW, DEP, PAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    long long res[16];
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((kfed<D, R, MW, DEP, PAT>), dim3(256), dim3(256 * MW), 64 * 1024, 0, nm, out, res_d);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+    long long lo = res[0], hi = res[1];
+    for (int w = 0; w < 4 * MW; ++w) { lo = res[2 * w] < lo ? res[2 * w] : lo; hi = res[2 * w + 1] > hi ? res[2 * w + 1] : hi; }
+    printf("reads FEED the MFMAs: %d ds_read_b128 per MFMA, used %d slots later, %d MFMA(s) per accumulator in a row, %s, waves/SIMD=%d : %6.1f cyc per MFMA slot (32 = pipe-bound)\n",
+           R, D, DEP, PAT ? "kernel addresses" : "lane * 16", MW, (double)(hi - lo) / ((double)nm * MW));
+}
+
+template <int R, int MW>
+static void sweep_fed(int nm, float *out, long long *res_d) {
+    run_fed<1, R, MW>(nm, out, res_d);
+    run_fed<2, R, MW>(nm, out, res_d);
+    run_fed<3, R, MW>(nm, out, res_d);
+    run_fed<4, R, MW>(nm, out, res_d);
+    run_fed<6, R, MW>(nm, out, res_d);
+}
+
+int main(int argc, char **argv) {
     float *out;
     long long *res_d;
     hipMalloc(&out, 256 * 512 * 4);
     hipMalloc(&res_d, 16 * 8);
     const int nm = 2048;
+    if (argc > 1 && argv[1][0] == 'f') {  // only the question of the reads that feed the products (independent reads for comparison)
+        run<1, 2, 2, true>(nm, out, res_d);
+        run<2, 2, 2, true>(nm, out, res_d);
+        sweep_fed<1, 2>(nm, out, res_d);
+        sweep_fed<2, 2>(nm, out, res_d);
+        sweep_fed<2, 1>(nm, out, res_d);
+        run_fed<3, 2, 2, 3, 0>(nm, out, res_d);   // dependent triples
+        run_fed<6, 2, 2, 3, 0>(nm, out, res_d);
+        run_fed<3, 2, 2, 1, 1>(nm, out, res_d);   // the kernels' address pattern
+        run_fed<3, 2, 2, 3, 1>(nm, out, res_d);   // both
+        run_fed<6, 2, 2, 3, 1>(nm, out, res_d);
+        return 0;
+    }
     sweep<0, 1>(nm, out, res_d);
     sweep<0, 2>(nm, out, res_d);
     sweep<1, 1>(nm, out, res_d);
