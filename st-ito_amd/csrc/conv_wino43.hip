@@ -37,10 +37,30 @@
 #include "conv_layout.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace stito {
 
 #ifndef W43_ABL
+#ifndef W43_CLK
+#define W43_CLK 0  // measurement build (tools/ab_build.sh clk -DW43_CLK=1): the workgroup in the middle of the grid reads s_memtime (shader
+                   // clock) and s_memrealtime (constant 100 MHz) at its start and end, the launcher prints the ratio = the clock the part
+                   // really ran at under this kernel; 0 in every build that ships
+#endif
+#if W43_CLK
+#define W43_CLK_BEGIN()                                                                                                 \
+    const bool clk_on = g.clk != nullptr && blockIdx.x == (gridDim.x >> 1) && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0; \
+    long long clk_c0 = 0, clk_r0 = 0;                                                                                   \
+    if (clk_on) { clk_c0 = (long long)__builtin_readcyclecounter(); clk_r0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+#define W43_CLK_END()                                                                                                   \
+    if (clk_on && (threadIdx.x & 63) == 0) {                                                                            \
+        g.clk[0] = clk_c0; g.clk[1] = (long long)__builtin_readcyclecounter();                                          \
+        g.clk[2] = clk_r0; g.clk[3] = (long long)__builtin_amdgcn_s_memrealtime();                                      \
+    }
+#else
+#define W43_CLK_BEGIN()
+#define W43_CLK_END()
+#endif
 #define W43_ABL 0  // timing-experiment bit mask (1 no transform, 2 no U copies, 4 no patch copies, 8 no operand reads); 0 in every build that ships
 #endif
 static constexpr int W43_THREADS = 512;
@@ -77,6 +97,7 @@ struct Wino43Geom {
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
     FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
+    long long *clk;    // W43_CLK builds only
     unsigned *amax_out;  // or NULL: per stream, the largest output of this layer as a bit pattern (atomicMax; zeroed by the caller):
                          // what the split-precision kernels scale the NEXT layer's transformed input by (w43s_vscale)
     // FUSE1 instantiation (conv_block1: the Cin = 1 first conv computed on the fly while staging the patch):
@@ -305,6 +326,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
                                                               Wino43Geom g) {
     constexpr int TTH = 32 / TTW;
     constexpr int PWC = 4 * TTW + 2;  // patch columns
+    W43_CLK_BEGIN()
     using PL = W43Patch<TTW>;
     constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
     constexpr int PFL = PL::PFL;      // floats per patch buffer
@@ -752,6 +774,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     W43_STAMP(2)
 
     w43_epilogue<TTW, POOL, false>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, 1.0f, nullptr);
+    W43_CLK_END()
     W43_STAMP(3)
 }
 
@@ -1101,6 +1124,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     const int m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
     const int n0 = ct * 64;
     if (m_blk >= g.n_mblocks) return;
+    W43_CLK_BEGIN()
     int cb;
     const int rb = fdiv(m_blk, g.fNCB, cb);
     const int vtr0 = rb * TTH, tc0 = cb * TTW;
@@ -1193,6 +1217,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
     }
     w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
+    W43_CLK_END()
 }
 
 // ---- the same on 64 x 64 workgroup tiles, in two sweeps over the positions ----------------------------------------------
@@ -1225,6 +1250,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
     const int m_pair = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
     const int n0 = ct * 64;
     if (m_pair >= g.n_mblocks) return;
+    W43_CLK_BEGIN()
     const int n_slabs = (g.Cin >> 4) * 3;
     const int set = wv >> 2, w4 = wv & 3, th = wv >> 2, nh = (wv >> 1) & 1, pp = wv & 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
@@ -1406,6 +1432,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
             }
         }
     }
+    W43_CLK_END()
 #undef A4
 #undef S4
 #undef F4
@@ -1632,6 +1659,52 @@ int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, 
     return STITO_OK;
 }
 
+#if W43_CLK
+// a ring of 256 launches, no synchronisation (the launches stay back to back); dumped when the process exits: the LAST launch of
+// every (kernel, shape), i.e. the clock after that kernel has run for as long as the caller kept launching it
+struct W43ClkLog { char what[32]; int H, W, Cin, Cout; };
+static long long *w43_clk_ring = nullptr;
+static W43ClkLog w43_clk_log[256];
+static int w43_clk_n = 0;
+static void w43_clk_dump() {
+    if (w43_clk_n == 0) return;
+    static long long v[256 * 4];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(v, w43_clk_ring, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return;
+    const int first = w43_clk_n > 256 ? w43_clk_n - 256 : 0;
+    for (int i = first; i < w43_clk_n; ++i) {
+        const W43ClkLog &l = w43_clk_log[i & 255];
+        bool last = true;  // of its (kernel, shape) in the ring
+        for (int j = i + 1; j < w43_clk_n && last; ++j) {
+            const W43ClkLog &m = w43_clk_log[j & 255];
+            last = !(m.H == l.H && m.W == l.W && m.Cin == l.Cin && m.Cout == l.Cout && strcmp(m.what, l.what) == 0);
+        }
+        if (!last) continue;
+        const long long *q = v + (i & 255) * 4;
+        const double us = (double)(q[3] - q[2]) / 100.0;
+        fprintf(stderr, "[stito clock] %-28s %dx%d %d->%d: workgroup in the middle of the grid ran %.1f us at %.0f MHz (launch %d)\n", l.what, l.H, l.W,
+                l.Cin, l.Cout, us, us > 0 ? (double)(q[1] - q[0]) / us : 0.0, i);
+    }
+}
+static long long *w43_clk_buf() {
+    if (w43_clk_ring == nullptr) {
+        if (hipMalloc(&w43_clk_ring, 256 * 4 * sizeof(long long)) != hipSuccess) return nullptr;
+        atexit(w43_clk_dump);
+    }
+    return w43_clk_ring + (w43_clk_n & 255) * 4;
+}
+static void w43_clk_report(const char *what, const ConvShape &c, hipStream_t) {
+    W43ClkLog &l = w43_clk_log[w43_clk_n & 255];
+    snprintf(l.what, sizeof(l.what), "%s", what);
+    l.H = c.H; l.W = c.W; l.Cin = c.Cin; l.Cout = c.Cout;
+    ++w43_clk_n;
+}
+#define W43_CLK_ARM(G) (G).clk = w43_clk_buf();
+#define W43_CLK_REPORT(WHAT, C, ST) w43_clk_report(WHAT, C, ST);
+#else
+#define W43_CLK_ARM(G) (G).clk = nullptr;
+#define W43_CLK_REPORT(WHAT, C, ST)
+#endif
+
 template <int TTW, bool POOL>
 static int launch_w43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                       long long *trace, hipStream_t st, unsigned *amax_out) {
@@ -1642,10 +1715,12 @@ static int launch_w43(const float *in, const float *upk, const float *scale, con
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     g.trace = trace;
     g.amax_out = amax_out;
+    W43_CLK_ARM(g)
     auto kern = trace ? k_conv_wino43<TTW, POOL, true> : k_conv_wino43<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
+    W43_CLK_REPORT("k_conv_wino43 (f32 MFMA)", c, st)
     return STITO_OK;
 }
 
@@ -1797,9 +1872,11 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv (split-precision winograd): grid");
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    W43_CLK_ARM(g)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
                        (const unsigned *)amax, u_inv);
     STITO_LAUNCH_CHECK();
+    W43_CLK_REPORT("k_conv_wino43s (f16 MFMA)", c, st)
     return STITO_OK;
 }
 
@@ -1949,9 +2026,11 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
     g.ct_group = a;
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    W43_CLK_ARM(g)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
                        (const unsigned *)amax, u_inv, partial);
     STITO_LAUNCH_CHECK();
+    W43_CLK_REPORT("k_conv_wino43s2 (f16 MFMA)", c, st)
     return STITO_OK;
 }
 

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res
     f32x4 a = {1.f, 2.f, 3.f, 4.f}, b = {1e-3f, 1.f, 1e-3f, 1.f};
     f32x2 p = {1.f, 2.f}, q = {1e-3f, 1.f};
     const unsigned addr = wv * 1024 + lane * 16;
+    const long long r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < nm / 8; ++it) {
 #pragma unroll
@@ -58,17 +59,18 @@ __global__ __launch_bounds__(256 * MW) void k(int nm, float *out, long long *res
         if (TYPE == 2 || TYPE == 3 || TYPE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     const long long t1 = __builtin_readcyclecounter();
+    const long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + p.x + p.y;
     for (int j = 0; j < 8; ++j)
         for (int r = 0; r < 16; ++r) s += acc[j][r];
     out[blockIdx.x * 512 + tid] = s;
-    if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; }
+    if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; if (wv == 0) { res[16] = r0; res[17] = r1; } }
 }
 
 template <int K, int TYPE, int MW, bool F16 = false>
 static void run(int nm, float *out, long long *res_d) {
     hipFuncSetAttribute((const void *)k<K, TYPE, MW, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    long long res[16];
+    long long res[18];
     for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL((k<K, TYPE, MW, F16>), dim3(256), dim3(256 * MW), 64 * 1024, 0, nm, out, res_d);
         hipDeviceSynchronize();
@@ -180,6 +182,74 @@ static void run_fed(int nm, float *out, long long *res_d) {
            R, D, DEP, PAT ? "kernel addresses" : "lane * 16", MW, (double)(hi - lo) / ((double)nm * MW));
 }
 
+// PHASE: the streaming convolutions' period as it is compiled (S43_ILV), in asm: 9 MFMAs in three dependent triples per wave and
+// barrier, 12 operand reads in the first six gaps, the first triple fed from the phase before.  BAR = 0: without the s_barrier.
+template <int MW, int BAR, int DATA = 0>
+__global__ __launch_bounds__(256 * MW) void kphase(int nphase, float *out, long long *res) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // DATA: the f16 values the reads fetch -- 0 ordinary, 1 all subnormal (0x0123), 2 NaN (0x7e00), 3 zeros, 4 = hi normal / lo subnormal mix
+    for (int i = tid; i < 16384; i += 256 * MW) {
+        if (DATA == 0) lds[i] = 1e-3f * (float)(i & 255);
+        else ((unsigned *)lds)[i] = DATA == 1 ? 0x01230123u : DATA == 2 ? 0x7e007e00u : DATA == 3 ? 0u : ((i >> 9) & 1 ? 0x00410023u : 0x3a833c00u);
+    }
+    __syncthreads();
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    h8 ah0, al0, bh0, bl0, ah1, al1, bh1, bl1, ahP, alP, bhP, blP;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ahP[i] = alP[i] = (_Float16)(1.0f + lane * 1e-3f); bhP[i] = blP[i] = (_Float16)0.5f; }
+    const unsigned addr = (wv & 1) * 4096 + ((lane >> 5) * 64 + ((wv >> 2) & 1) * 32 + (lane & 31)) * 16 + ((wv >> 1) & 1) * 24576;
+#define PH_RD(X, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(X) : "v"(addr) : "memory");
+#define PH_MM(Q, A_, B_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[Q]) : "v"(A_), "v"(B_));
+#define PH_WAIT(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");
+    const long long r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < nphase; ++it) {
+        PH_MM(2, alP, bhP) PH_RD(ah0, 0) PH_RD(al0, 2048)
+        PH_MM(2, ahP, blP) PH_RD(bh0, 512) PH_RD(bl0, 2560)
+        PH_MM(2, ahP, bhP) PH_RD(ah1, 8192) PH_RD(al1, 10240)
+        PH_WAIT(3) PH_MM(0, al0, bh0) PH_RD(bh1, 8704) PH_RD(bl1, 10752)
+        PH_WAIT(4) PH_MM(0, ah0, bl0) PH_RD(ahP, 16384) PH_RD(alP, 18432)
+        PH_MM(0, ah0, bh0) PH_RD(bhP, 16896) PH_RD(blP, 18944)
+        PH_WAIT(5) PH_MM(1, al1, bh1)
+        PH_WAIT(4) PH_MM(1, ah1, bl1)
+        PH_MM(1, ah1, bh1)
+        if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    const long long r1 = __builtin_amdgcn_s_memrealtime();
+    float s = (float)ah0[0] + (float)al0[0] + (float)bh0[0] + (float)bl0[0] + (float)ah1[0] + (float)al1[0] + (float)bh1[0] + (float)bl1[0];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * 512 + tid] = s;
+    if (lane == 0 && blockIdx.x == 7) { res[wv * 2] = t0; res[wv * 2 + 1] = t1; if (wv == 0) { res[16] = r0; res[17] = r1; } }
+}
+
+template <int MW, int BAR, int DATA = 0>
+static void run_phase(int nphase, float *out, long long *res_d) {
+    hipFuncSetAttribute((const void *)kphase<MW, BAR, DATA>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    long long res[18];
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((kphase<MW, BAR, DATA>), dim3(256), dim3(256 * MW), 64 * 1024, 0, nphase, out, res_d);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+    long long lo = res[0], hi = res[1];
+    for (int w = 0; w < 4 * MW; ++w) { lo = res[2 * w] < lo ? res[2 * w] : lo; hi = res[2 * w + 1] > hi ? res[2 * w + 1] : hi; }
+    static const char *dn[] = {"ordinary values", "all f16 subnormal", "NaN", "zeros", "normal / subnormal mix"};
+    const double mhz = MW == 1 ? 0.0 : (double)(res[1] - res[0]) / ((double)(res[17] - res[16]) / 100.0);
+    printf("[shader clock %.0f MHz: s_memtime against s_memrealtime] ", mhz);
+    printf("the kernels' period in asm (9 MFMAs in dependent triples, 12 fed reads, %s, %s), waves/SIMD=%d : %7.1f cycles per period (%d MFMAs per SIMD: %d = pipe-bound)\n",
+           BAR ? "s_barrier" : "no barrier", dn[DATA], MW, (double)(hi - lo) / nphase, 9 * MW, 9 * MW * 32);
+}
+
 template <int R, int MW>
 static void sweep_fed(int nm, float *out, long long *res_d) {
     run_fed<1, R, MW>(nm, out, res_d);
@@ -193,8 +263,30 @@ int main(int argc, char **argv) {
     float *out;
     long long *res_d;
     hipMalloc(&out, 256 * 512 * 4);
-    hipMalloc(&res_d, 16 * 8);
+    hipMalloc(&res_d, 32 * 8);
     const int nm = 2048;
+    if (argc > 1 && argv[1][0] == 'c') {  // what clock does the part hold under a sustained stream of MFMAs?  (s_memtime = shader clock,
+        // s_memrealtime = constant 100 MHz; every kernel runs on all 256 CUs, two waves per SIMD, for the given number of MFMAs per wave)
+        for (int nmc : {4096, 65536, 1048576}) {
+            long long res[18];
+            hipLaunchKernelGGL((k<0, 0, 2, false>), dim3(256), dim3(512), 64 * 1024, 0, nmc, out, res_d);
+            hipDeviceSynchronize();
+            hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+            printf("v_mfma_f32_32x32x2_f32  alone, %8d per wave: %6.1f cycles each, %7.3f ms, shader clock %4.0f MHz\n", nmc,
+                   (double)(res[1] - res[0]) / (2.0 * nmc), (double)(res[17] - res[16]) / 1e5, (double)(res[1] - res[0]) / ((double)(res[17] - res[16]) / 100.0));
+            hipLaunchKernelGGL((k<0, 0, 2, true>), dim3(256), dim3(512), 64 * 1024, 0, nmc, out, res_d);
+            hipDeviceSynchronize();
+            hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+            printf("v_mfma_f32_32x32x16_f16 alone, %8d per wave: %6.1f cycles each, %7.3f ms, shader clock %4.0f MHz\n", nmc,
+                   (double)(res[1] - res[0]) / (2.0 * nmc), (double)(res[17] - res[16]) / 1e5, (double)(res[1] - res[0]) / ((double)(res[17] - res[16]) / 100.0));
+            hipLaunchKernelGGL((k<2, 2, 2, true>), dim3(256), dim3(512), 64 * 1024, 0, nmc, out, res_d);
+            hipDeviceSynchronize();
+            hipMemcpy(res, res_d, sizeof(res), hipMemcpyDeviceToHost);
+            printf("  + 2 ds_read_b128 per MFMA,   %8d per wave: %6.1f cycles each, %7.3f ms, shader clock %4.0f MHz\n", nmc,
+                   (double)(res[1] - res[0]) / (2.0 * nmc), (double)(res[17] - res[16]) / 1e5, (double)(res[1] - res[0]) / ((double)(res[17] - res[16]) / 100.0));
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'f') {  // only the question of the reads that feed the products (independent reads for comparison)
         run<1, 2, 2, true>(nm, out, res_d);
         run<2, 2, 2, true>(nm, out, res_d);
@@ -206,6 +298,13 @@ int main(int argc, char **argv) {
         run_fed<3, 2, 2, 1, 1>(nm, out, res_d);   // the kernels' address pattern
         run_fed<3, 2, 2, 3, 1>(nm, out, res_d);   // both
         run_fed<6, 2, 2, 3, 1>(nm, out, res_d);
+        run_phase<2, 1>(20000, out, res_d);
+        run_phase<2, 0>(512, out, res_d);
+        run_phase<1, 1>(512, out, res_d);
+        run_phase<2, 1, 1>(512, out, res_d);
+        run_phase<2, 1, 2>(512, out, res_d);
+        run_phase<2, 1, 3>(512, out, res_d);
+        run_phase<2, 1, 4>(512, out, res_d);
         return 0;
     }
     sweep<0, 1>(nm, out, res_d);
