@@ -1862,7 +1862,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     g.n_mblocks = (int)m_blocks;
     const int n_tiles = c.Cout / 64;
-    int a = n_tiles >= 16 ? 8 : 4;
+    int a = n_tiles >= 16 ? 8 : (n_tiles >= 8 ? 4 : 2);  // swept again with the round's final kernels (profiles/round3_stream_loop_experiments.txt, 15.)
     if (const char *e = getenv("STITO_W43S_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }  // tuning aid (tools/conv_bench.py)
     STITO_REQUIRE(a >= 1 && a <= 32 && (a & (a - 1)) == 0 && n_tiles % a == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cout %d", c.Cout);
     g.ct_group = a;
@@ -1942,7 +1942,7 @@ static int64_t w43_split2_grid(const ConvShape &c, bool pool, int64_t &m_pairs, 
     const int64_t m_blocks = blocks / (c.Cout / 64);
     m_pairs = (m_blocks + 1) / 2;
     const int n_tiles = c.Cout / 64;
-    int a = n_tiles >= 16 ? 8 : 4;
+    int a = n_tiles % 8 == 0 ? 8 : 4;  // (n_tiles is a multiple of 4: wino43_split_supported)
     if (const char *e = getenv("STITO_W43S_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }
     if (a < 1 || a > 32 || (a & (a - 1)) != 0 || n_tiles % a != 0) return 0;
     ct_group = a;
