@@ -637,23 +637,17 @@ __global__ __launch_bounds__(WINO8_THREADS) void k_conv_wino8(const float *__res
 // octet) stores 2 KB contiguous -- the first version (thread = 4 channels, the 16 quads of a pixel side by side) scattered
 // every wave store over 32 separate 32-byte pieces and reached 3.2 TB/s.
 // ------------------------------------------------------------------------------------------------
+// ALLOCT: a thread keeps its pixel's nine input values and walks all channel octets (weights by scalar loads per octet) instead of
+// one octet per workgroup (blockIdx.z): the loads, the bounds tests and the p / W of a pixel are done once, not Cout / 8 times.
+template <bool ALLOCT>
 __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in, const float *__restrict__ w /*[cout][9]*/,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      float *__restrict__ out, int H, int W, int Cout, int64_t n_pix_per_stream,
                                                      unsigned *__restrict__ amax_out) {
     const int s = blockIdx.y;
-    const int oct = blockIdx.z;  // channels 8 oct .. 8 oct + 7
+    const int oct0 = ALLOCT ? 0 : blockIdx.z, oct1 = ALLOCT ? Cout / 8 : oct0 + 1;  // channels 8 oct .. 8 oct + 7
     unsigned mx = 0;             // largest output of this thread (>= 0 after ReLU: bit patterns order like the values)
-    float wr[8][9], sc[8], sh[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wr[c][t] = w[(oct * 8 + c) * 9 + t];  // wave-uniform: scalar loads
-        sc[c] = scale[oct * 8 + c];
-        sh[c] = shift[oct * 8 + c];
-    }
     const float *ip = in + (int64_t)s * n_pix_per_stream;
-    float *op = out + (int64_t)s * n_pix_per_stream * Cout + (int64_t)oct * n_pix_per_stream * 8;  // NC8HW8 plane of this octet
     const int npix = (int)n_pix_per_stream;  // H * W of one stream: 32-bit (a 64-bit p / W costs more than the conv)
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
         const int h = p / W, x = p - h * W;
@@ -663,22 +657,26 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ in
             const int hh = h + t / 3 - 1, ww = x + t % 3 - 1;
             v[t] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? ip[(int64_t)hh * W + ww] : 0.0f;
         }
-        float r[8];
+        for (int oct = oct0; oct < oct1; ++oct) {
+            const float *wo = w + oct * 72;  // wave-uniform: scalar loads
+            float *op = out + (int64_t)s * n_pix_per_stream * Cout + (int64_t)oct * n_pix_per_stream * 8;  // NC8HW8 plane of this octet
+            float r[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float a = 0.0f;
+            for (int c = 0; c < 8; ++c) {
+                float a = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) a = fmaf(v[t], wr[c][t], a);
-            r[c] = fmaxf(fmaf(a, sc[c], sh[c]), 0.0f);
-        }
-        float4 o0, o1;
-        o0.x = r[0]; o0.y = r[1]; o0.z = r[2]; o0.w = r[3];
-        o1.x = r[4]; o1.y = r[5]; o1.z = r[6]; o1.w = r[7];
-        *(float4 *)(op + (int64_t)p * 8) = o0;
-        *(float4 *)(op + (int64_t)p * 8 + 4) = o1;
-        if (amax_out != nullptr) {
+                for (int t = 0; t < 9; ++t) a = fmaf(v[t], wo[c * 9 + t], a);
+                r[c] = fmaxf(fmaf(a, scale[oct * 8 + c], shift[oct * 8 + c]), 0.0f);
+            }
+            float4 o0, o1;
+            o0.x = r[0]; o0.y = r[1]; o0.z = r[2]; o0.w = r[3];
+            o1.x = r[4]; o1.y = r[5]; o1.z = r[6]; o1.w = r[7];
+            *(float4 *)(op + (int64_t)p * 8) = o0;
+            *(float4 *)(op + (int64_t)p * 8 + 4) = o1;
+            if (amax_out != nullptr) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) mx = max(mx, __float_as_uint(r[c]));
+                for (int c = 0; c < 8; ++c) mx = max(mx, __float_as_uint(r[c]));
+            }
         }
     }
     if (amax_out != nullptr) {  // per-stream maximum for the split-precision layer behind (conv_layout.h): one atomic per wave
@@ -1035,9 +1033,14 @@ static int conv_first(const float *in, const float *w, const float *scale, const
     STITO_REQUIRE(npix < (1ll << 30), STITO_E_UNSUPPORTED, "first conv: %dx%d map too large", H, W);
     STITO_REQUIRE(S <= 65535, STITO_E_UNSUPPORTED, "first conv: %d streams per launch", S);
     int64_t gx = (npix + 255) / 256;
-    const int64_t cap = (256 * 64 + (int64_t)S * (Cout / 8) - 1) / ((int64_t)S * (Cout / 8));  // ~64 workgroups per CU in total
+    // default: one thread per pixel walks all channel octets (2.80 -> 2.14 ms at 512 streams: the kernel was bound by the
+    // instructions in front of its stores, not by the stores); STITO_CONV_FIRST_ALLOCT=0 = one octet per workgroup, for A / B runs
+    static const bool alloct = [] { const char *e = getenv("STITO_CONV_FIRST_ALLOCT"); return e ? atoi(e) != 0 : true; }();
+    const int64_t nz = alloct ? 1 : Cout / 8;
+    const int64_t cap = (256 * 64 + (int64_t)S * nz - 1) / ((int64_t)S * nz);  // ~64 workgroups per CU in total
     gx = gx < cap ? gx : (cap < 1 ? 1 : cap);
-    hipLaunchKernelGGL(k_conv_first, dim3((unsigned)gx, S, Cout / 8), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix, amax_out);
+    if (alloct) hipLaunchKernelGGL(k_conv_first<true>, dim3((unsigned)gx, S, 1), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix, amax_out);
+    else hipLaunchKernelGGL(k_conv_first<false>, dim3((unsigned)gx, S, Cout / 8), dim3(256), 0, st, in, w, scale, shift, out, H, W, Cout, npix, amax_out);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
 }
