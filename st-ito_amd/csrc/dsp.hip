@@ -216,21 +216,26 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
     // tile staging: every thread fetches EQ_NC/8 = 32 scattered 4-byte pieces per tile; all of them
     // are issued together into registers one tile ahead of use so HBM latency overlaps the cascade.
     float pre[EQ_NC / 8];
+    // Index arithmetic in 32 bits (the launchers refuse streams of 2^31 samples), one add and one min per load: the staging of a
+    // tile, not the float64 recurrence, is where this kernel's time went (profiles/README.md; the same lesson as k_conv_first).
+    // A tile is INTERIOR when all of its 256 x 32 samples exist (58 of the 59 tiles of a 10 s stream): no masks at all then.
+    const unsigned vbase = (unsigned)lr * (unsigned)B + (unsigned)lj, stride8 = 8u * (unsigned)B, last = (unsigned)L - 1u;
+    auto interior = [&](int64_t t0) { return t0 + EQ_TS <= B && (int64_t)(EQ_NC - 1) * B + t0 + EQ_TS <= L; };
     auto fetch = [&](int64_t t0) {  // unconditional loads (clamped); masked in stage(), one tile later
+        const unsigned o0 = vbase + (unsigned)t0;
 #pragma unroll
-        for (int it = 0; it < EQ_NC / 8; ++it) {
-            const int r = it * 8 + lr;
-            const int64_t idx = (int64_t)r * B + t0 + lj;
-            pre[it] = x[idx < L ? idx : L - 1];
-        }
+        for (int it = 0; it < EQ_NC / 8; ++it) pre[it] = x[min(o0 + (unsigned)it * stride8, last)];
     };
     auto stage = [&](int64_t t0) {
+        if (interior(t0)) {
 #pragma unroll
-        for (int it = 0; it < EQ_NC / 8; ++it) {
-            const int r = it * 8 + lr;
-            const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
-            tile[r][lj] = (pos < B && idx < L) ? pre[it] : 0.0f;
+            for (int it = 0; it < EQ_NC / 8; ++it) tile[it * 8 + lr][lj] = pre[it];
+            return;
         }
+        const unsigned o0 = vbase + (unsigned)t0;
+        const bool in_chunk = t0 + lj < B;
+#pragma unroll
+        for (int it = 0; it < EQ_NC / 8; ++it) tile[it * 8 + lr][lj] = (in_chunk && o0 + (unsigned)it * stride8 <= last) ? pre[it] : 0.0f;
     };
     // ---- pass A: zero-state response of every chunk, keep only the final state -------------
 #pragma unroll
@@ -308,14 +313,17 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
         n = n < 0 ? 0 : (n > EQ_TS ? EQ_TS : n);
         for (int j = 0; j < (int)n; ++j) tile[tid][j] = (float)eq_step((double)tile[tid][j], sec, z);
         __syncthreads();
+        {
+            const unsigned o0 = vbase + (unsigned)t0;
+            const bool all = interior(t0), in_chunk = t0 + lj < B;
 #pragma unroll
-        for (int it = 0; it < EQ_NC / 8; ++it) {
-            const int r = it * 8 + lr;
-            const int64_t pos = t0 + lj, idx = (int64_t)r * B + pos;
-            if (pos < B && idx < L) {
-                const float v = tile[r][lj] * post_gain;
-                y[idx] = v;
-                post_max = fmaxf(post_max, fabsf(v));
+            for (int it = 0; it < EQ_NC / 8; ++it) {
+                const unsigned o = o0 + (unsigned)it * stride8;
+                if (all || (in_chunk && o <= last)) {
+                    const float v = tile[it * 8 + lr][lj] * post_gain;
+                    y[o] = v;
+                    post_max = fmaxf(post_max, fabsf(v));
+                }
             }
         }
     }
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
 // The same cascade for other callers (features.hip: the K-weighting of BS.1770 = two biquads, the other four sections identity
 // rows b0 = 1): coef = n_cand rows of COEF_STRIDE doubles, out (n_cand, C, L) float32.
 int eq_cascade(const InView &in, float *out, int n_cand, int C, int64_t L, const double *coef, hipStream_t st) {
+    STITO_REQUIRE(L > 0 && L < ((int64_t)1 << 31) - 65536, STITO_E_UNSUPPORTED, "parametric EQ: %lld samples per stream (k_eq indexes in 32 bits)", (long long)L);
     hipLaunchKernelGGL(k_eq, dim3((unsigned)(n_cand * C)), dim3(EQ_NC), 0, st, in, PostOp{}, out, (int64_t)C * L, C, L, coef);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
@@ -873,6 +882,7 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                     post.peaks = peaks_dev;
                     peaks_done = true;
                 }
+                STITO_REQUIRE(L < ((int64_t)1 << 31) - 65536, STITO_E_UNSUPPORTED, "parametric EQ: %lld samples per stream (k_eq indexes in 32 bits)", (long long)L);
                 hipLaunchKernelGGL(k_eq, dim3(S), dim3(EQ_NC), 0, st, in, post, audio_dev, cand_stride, Cn, L, cf);
                 break;
             }
