@@ -79,10 +79,11 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 6 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+/* ABI version: 7 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
- * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT). */
+ * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT;
+ * 7: STITO_CONV_WINOGRAD_F2_REG). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -213,7 +214,13 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * transform, no 36-position exchange and 576 MACs per input element copied into LDS -- for the layers whose maps are
         * large and whose channel loops are short (conv_block1 - conv_block4.conv1).  cin % 16 == 0, cout % 64 == 0, maps at
         * least 16 wide; own packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 6). */
-       STITO_CONV_DIRECT_SPLIT = 7 };
+       STITO_CONV_DIRECT_SPLIT = 7,
+       /* Winograd F(2x2,3x3) on the f16 matrix pipe with the same split operands, for the 64-input-channel layers (conv_block1.conv2,
+        * conv_block2.conv1): the transformed WEIGHTS (16 positions x 64 x 64 as f16 hi + lo = 256 KB) stay in the registers of
+        * persistent workgroups for the whole launch, the input transform is done in registers straight into the MFMA operand
+        * layout (no transformed input in LDS or HBM), the raw halo patches arrive by LDS-DMA.  cin == 64, cout % 64 == 0; own
+        * packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 7). */
+       STITO_CONV_WINOGRAD_F2_REG = 8 };
 
 typedef struct {
     int32_t embed_dim;
@@ -225,7 +232,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2, _F4_SPLITK or STITO_CONV_DIRECT_SPLIT */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2, _F4_SPLITK, STITO_CONV_DIRECT_SPLIT or STITO_CONV_WINOGRAD_F2_REG */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */

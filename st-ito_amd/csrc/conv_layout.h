@@ -108,6 +108,14 @@ size_t dsplit_packed_floats(int cout, int cin);
 int pack_dsplit(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
 int launch_dsplit(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c, bool pool,
                   void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+// conv_wino23r.hip: Winograd F(2x2,3x3) on the f16 matrix pipe, weights resident in registers (the 64-input-channel layers)
+bool wino23r_supported(const ConvShape &c, bool pool);
+double wino23r_issued_flops(const ConvShape &c, bool pool);
+size_t wino23r_workspace_bytes(const ConvShape &c, bool pool);  // per-stream maxima of the input when the caller has none
+size_t wino23r_packed_floats(int cout, int cin);
+int pack_wino23r(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
+int launch_wino23r(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c, bool pool,
+                   void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv
 int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st);
 int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,

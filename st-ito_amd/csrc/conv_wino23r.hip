@@ -1,0 +1,526 @@
+// conv_wino23r.hip -- 3x3 conv (pad 1) + BN + ReLU (+ 2x2 average pool) of the Cnn14 trunk's 64- and 128-channel layers
+// (reference: ConvBlock.forward, st_ito/models/panns.py:65-80; conv_block1.conv2, conv_block2 of panns.py:250-253) by
+// Winograd F(2x2, 3x3) on the f16 matrix pipe with split operands, built the other way round from conv_wino43.hip:
+//
+//   * the WEIGHTS stay in registers.  U = G g G^T of a 64 -> 64 layer is 16 positions x 64 x 64 x (f16 hi + lo) = 256 KB: half of a
+//     CU's register file.  A workgroup is 4 waves of up to 512 registers (one per SIMD); wave i keeps the four positions (i, 0..3)
+//     of all input channels and its 32 NB output channels as MFMA operands for the whole launch.  Workgroups are persistent (one per
+//     CU) and walk over pixel groups: no weight slab is ever copied again -- the traffic that bound every earlier kernel of these
+//     layers (36 KB of weights through L2 and LDS per 4-channel chunk of a 32-tile block) is gone.
+//   * the INPUT TRANSFORM happens in registers, straight into the operand layout.  The second operand of
+//     v_mfma_f32_32x32x16_f16 wants, per lane, 8 consecutive k (= input channels) of one column (= tile): lane (tile, channel
+//     octet) reads the two patch rows its position row combines (8 pixels x 8 channels by ds_read_b128 from the raw f32 halo
+//     patch), forms t = d[a1] +- d[a2] and the four V(i, j) = t[b1] +- t[b2] with packed f32 adds, and rounds every value
+//     to scaled f16 halves hi + lo with v_fma_mixlo/hi_f16 (one instruction per half: hi = rn16(s v), lo = rn16(s v - hi)).
+//     No transformed input in LDS or HBM, no operand reads from LDS at all.
+//   * F(2x2,3x3) instead of F(4x4,3x3): 4 MACs per output instead of 2.25, but on the f16 pipe they are cheap (3 products per
+//     MAC at 16 x the f32 rate); what decides is that 16 positions of weights fit the registers where 36 do not, and that the
+//     transforms are adds only.
+//   * the products D = U^T-block x V: A operand = weights (rows = output channels), B operand = V (columns = tiles), so that a
+//     lane's accumulators are 4 consecutive output channels of ITS tile: the epilogue's 16-byte exchanges and stores fall out
+//     of the layout.
+//   * Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]: wave i reduces its row over j in registers (Z_i[c], two values), the sum over i
+//     goes through LDS (each wave writes its Z, 16 KB, and finishes a quarter of the group's outputs: BN + ReLU (+ pool) + stores).
+//
+// Pixel group = 2 tile rows x 16 tile columns (output 4 x 32 pixels before pooling), halo patch 6 x 34 pixels, staged by
+// LDS-DMA one k-step (16 channels = 4 channel quads, 13 KB) at a time into a ring of W23_RING entries.  Patch layout per
+// entry: [quad][row parity, column parity][3 x 17 pixels] x 16 bytes -- the four parity planes make the 16 tiles of a
+// ds_read_b128 lane group (a tile row; lanes are mapped to tiles group by group) read 16 consecutive 16-byte slots: no bank
+// conflicts; wave w copies plane w (51 lanes per instruction, pixels outside the map masked off through EXEC and zeroed by hand).
+// Two barriers per group: B1 at its top (its patch has landed; the previous group's Z are written), B2 after its first k-step
+// (that entry is free for the next group's last k-step; the exchange buffer may be rewritten at the end of the group).
+#include "conv_layout.h"
+
+#include <cstdlib>
+
+namespace stito {
+
+typedef _Float16 rh8 __attribute__((ext_vector_type(8)));
+typedef unsigned ru4 __attribute__((ext_vector_type(4)));
+
+static constexpr int W23_THREADS = 256;
+static constexpr int W23_PLANE = 51;                        // 3 x 17 pixels of one parity plane
+static constexpr int W23_ENTRY = 4 * 4 * W23_PLANE * 16;    // bytes of one k-step of the patch: [quad][plane][51][16 B]
+static constexpr int W23_RING = 7;
+
+#ifndef W23_ABL
+#define W23_ABL 0  // timing-experiment bit mask (1 no transform, 2 no MFMAs, 4 no DMA, 8 no epilogue); 0 in every build that ships
+#endif
+
+// power-of-two scale of a stream's transformed input: |B^T d B| <= 4 max|d|, amax < 2^e -> 2^(12 - e): below 2^14
+__host__ __device__ __forceinline__ float w23_vscale(unsigned amax_bits) {
+    int e = (int)((amax_bits >> 23) & 0xff) - 126;  // amax = f * 2^e, f in [0.5, 1)
+    if (amax_bits == 0u) e = 12;                      // all-zero stream: scale 1
+    e = e < -40 ? -40 : (e > 60 ? 60 : e);
+    return __builtin_ldexpf(1.0f, 12 - e);
+}
+
+struct W23Geom {
+    int S, H, W, Cin, Cout;
+    int Ho, Wo;           // output map (pooled when POOL)
+    int TR, TC;           // tile rows / columns per stream that produce output
+    int n_bands, n_txb;   // pixel groups per stream: ceil(TR / 2) x ceil(TC / 16)
+    int n_groups;         // S * n_bands * n_txb
+    int n_cb;             // output-channel blocks (Cout / (32 NB))
+    int wg_per_cb;        // persistent workgroups per channel block
+    FDiv fGPS, fTXB;      // groups per stream, n_txb as launch-constant divisors
+    const unsigned *amax_in;   // per stream: largest input activation (bit pattern)
+    unsigned *amax_out;        // or NULL: per stream, the largest output (atomicMax; zeroed by the caller)
+    const float *u_inv;        // 1 / weight scale (header of the packed weights)
+};
+
+// hi = rn16(s v), lo = rn16(s v - hi) into the low (E = 0) or high (E = 1) half of one register each
+#define W23_SPLIT(HI, LO, V, SC, E)                                                                              \
+    if ((E) == 0) {                                                                                              \
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(HI) : "v"(V), "s"(SC));                             \
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(LO) : "v"(V), "s"(SC), "v"(HI)); \
+    } else {                                                                                                     \
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(HI) : "v"(V), "s"(SC));                             \
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(LO) : "v"(V), "s"(SC), "v"(HI)); \
+    }
+
+#define W23_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+// The products are inline asm so that the weight operand can be pinned to the AGPR half of the register file ("a": hipcc
+// given the builtin keeps MFMA sources in arch VGPRs and copies 256 weight registers per group through v_accvgpr_read, with
+// spills).  What the compiler's hazard recognizer no longer sees is handled here: the first product of an accumulator takes
+// the inline constant 0 as its C operand (no VALU-written accumulator feeds an MFMA), dependent products on the same
+// accumulator issue back to back (the matrix pipe interlocks on an exactly overlapping C), and W23_MFMA_DRAIN (>= 18 wait
+// states behind a 16-pass MFMA) stands between the last product and the first VALU read of the accumulators.
+#define W23_MFMA0(ACC, A_, B_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "a"(A_), "v"(B_));
+#define W23_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(A_), "v"(B_));
+#define P2(v, h) __builtin_shufflevector(v, v, 2 * (h), 2 * (h) + 1)
+
+template <int KS, int NB, bool POOL>
+__global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__restrict__ in, const char *__restrict__ wpk,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                float *__restrict__ out, W23Geom g) {
+    static_assert(KS * NB == 8, "256 weight registers per lane");
+    static_assert(KS == 4, "ring schedule below: 4 k-steps per group");
+    constexpr int XCH = 4 * 2 * NB * 4 * 1024;  // exchange: [wave][c][n][register quad][lane] x 16 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const ring = smem;
+    char *const xch = smem + W23_RING * W23_ENTRY;
+    float *const bnp = (float *)(xch + XCH);  // [scale | shift][32 NB]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, t31 = lane & 31;
+
+    // workgroup -> (channel block, group range): workgroups that walk the same groups with different channel blocks are 8 apart
+    // (same XCD, b % 8): the patch comes from HBM once
+    const int b = blockIdx.x;
+    const int cb = (b >> 3) % g.n_cb;
+    const int wi = (b & 7) + 8 * ((b >> 3) / g.n_cb);
+    const int g_lo = (int)((int64_t)g.n_groups * wi / g.wg_per_cb), g_hi = (int)((int64_t)g.n_groups * (wi + 1) / g.wg_per_cb);
+    if (g_lo >= g_hi) return;
+
+    // ---- weights: [cb][wave][j][ks][n][hi | lo][lane] x 16 B, read once ------------------------------------------------
+    rh8 Wt[4][KS][NB][2];
+    {
+        const char *wp = wpk + ((int64_t)(cb * 4 + wv) * 4 * KS * NB * 2) * 1024 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) Wt[j][ks][n][p] = *(const rh8 *)(wp + ((((j * KS + ks) * NB + n) * 2 + p) * 1024));
+    }
+    if (tid < 32 * NB) {
+        bnp[tid] = scale[cb * 32 * NB + tid];
+        bnp[32 * NB + tid] = shift[cb * 32 * NB + tid];
+    }
+    const float u_inv = g.u_inv[0];
+
+    // ---- lane -> tile: the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) each get one
+    // tile row (16 consecutive 16-byte slots of a parity plane)
+    const bool in_a = t31 < 4 || (t31 >= 12 && t31 < 16) || (t31 >= 20 && t31 < 28);
+    const int ty = in_a ? 0 : 1;
+    const int tx = in_a ? (t31 < 4 ? t31 : (t31 < 16 ? t31 - 8 : t31 - 12)) : (t31 < 12 ? t31 - 4 : (t31 < 20 ? t31 - 8 : t31 - 16));
+    // transform of position row i = wv: t[b] = d[a1][b] + sg d[a2][b]   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+    const int a1 = wv == 0 ? 0 : (wv == 2 ? 2 : 1), a2 = wv == 0 ? 2 : (wv == 1 ? 2 : (wv == 2 ? 1 : 3));
+    const float sgf = wv == 1 ? 1.0f : -1.0f;
+    const f32x2 sg2 = {sgf, sgf};
+    // byte offset inside a ring entry of patch pixel (2 ty + a, 2 tx + b), quad 2 half + qq:
+    //   ((quad * 4 + (a & 1) * 2 + (b & 1)) * 51 + (ty + a / 2) * 17 + tx + b / 2) * 16
+    const int rd_lane = ((2 * half * 4) * W23_PLANE + ty * 17 + tx) * 16;
+    const int rd1 = rd_lane + (((a1 & 1) * 2) * W23_PLANE + (a1 >> 1) * 17) * 16;
+    const int rd2 = rd_lane + (((a2 & 1) * 2) * W23_PLANE + (a2 >> 1) * 17) * 16;
+#define W23_RDOFF(B_, QQ_) ((((QQ_) * 4 + ((B_) & 1)) * W23_PLANE + ((B_) >> 1)) * 16)
+
+    // ---- patch copies: wave w copies parity plane w; lane L < 51 -> plane pixel (L / 17, L % 17) -> patch pixel (y, x) -------
+    const int dy = 2 * (lane / 17) + (wv >> 1), dx = 2 * (lane % 17) + (wv & 1);
+    const unsigned dma_voff = (unsigned)((dy * g.W + dx) * 32);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned dma_lds = lds0 + (unsigned)(wv * W23_PLANE * 16);
+    const int64_t plane8 = (int64_t)g.H * g.W * 32;  // bytes per channel octet of one stream
+
+    // group coordinates
+    int gs = 0, gband = 0, gtxb = 0;  // of the group being multiplied
+#define W23_COORDS(G_, S_, BAND_, TXB_)                                                                          \
+    {                                                                                                            \
+        int r_;                                                                                                  \
+        S_ = fdiv((G_), g.fGPS, r_);                                                                             \
+        BAND_ = fdiv(r_, g.fTXB, TXB_);                                                                          \
+    }
+    // DMA state of the group being fetched
+    uint64_t dma_mask = 0;
+    const char *dma_base = nullptr;
+    bool dma_edge = false;
+#define W23_DMA_SETUP(G_)                                                                                        \
+    {                                                                                                            \
+        int s_, band_, txb_;                                                                                     \
+        W23_COORDS(G_, s_, band_, txb_)                                                                          \
+        const int h0_ = 4 * band_ - 1, w0_ = 32 * txb_ - 1;                                                      \
+        const bool ok_ = lane < W23_PLANE && h0_ + dy >= 0 && h0_ + dy < g.H && w0_ + dx >= 0 && w0_ + dx < g.W; \
+        dma_mask = __builtin_amdgcn_ballot_w64(ok_);                                                             \
+        dma_edge = dma_mask != ((1ull << W23_PLANE) - 1);                                                        \
+        dma_base = (const char *)in + (int64_t)s_ * (g.Cin >> 3) * plane8 + ((int64_t)h0_ * g.W + w0_) * 32;     \
+    }
+// k-step KS_ of the group set up last -> ring entry E_: four masked 1 KB copies (one per channel quad); lanes of the plane
+// without a pixel get zeros
+#define W23_DMA_KSTEP(KS_, E_)                                                                                   \
+    if (!(W23_ABL & 4)) {                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+            const char *sb_ = dma_base + (int64_t)(2 * (KS_) + (q_ >> 1)) * plane8 + (q_ & 1) * 16;               \
+            const unsigned dst_ = dma_lds + (unsigned)((E_) * W23_ENTRY + q_ * 4 * W23_PLANE * 16);              \
+            uint64_t keep_;                                                                                      \
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"          \
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                  \
+                         : "=&s"(keep_)                                                                          \
+                         : "v"(dma_voff), "s"(sb_), "s"(dst_), "s"(dma_mask)                                     \
+                         : "memory");                                                                            \
+            if (dma_edge && lane < W23_PLANE && !((dma_mask >> lane) & 1))                                       \
+                *(f32x4 *)(ring + (E_) * W23_ENTRY + (q_ * 4 + wv) * W23_PLANE * 16 + lane * 16) = (f32x4)(0.0f); \
+        }                                                                                                        \
+    }
+
+    f32x16 acc[4][NB];
+    // epilogue state of the previous group
+    int e_s = 0, e_band = 0, e_txb = 0;
+    bool e_have = false;
+
+    // ---- prologue: the first group's four k-steps -------------------------------------------------------------------------
+    int ent = 0;  // ring entry of the current group's k-step 0
+    W23_DMA_SETUP(g_lo)
+    W23_DMA_KSTEP(0, 0) W23_DMA_KSTEP(1, 1) W23_DMA_KSTEP(2, 2) W23_DMA_KSTEP(3, 3)
+
+    for (int gi = g_lo; gi <= g_hi; ++gi) {
+        const bool have = gi < g_hi;        // a group to multiply (the last trip only finishes the previous group's outputs)
+        const bool more = gi + 1 < g_hi;    // a group to fetch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W23_BARRIER()  // B1: this group's patch has landed; the previous group's Z are in the exchange buffer
+        int e1 = ent + 4, e2 = ent + 5, e3 = ent + 6, e0n = ent;  // entries of the next group's k-steps 0, 1, 2; 3 reuses this group's k-step 0
+        e1 = e1 >= W23_RING ? e1 - W23_RING : e1;
+        e2 = e2 >= W23_RING ? e2 - W23_RING : e2;
+        e3 = e3 >= W23_RING ? e3 - W23_RING : e3;
+        if (more) {
+            W23_DMA_SETUP(gi + 1)
+            W23_DMA_KSTEP(0, e1) W23_DMA_KSTEP(1, e2) W23_DMA_KSTEP(2, e3)
+        }
+        float sv = 1.0f;
+        if (have) {
+            W23_COORDS(gi, gs, gband, gtxb)
+            sv = w23_vscale(g.amax_in[gs]);
+            if (W23_ABL & 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
+            }
+        }
+
+        // ---- the previous group's outputs: this wave's quarter (NB register quads) of Y = sum_i A^T[.][i] Z_i ----------------
+        if (e_have && !(W23_ABL & 8)) {
+            const float esc = u_inv / w23_vscale(g.amax_in[e_s]);
+            unsigned mx = 0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int u = wv * NB + k, n = u >> 2, rq = u & 3;
+                f32x4 Z[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) Z[i][c] = *(const f32x4 *)(xch + ((((i * 2 + c) * NB + n) * 4 + rq) * 64 + lane) * 16);
+                const int cl = 32 * n + 8 * rq + 4 * half;  // first of the lane's 4 output channels inside the block
+                const f32x4 sc = *(const f32x4 *)(bnp + cl) * esc, sh = *(const f32x4 *)(bnp + 32 * NB + cl);
+                f32x4 Y[2][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    Y[0][c] = (Z[0][c] + Z[1][c]) + Z[2][c];
+                    Y[1][c] = (Z[1][c] - Z[2][c]) - Z[3][c];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) Y[r][c] = __builtin_elementwise_max(Y[r][c] * sc + sh, (f32x4)(0.0f));
+                }
+                const int co = cb * 32 * NB + cl;
+                if (POOL) {
+                    const int oh = 2 * e_band + ty, ow = 16 * e_txb + tx;
+                    if (oh < g.Ho && ow < g.Wo) {
+                        const f32x4 v = (((Y[0][0] + Y[0][1]) + Y[1][0]) + Y[1][1]) * 0.25f;
+                        *(f32x4 *)(out + act_off(e_s, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
+                        mx = max(mx, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])), max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int hh = 4 * e_band + 2 * ty + r, ww = 32 * e_txb + 2 * tx + c;
+                            if (hh < g.H && ww < g.W) {
+                                const f32x4 v = Y[r][c];
+                                *(f32x4 *)(out + act_off(e_s, co, hh, ww, g.Cout, g.H, g.W)) = v;
+                                mx = max(mx, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])), max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
+                            }
+                        }
+                }
+            }
+            if (g.amax_out != nullptr) {  // one atomic per wave and group at most (the maximum only grows: skip when covered)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+                if (lane == 0 && mx > __hip_atomic_load(g.amax_out + e_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.amax_out + e_s, mx);
+            }
+        }
+
+        if (have) {
+            // ---- four k-steps: transform in registers, 6 NB products per position ---------------------------------------------
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int e = ent + ks;
+                e = e >= W23_RING ? e - W23_RING : e;
+                const char *eb = ring + e * W23_ENTRY;
+                unsigned vh[4][4], vl[4][4];  // B operands of the four positions: 8 channels as f16 hi / lo
+                if (!(W23_ABL & 1)) {
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        f32x4 t[4];
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            const f32x4 d1 = *(const f32x4 *)(eb + rd1 + W23_RDOFF(bb, qq));
+                            const f32x4 d2 = *(const f32x4 *)(eb + rd2 + W23_RDOFF(bb, qq));
+                            const f32x2 lo = pk_fma(P2(d2, 0), sg2, P2(d1, 0)), hi = pk_fma(P2(d2, 1), sg2, P2(d1, 1));
+                            t[bb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+                        }
+                        f32x4 V[4];
+#define W23_PK4(OP, A_, B_) __builtin_shufflevector(OP(P2(A_, 0), P2(B_, 0)), OP(P2(A_, 1), P2(B_, 1)), 0, 1, 2, 3)
+                        V[0] = W23_PK4(pk_sub, t[0], t[2]);
+                        V[1] = W23_PK4(pk_add, t[1], t[2]);
+                        V[2] = W23_PK4(pk_sub, t[2], t[1]);
+                        V[3] = W23_PK4(pk_sub, t[1], t[3]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            W23_SPLIT(vh[j][2 * qq], vl[j][2 * qq], V[j][0], sv, 0)
+                            W23_SPLIT(vh[j][2 * qq], vl[j][2 * qq], V[j][1], sv, 1)
+                            W23_SPLIT(vh[j][2 * qq + 1], vl[j][2 * qq + 1], V[j][2], sv, 0)
+                            W23_SPLIT(vh[j][2 * qq + 1], vl[j][2 * qq + 1], V[j][3], sv, 1)
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) { vh[j][x] = 0x3c003c00u; vl[j][x] = 0; }
+                }
+                if (!(W23_ABL & 2)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const ru4 h4 = {vh[j][0], vh[j][1], vh[j][2], vh[j][3]}, l4 = {vl[j][0], vl[j][1], vl[j][2], vl[j][3]};
+                        const rh8 bh = __builtin_bit_cast(rh8, h4), bl = __builtin_bit_cast(rh8, l4);
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            if (ks == 0) { W23_MFMA0(acc[j][n], Wt[j][ks][n][1], bh) } else { W23_MFMA(acc[j][n], Wt[j][ks][n][1], bh) }
+                            W23_MFMA(acc[j][n], Wt[j][ks][n][0], bl)
+                            W23_MFMA(acc[j][n], Wt[j][ks][n][0], bh)
+                        }
+                    }
+                }
+                if (ks == 0) {
+                    W23_BARRIER()  // B2: every wave has read k-step 0 of this group and the previous group's Z
+                    if (more) { W23_DMA_KSTEP(3, e0n) }
+                }
+            }
+            if constexpr (NB == 2)
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+            else
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
+            // ---- Z_i[c] = sum_j M(i, j) A[j][c]:  c = 0: M0 + M1 + M2,  c = 1: M1 - M2 - M3; into the exchange buffer -----------------
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 m[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = (f32x4){acc[j][n][4 * rq], acc[j][n][4 * rq + 1], acc[j][n][4 * rq + 2], acc[j][n][4 * rq + 3]};
+                    const f32x4 z0 = (m[0] + m[1]) + m[2], z1 = (m[1] - m[2]) - m[3];
+                    *(f32x4 *)(xch + ((((wv * 2 + 0) * NB + n) * 4 + rq) * 64 + lane) * 16) = z0;
+                    *(f32x4 *)(xch + ((((wv * 2 + 1) * NB + n) * 4 + rq) * 64 + lane) * 16) = z1;
+                }
+        } else {
+            W23_BARRIER()  // keep the barrier count of the other trips
+        }
+        e_have = have;
+        e_s = gs; e_band = gband; e_txb = gtxb;
+        ent += 4;
+        ent = ent >= W23_RING ? ent - W23_RING : ent;
+    }
+}
+
+// ---- weights: U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], float64, rounded once to float32), scaled by the layer's
+// power of two (max |U| < 2^e -> 2^(14 - e)) and split into f16 halves, in the register order of the kernel:
+// [cout / (32 NB)][wave i][j][k-step][n][hi | lo][lane] x 16 B, lane (m = lane % 32, octet = lane / 32) = 8 input channels
+// 16 ks + 8 octet .. of output channel 32 (NB cb + n) + m.  hdr = {max bits, 1 / scale, scale} behind the data.
+template <int PASS>
+__global__ void k_pack_wino23r(const float *__restrict__ w, int Cout, int Cin, int NB, char *__restrict__ o, unsigned *__restrict__ hdr) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Cout * Cin) return;
+    const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    double gk[3][3], t[4][3];
+    for (int a = 0; a < 3; ++a)
+        for (int bb = 0; bb < 3; ++bb) gk[a][bb] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + bb];
+    for (int a = 0; a < 4; ++a)
+        for (int bb = 0; bb < 3; ++bb) t[a][bb] = G[a][0] * gk[0][bb] + G[a][1] * gk[1][bb] + G[a][2] * gk[2][bb];
+    const int KS = Cin / 16;
+    const int cb = co / (32 * NB), n = (co / 32) % NB, m = co & 31;
+    const int ks = ci >> 4, oct = (ci >> 3) & 1, e8 = ci & 7;
+    const float su = PASS == 1 ? __uint_as_float(hdr[2]) : 1.0f;
+    unsigned mx = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const float u = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+            if (PASS == 0) {
+                mx = max(mx, __float_as_uint(u) & 0x7fffffffu);
+            } else {
+                const float us = u * su;
+                const _Float16 hi = (_Float16)us, lo = (_Float16)(us - (float)hi);
+                char *d = o + ((((((int64_t)cb * 4 + i) * 4 + j) * KS + ks) * NB + n) * 2) * 1024 + (oct * 32 + m) * 16 + e8 * 2;
+                *(_Float16 *)d = hi;
+                *(_Float16 *)(d + 1024) = lo;
+            }
+        }
+    if (PASS == 0 && mx) atomicMax(hdr, mx);
+}
+
+__global__ void k_pack_wino23r_scale(unsigned *hdr) {
+    const unsigned mb = hdr[0];
+    int e = (int)((mb >> 23) & 0xff) - 126;
+    if (mb == 0u) e = 14;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    hdr[1] = __float_as_uint(__builtin_ldexpf(1.0f, e - 14));
+    hdr[2] = __float_as_uint(__builtin_ldexpf(1.0f, 14 - e));
+}
+
+static int w23_nb(int cin) { return cin == 64 ? 2 : 0; }
+
+size_t wino23r_packed_floats(int cout, int cin) { return (size_t)16 * cout * cin + 64; }
+
+bool wino23r_supported(const ConvShape &c, bool pool) {
+    if (w23_nb(c.Cin) == 0 || c.Cout % (32 * w23_nb(c.Cin)) != 0) return false;
+    if (pool && (c.H < 2 || c.W < 2)) return false;
+    if ((int64_t)c.H * c.W * 32 >= (1ll << 31)) return false;  // 32-bit byte offsets inside a channel-octet plane
+    const int tr = pool ? c.H / 2 : (c.H + 1) / 2, tc = pool ? c.W / 2 : (c.W + 1) / 2;
+    const int64_t groups = (int64_t)c.S * ((tr + 1) / 2) * ((tc + 15) / 16);
+    return groups > 0 && groups < (1ll << 22);  // fdiv range
+}
+
+size_t wino23r_workspace_bytes(const ConvShape &c, bool pool) {
+    return wino23r_supported(c, pool) ? align_up((size_t)c.S * sizeof(unsigned), 256) : 0;  // stream maxima when the caller has none
+}
+
+// f16-pipe FLOPs the kernel issues: groups x 32 tiles x 16 positions x cin x cout x 3 products
+double wino23r_issued_flops(const ConvShape &c, bool pool) {
+    if (!wino23r_supported(c, pool)) return 0.0;
+    const int tr = pool ? c.H / 2 : (c.H + 1) / 2, tc = pool ? c.W / 2 : (c.W + 1) / 2;
+    const double groups = (double)c.S * ((tr + 1) / 2) * ((tc + 15) / 16);
+    return 3.0 * 2.0 * groups * 32.0 * 16.0 * c.Cin * c.Cout;
+}
+
+int pack_wino23r(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st) {
+    const int nb = w23_nb(cin);
+    STITO_REQUIRE(nb > 0 && cout % (32 * nb) == 0, STITO_E_UNSUPPORTED, "conv (winograd F(2x2,3x3), register-resident weights): cin %d / cout %d", cin, cout);
+    const int64_t n = (int64_t)cout * cin;
+    unsigned *hdr = (unsigned *)(packed + (size_t)16 * cout * cin);
+    STITO_HIP_CHECK(hipMemsetAsync(hdr, 0, 64 * sizeof(float), st));
+    hipLaunchKernelGGL(k_pack_wino23r<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, nb, (char *)packed, hdr);
+    STITO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pack_wino23r_scale, dim3(1), dim3(1), 0, st, hdr);
+    STITO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pack_wino23r<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, nb, (char *)packed, hdr);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+__global__ __launch_bounds__(256) void k_stream_absmax23(const float *__restrict__ x, int64_t per_stream, unsigned *__restrict__ amax) {
+    const f32x4 *xs = (const f32x4 *)(x + (int64_t)blockIdx.y * per_stream);
+    const int64_t n4 = per_stream >> 2;
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = xs[i];
+        m = max(max(m, max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu)),
+                max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax + blockIdx.y, m);
+}
+
+template <bool POOL>
+static int launch_w23(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                      char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
+    constexpr int KS = 4, NB = 2;
+    W23Geom g{};
+    g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
+    g.Ho = POOL ? c.H / 2 : c.H;
+    g.Wo = POOL ? c.W / 2 : c.W;
+    g.TR = POOL ? g.Ho : (c.H + 1) / 2;
+    g.TC = POOL ? g.Wo : (c.W + 1) / 2;
+    g.n_bands = (g.TR + 1) / 2;
+    g.n_txb = (g.TC + 15) / 16;
+    g.n_groups = c.S * g.n_bands * g.n_txb;
+    g.n_cb = c.Cout / (32 * NB);
+    g.fGPS = make_fdiv(g.n_bands * g.n_txb);
+    g.fTXB = make_fdiv(g.n_txb);
+    int dev = 0, cus = 256;
+    STITO_HIP_CHECK(hipGetDevice(&dev));
+    STITO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // persistent workgroups, one per CU; per channel block a multiple of 8 of them (one set per XCD)
+    int per_cb = (cus / g.n_cb) & ~7;
+    if (per_cb < 8) per_cb = 8;
+    if (const char *e = getenv("STITO_W23_WG")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) per_cb = v; }  // tuning aid
+    g.wg_per_cb = per_cb;
+    const unsigned *amax = amax_in;
+    if (amax_in == nullptr) {
+        unsigned *amax_ws = (unsigned *)ws;
+        amax = amax_ws;
+        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
+        const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
+        int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
+        const int cap = (4096 + c.S - 1) / c.S;
+        splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
+        hipLaunchKernelGGL(k_stream_absmax23, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax_ws);
+        STITO_LAUNCH_CHECK();
+    }
+    g.amax_in = amax;
+    g.amax_out = amax_out;
+    g.u_inv = wpk + (size_t)16 * c.Cout * c.Cin + 1;
+    auto kern = k_conv_wino23r<KS, NB, POOL>;
+    const size_t lds = (size_t)W23_RING * W23_ENTRY + (size_t)4 * 2 * NB * 4 * 1024 + (size_t)2 * 32 * NB * sizeof(float);
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_cb * g.n_cb)), dim3(W23_THREADS), lds, st, in, (const char *)wpk, scale, shift, out, g);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+int launch_wino23r(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c, bool pool,
+                   void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
+    STITO_REQUIRE(wino23r_supported(c, pool), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(2x2,3x3), register-resident weights): %dx%d map, %d -> %d channels not covered", c.H, c.W, c.Cin, c.Cout);
+    STITO_REQUIRE(amax_in != nullptr || (ws != nullptr && ws_bytes >= wino23r_workspace_bytes(c, pool)), STITO_E_WORKSPACE,
+                  "conv (winograd F(2x2,3x3), register-resident weights): workspace have %zu need %zu", ws_bytes, wino23r_workspace_bytes(c, pool));
+    return pool ? launch_w23<true>(in, wpk, scale, shift, out, c, (char *)ws, st, amax_in, amax_out)
+                : launch_w23<false>(in, wpk, scale, shift, out, c, (char *)ws, st, amax_in, amax_out);
+}
+
+}  // namespace stito

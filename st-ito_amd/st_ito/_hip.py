@@ -19,6 +19,7 @@ NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
 FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
 CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE, CONV_WINOGRAD_F4_SPLIT, CONV_WINOGRAD_F4_SPLIT2, CONV_WINOGRAD_F4_SPLITK = 0, 1, 2, 3, 4, 5, 6
 CONV_DIRECT_SPLIT = 7
+CONV_WINOGRAD_F2_REG = 8
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 

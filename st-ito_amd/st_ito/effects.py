@@ -230,12 +230,13 @@ def chorus_lfo_device(sample_rate: float, n_samples: int, device):
     (sample rate, device) and grown in powers of two."""
     import torch
 
-    key = (float(sample_rate), str(device))
+    rate_hz = 1.0  # the reference's BasicChorus.process() never passes rate_hz on (effects.py:962-985): the library default
+    key = (float(sample_rate), rate_hz, str(device))
     t = _CHORUS_LFO.get(key)
     if t is None or t.numel() < n_samples:
         n = 1 << max(16, int(n_samples - 1).bit_length())
         t = torch.empty(n, dtype=torch.float32, device=device)
-        _hip.check(_hip.lib().stito_chorus_lfo(float(sample_rate), 1.0, n, _hip.ptr(t), _hip.stream_ptr()))
+        _hip.check(_hip.lib().stito_chorus_lfo(float(sample_rate), rate_hz, n, _hip.ptr(t), _hip.stream_ptr()))
         _CHORUS_LFO[key] = t
     return t
 

@@ -124,10 +124,16 @@ def render_population(plugins: Dict[str, dict], x: torch.Tensor, W: torch.Tensor
         audio, peaks = out
         assert audio.shape == (P, c_out, n) and audio.is_contiguous() and audio.dtype == torch.float32 and peaks.shape == (P,)
     for i in range(n_fx):  # the chorus stage reads its LFO from a table that has to cover this length
-        if descs[i].kind == _hip.FX_CHORUS and descs[i].aux_len < n:
+        if descs[i].kind == _hip.FX_CHORUS:
+            # re-fetched on every call: the shared table belongs to one (sample rate, device) and is replaced when a longer render
+            # grows it, so a descriptor compiled earlier may point at the old one (or at another rate's).  The descriptor keeps
+            # every table it has pointed at alive (descs._keep): a launch already queued on the stream may still read it
             from .effects import chorus_lfo_device
             t = chorus_lfo_device(sample_rate, n, x.device)
-            descs[i].aux_dev, descs[i].aux_len = t.data_ptr(), t.numel()
+            if descs[i].aux_dev != t.data_ptr() or descs[i].aux_len != t.numel():
+                descs[i].aux_dev, descs[i].aux_len = t.data_ptr(), t.numel()
+                if hasattr(descs, "_keep"):
+                    descs._keep.append(t)
     need = L.stito_render_workspace_bytes(descs, n_fx, C, n, P)
     ws = _WS.get(ws_key, need, x.device)
     _hip.check(L.stito_render_population_multi(descs, n_fx, _hip.ptr(x), n_inputs, C, n, _hip.ptr(W), P, ndims,

@@ -142,6 +142,10 @@ class Cnn14(nn.Module):
         # operands (CONV_DIRECT_SPLIT): 9 MACs per output at 3 / 16 of the f32 pipe's price, no transform, no exchange epilogue,
         # 576 MACs per input element copied into LDS -- the large maps with short channel loops (0 = never)
         self.conv_dsplit_max_cin = int(os.environ.get("STITO_CONV_DSPLIT_MAX_CIN", "0"))
+        # the 64-input-channel layers (conv_block1.conv2, conv_block2.conv1) by Winograd F(2x2,3x3) on the f16 pipe with the
+        # transformed weights resident in registers and the input transform done in registers (CONV_WINOGRAD_F2_REG), unless
+        # STITO_CONV_F2REG=0
+        self.conv_f2reg = os.environ.get("STITO_CONV_F2REG", "1") != "0"
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -196,6 +200,8 @@ class Cnn14(nn.Module):
                         algo = _hip.CONV_WINOGRAD_F4_SPLITK
                     if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cin % 16 == 0 and cin <= self.conv_dsplit_max_cin:
                         algo = _hip.CONV_DIRECT_SPLIT
+                    if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and self.conv_f2reg and cin == 64 and cout % 64 == 0:
+                        algo = _hip.CONV_WINOGRAD_F2_REG
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)
                     _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()

@@ -343,10 +343,13 @@ CONV_CASES = [  # (n, H, W, cin, cout, pool)
     # maps the direct split-precision kernel (algo 7) tiles: 32- and 16-wide tiles, odd heights under pooling (a skipped input
     # row at every stream boundary), partial column tiles, tiles that span several short streams, 16-channel inputs
     (3, 21, 32, 64, 64, 1), (2, 117, 32, 128, 256, 0), (9, 5, 16, 16, 64, 0), (2, 35, 48, 32, 128, 1), (3, 58, 16, 256, 256, 0),
+    # the register-resident F(2x2,3x3) kernel (algo 8): the bench maps of conv_block1.conv2 / conv_block2.conv1, widths that are not
+    # multiples of its 32-pixel groups, odd sizes with and without pooling, one-pixel-wide and one-row maps
+    (1, 469, 128, 64, 64, 1), (2, 234, 64, 64, 128, 0), (2, 37, 50, 64, 64, 0), (3, 11, 33, 64, 192, 1), (2, 1, 70, 64, 64, 0), (2, 9, 1, 64, 64, 0),
 ]
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
 def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     from st_ito import _hip
@@ -378,7 +381,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
     sd, hd = scale.to(dev), shift.to(dev)
     wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, algo)
-    assert (wsb > 0) == (algo in (3, 4, 5, 6, 7))
+    assert (wsb > 0) == (algo in (3, 4, 5, 6, 7, 8))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
                                           n, H, W, cin, cout, pool, algo, _hip.ptr(ws), wsb, st))
@@ -393,7 +396,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
                                        n, H, W, cin, cout, pool, 3, st) == _hip.E_WORKSPACE  # no workspace, no launch
     err = (got - ref).abs().max().item()
     print(f"conv algo {algo} {n}x{H}x{W} {cin}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
-    if algo in (4, 5, 6, 7):
+    if algo in (4, 5, 6, 7, 8):
         assert L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
                                        n, H, W, cin, cout, pool, algo, st) == _hip.E_WORKSPACE  # no workspace, no launch
     # F(4x4,3x3): random SIGNED inputs are the worst case for the cancellation in its output transform (3.3e-5 of the
@@ -402,7 +405,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     assert err < tol * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
 
 
-@pytest.mark.parametrize("algo", [4, 5, 6, 7])
+@pytest.mark.parametrize("algo", [4, 5, 6, 7, 8])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", [(6, 14, 4, 512, 512, 0), (5, 29, 8, 256, 512, 1), (9, 58, 16, 64, 256, 0),
                                                  (7, 21, 32, 64, 64, 1), (12, 6, 16, 128, 64, 0)])
 def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
@@ -413,7 +416,7 @@ def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
     overflow, no loss on the quiet streams), and bitwise independent of what else is in the batch."""
     from st_ito import _hip
     L = _hip.lib()
-    if (algo in (6, 7) or cout < 256) and not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
+    if (algo in (6, 7, 8) or cout < 256) and not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
         pytest.skip("the in-kernel-transform split kernel only stages maps at least 4 tiles wide, the direct one maps at least 16 "
                     "pixels wide, the streaming ones 256-channel outputs")
     assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)
@@ -457,6 +460,55 @@ def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
     # batch independence: stream 2 (quiet) and stream 0 evaluated alone / in another order give the same bits
     alone = run(x[[2, 0]])
     assert torch.equal(alone[0], got[2]) and torch.equal(alone[1], got[0])
+
+
+@pytest.mark.parametrize("n,H,W,cout,pool,wgs", [(6, 117, 64, 64, 1, 8), (3, 60, 100, 128, 0, 8), (5, 29, 128, 64, 0, 16), (2, 469, 128, 64, 1, 24)])
+def test_conv_f2reg_persistent_loop(dev, n, H, W, cout, pool, wgs, monkeypatch):
+    """STITO_CONV_WINOGRAD_F2_REG runs persistent workgroups (one per CU) that walk over pixel groups through a 7-entry ring of
+    patch k-steps (4 per group): with the grid cut down to a few workgroups (STITO_W23_WG, a tuning aid) every workgroup
+    walks tens to hundreds of groups, so every alignment of a group in the ring, every edge-mask change between consecutive
+    groups (left / right / top / bottom of the map, stream changes) and the hand-off of a group's outputs to the next trip are
+    exercised; results must equal the default grid's bit for bit (a pixel group's arithmetic does not depend on who computes
+    it) and agree with float64 torch."""
+    from st_ito import _hip
+    L = _hip.lib()
+    cin, algo = 64, 8
+    g = torch.Generator().manual_seed(H + W + cout)
+    x = torch.relu(torch.randn((n, cin, H, W), generator=g))
+    w = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)
+    scale = 0.5 + torch.rand(cout, generator=g)
+    shift = 0.2 * torch.randn(cout, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double()[None, :, None, None]
+                     + shift.double()[None, :, None, None])
+    if pool:
+        ref = torch.nn.functional.avg_pool2d(ref, 2)
+    def blocked(t):
+        n_, C_, H_, W_ = t.shape
+        return t.reshape(n_, C_ // 8, 8, H_, W_).permute(0, 1, 3, 4, 2).contiguous()
+    ref = blocked(ref)
+    xd, wd, sd, hd = blocked(x).to(dev), w.contiguous().to(dev), scale.to(dev), shift.to(dev)
+    st = _hip.stream_ptr()
+    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)
+    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(wd), cout, cin, algo, _hip.ptr(packed), st))
+    wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, algo)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    outs = []
+    for env in (str(wgs), None):
+        if env is None:
+            monkeypatch.delenv("STITO_W23_WG", raising=False)
+        else:
+            monkeypatch.setenv("STITO_W23_WG", env)
+        out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
+        for _ in range(3):  # repeated launches into the same buffers
+            _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
+                                                  n, H, W, cin, cout, pool, algo, _hip.ptr(ws), wsb, st))
+        outs.append(out.cpu())
+    err = (outs[0].double() - ref).abs().max().item()
+    print(f"f2reg {n}x{H}x{W} 64->{cout} pool={pool} wgs={wgs}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
+    assert not torch.isnan(outs[0]).any() and not torch.isnan(outs[1]).any(), "unwritten outputs"
+    assert err < 5e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("n,H,W,c1,cout,pool", [(2, 33, 128, 64, 64, 1), (3, 9, 64, 64, 64, 1), (5, 6, 32, 64, 128, 1),
