@@ -41,7 +41,7 @@ typedef unsigned ru4 __attribute__((ext_vector_type(4)));
 static constexpr int W23_THREADS = 256;
 static constexpr int W23_PLANE = 51;                        // 3 x 17 pixels of one parity plane
 static constexpr int W23_ENTRY = 4 * 4 * W23_PLANE * 16;    // bytes of one k-step of the patch: [quad][plane][51][16 B]
-static constexpr int W23_RING = 7;
+static constexpr int W23_RING = 6;  // k-step entries: the four of the group being read + two in flight (see conv_wino23r_body.inc)
 
 #ifndef W23_ABL
 #define W23_ABL 0  // timing-experiment bit mask (1 no transform, 2 no MFMAs, 4 no DMA, 8 no epilogue); 0 in every build that ships
@@ -90,12 +90,66 @@ struct W23Geom {
 #define W23_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(A_), "v"(B_));
 #define P2(v, h) __builtin_shufflevector(v, v, 2 * (h), 2 * (h) + 1)
 
+// scale as a bit pattern built with integer arithmetic only (the value stays in a scalar register: it is the SGPR operand of
+// every v_fma_mix of the transform)
+__device__ __forceinline__ float w23_vscale_s(unsigned amax_bits) {
+    int e = (int)((amax_bits >> 23) & 0xff) - 126;
+    if (amax_bits == 0u) e = 12;
+    e = e < -40 ? -40 : (e > 60 ? 60 : e);
+    return __uint_as_float((unsigned)(127 + 12 - e) << 23);
+}
+
+template <int J>
+__device__ __forceinline__ f32x4 w23_vcomb(const f32x4 (&t)[4]) {  // V(i, j) = sum_b t[b] B[b][j],  B^T rows as in the kernel header
+#define W23_PK4(OP, A_, B_) __builtin_shufflevector(OP(P2(A_, 0), P2(B_, 0)), OP(P2(A_, 1), P2(B_, 1)), 0, 1, 2, 3)
+    if (J == 0) return W23_PK4(pk_sub, t[0], t[2]);
+    if (J == 1) return W23_PK4(pk_add, t[1], t[2]);
+    if (J == 2) return W23_PK4(pk_sub, t[2], t[1]);
+    return W23_PK4(pk_sub, t[1], t[3]);
+}
+
+#define W23_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define W23_ENT(E_) ((E_) >= W23_RING ? (E_) - W23_RING : (E_))
+#define W23_X() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); W23_BARRIER()
+#define W23_BH(J) __builtin_bit_cast(rh8, (ru4){bh[J][0], bh[J][1], bh[J][2], bh[J][3]})
+#define W23_BL(J) __builtin_bit_cast(rh8, (ru4){bl[J][0], bl[J][1], bl[J][2], bl[J][3]})
+// product P of position J, channel half N, k-step KS_: lo' hi, hi' lo, hi' hi (the large term last); the first one of a group
+// starts the accumulator from the inline constant 0
+#define W23_MF(J, N, P, KS_)                                                                                     \
+    if (!(W23_ABL & 2)) {                                                                                        \
+        if ((P) == 0) { if ((KS_) == 0) { W23_MFMA0(acc[J][N], Wt[J][KS_][N][1], W23_BH(J)) } else { W23_MFMA(acc[J][N], Wt[J][KS_][N][1], W23_BH(J)) } } \
+        else if ((P) == 1) { W23_MFMA(acc[J][N], Wt[J][KS_][N][0], W23_BL(J)) }                                  \
+        else { W23_MFMA(acc[J][N], Wt[J][KS_][N][0], W23_BH(J)) }                                                \
+    }
+// the k-step whose patch rows are read next lives in ring entry E_ (< 2 W23_RING)
+#define W23_SETP(E_) { const int eo_ = W23_ENT(E_) * W23_ENTRY; pa = ring + eo_ + rd1; pb = ring + eo_ + rd2; }
+#define W23_LD(QQ, B_) if (!(W23_ABL & 1)) { dA[(B_) & 1] = *(const f32x4 *)(pa + W23_RDOFF(B_, QQ)); dB[(B_) & 1] = *(const f32x4 *)(pb + W23_RDOFF(B_, QQ)); }
+#define W23_TT(QQ, B_) if (!(W23_ABL & 1)) { tt[QQ][B_] = __builtin_shufflevector(pk_fma(P2(dB[(B_) & 1], 0), sg2, P2(dA[(B_) & 1], 0)), pk_fma(P2(dB[(B_) & 1], 1), sg2, P2(dA[(B_) & 1], 1)), 0, 1, 2, 3); }
+#define W23_VV(QQ, J, T_) if (!(W23_ABL & 1)) { vv[T_] = w23_vcomb<J>(tt[QQ]); }
+// hi halves of the four values of a unit: registers 2 QQ (values 0, 1) and 2 QQ + 1 (values 2, 3); the two writes of a register
+// (low half, high half) are kept apart.  The low-half write is declared a plain output ("=v": v_fma_mixlo_f16 keeps the upper
+// half of its destination, but whatever was there is overwritten by the mixhi that follows), so an operand register is dead
+// between its last product and its next transform instead of live for the whole loop
+#define W23_SH(QQ, J, T_, SV_)                                                                                   \
+    if (!(W23_ABL & 1)) {                                                                                        \
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[J][2 * (QQ)]) : "v"(vv[T_][0]), "s"(SV_));        \
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[J][2 * (QQ) + 1]) : "v"(vv[T_][2]), "s"(SV_));    \
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[J][2 * (QQ)]) : "v"(vv[T_][1]), "s"(SV_));        \
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[J][2 * (QQ) + 1]) : "v"(vv[T_][3]), "s"(SV_));    \
+    }
+#define W23_SL(QQ, J, T_, SV_)                                                                                   \
+    if (!(W23_ABL & 1)) {                                                                                        \
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(bl[J][2 * (QQ)]) : "v"(vv[T_][0]), "s"(SV_), "v"(bh[J][2 * (QQ)])); \
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(bl[J][2 * (QQ) + 1]) : "v"(vv[T_][2]), "s"(SV_), "v"(bh[J][2 * (QQ) + 1])); \
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[J][2 * (QQ)]) : "v"(vv[T_][1]), "s"(SV_), "v"(bh[J][2 * (QQ)])); \
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[J][2 * (QQ) + 1]) : "v"(vv[T_][3]), "s"(SV_), "v"(bh[J][2 * (QQ) + 1])); \
+    }
+
 template <int KS, int NB, bool POOL>
 __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__restrict__ in, const char *__restrict__ wpk,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 float *__restrict__ out, W23Geom g) {
-    static_assert(KS * NB == 8, "256 weight registers per lane");
-    static_assert(KS == 4, "ring schedule below: 4 k-steps per group");
+    static_assert(KS == 4 && NB == 2, "the generated group loop (conv_wino23r_body.inc) is for 4 k-steps x 2 channel halves");
     constexpr int XCH = 4 * 2 * NB * 4 * 1024;  // exchange: [wave][c][n][register quad][lane] x 16 B
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const ring = smem;
@@ -114,7 +168,7 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     const int g_lo = (int)((int64_t)g.n_groups * wi / g.wg_per_cb), g_hi = (int)((int64_t)g.n_groups * (wi + 1) / g.wg_per_cb);
     if (g_lo >= g_hi) return;
 
-    // ---- weights: [cb][wave][j][ks][n][hi | lo][lane] x 16 B, read once ------------------------------------------------
+    // ---- weights: [cb][wave][j][ks][n][hi | lo][lane] x 16 B, read once, pinned to the AGPRs by the products' "a" operands ------
     rh8 Wt[4][KS][NB][2];
     {
         const char *wp = wpk + ((int64_t)(cb * 4 + wv) * 4 * KS * NB * 2) * 1024 + lane * 16;
@@ -156,15 +210,13 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     const unsigned dma_lds = lds0 + (unsigned)(wv * W23_PLANE * 16);
     const int64_t plane8 = (int64_t)g.H * g.W * 32;  // bytes per channel octet of one stream
 
-    // group coordinates
-    int gs = 0, gband = 0, gtxb = 0;  // of the group being multiplied
 #define W23_COORDS(G_, S_, BAND_, TXB_)                                                                          \
     {                                                                                                            \
         int r_;                                                                                                  \
         S_ = fdiv((G_), g.fGPS, r_);                                                                             \
         BAND_ = fdiv(r_, g.fTXB, TXB_);                                                                          \
     }
-    // DMA state of the group being fetched
+    // DMA state of the group set up last
     uint64_t dma_mask = 0;
     const char *dma_base = nullptr;
     bool dma_edge = false;
@@ -178,193 +230,168 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
         dma_edge = dma_mask != ((1ull << W23_PLANE) - 1);                                                        \
         dma_base = (const char *)in + (int64_t)s_ * (g.Cin >> 3) * plane8 + ((int64_t)h0_ * g.W + w0_) * 32;     \
     }
-// k-step KS_ of the group set up last -> ring entry E_: four masked 1 KB copies (one per channel quad); lanes of the plane
-// without a pixel get zeros
+// k-step KS_ of the group set up last -> ring entry E_ (< 2 W23_RING): four masked 1 KB copies (one per channel quad) under one
+// EXEC change; lanes of the plane without a pixel get zeros
 #define W23_DMA_KSTEP(KS_, E_)                                                                                   \
     if (!(W23_ABL & 4)) {                                                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
-            const char *sb_ = dma_base + (int64_t)(2 * (KS_) + (q_ >> 1)) * plane8 + (q_ & 1) * 16;               \
-            const unsigned dst_ = dma_lds + (unsigned)((E_) * W23_ENTRY + q_ * 4 * W23_PLANE * 16);              \
-            uint64_t keep_;                                                                                      \
-            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"          \
-                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                  \
-                         : "=&s"(keep_)                                                                          \
-                         : "v"(dma_voff), "s"(sb_), "s"(dst_), "s"(dma_mask)                                     \
-                         : "memory");                                                                            \
-            if (dma_edge && lane < W23_PLANE && !((dma_mask >> lane) & 1))                                       \
-                *(f32x4 *)(ring + (E_) * W23_ENTRY + (q_ * 4 + wv) * W23_PLANE * 16 + lane * 16) = (f32x4)(0.0f); \
+        const char *sb0_ = dma_base + (int64_t)(2 * (KS_)) * plane8, *sb2_ = sb0_ + plane8;                      \
+        const unsigned dst_ = dma_lds + (unsigned)(W23_ENT(E_) * W23_ENTRY);                                     \
+        uint64_t keep_;                                                                                          \
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %10\n\t"                                            \
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"                         \
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"                         \
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"                         \
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"                         \
+                     "s_mov_b64 exec, %0"                                                                        \
+                     : "=&s"(keep_)                                                                              \
+                     : "v"(dma_voff), "s"(sb0_), "s"(sb0_ + 16), "s"(sb2_), "s"(sb2_ + 16),                      \
+                       "s"(dst_), "s"(dst_ + 4 * W23_PLANE * 16), "s"(dst_ + 8 * W23_PLANE * 16), "s"(dst_ + 12 * W23_PLANE * 16), \
+                       "s"(dma_mask)                                                                             \
+                     : "memory");                                                                                \
+        if (dma_edge && lane < W23_PLANE && !((dma_mask >> lane) & 1)) {                                         \
+            char *z_ = ring + W23_ENT(E_) * W23_ENTRY + wv * W23_PLANE * 16 + lane * 16;                         \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) *(f32x4 *)(z_ + q_ * 4 * W23_PLANE * 16) = (f32x4)(0.0f); \
         }                                                                                                        \
     }
 
     f32x16 acc[4][NB];
-    // epilogue state of the previous group
-    int e_s = 0, e_band = 0, e_txb = 0;
-    bool e_have = false;
-
-    // ---- prologue: the first group's four k-steps -------------------------------------------------------------------------
-    int ent = 0;  // ring entry of the current group's k-step 0
-    W23_DMA_SETUP(g_lo)
-    W23_DMA_KSTEP(0, 0) W23_DMA_KSTEP(1, 1) W23_DMA_KSTEP(2, 2) W23_DMA_KSTEP(3, 3)
-
-    for (int gi = g_lo; gi <= g_hi; ++gi) {
-        const bool have = gi < g_hi;        // a group to multiply (the last trip only finishes the previous group's outputs)
-        const bool more = gi + 1 < g_hi;    // a group to fetch
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W23_BARRIER()  // B1: this group's patch has landed; the previous group's Z are in the exchange buffer
-        int e1 = ent + 4, e2 = ent + 5, e3 = ent + 6, e0n = ent;  // entries of the next group's k-steps 0, 1, 2; 3 reuses this group's k-step 0
-        e1 = e1 >= W23_RING ? e1 - W23_RING : e1;
-        e2 = e2 >= W23_RING ? e2 - W23_RING : e2;
-        e3 = e3 >= W23_RING ? e3 - W23_RING : e3;
-        if (more) {
-            W23_DMA_SETUP(gi + 1)
-            W23_DMA_KSTEP(0, e1) W23_DMA_KSTEP(1, e2) W23_DMA_KSTEP(2, e3)
-        }
-        float sv = 1.0f;
-        if (have) {
-            W23_COORDS(gi, gs, gband, gtxb)
-            sv = w23_vscale(g.amax_in[gs]);
-            if (W23_ABL & 2) {
+    unsigned bh[4][4], bl[4][4];        // B operands of the four positions: 8 channels as f16 hi / lo (2 per register)
+    f32x4 tt[2][4], dA[2], dB[2], vv[2];
+    const char *pa = ring, *pb = ring;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int n = 0; n < NB; ++n)
+        for (int x = 0; x < 4; ++x) { bh[j][x] = (W23_ABL & 1) ? 0x3c003c00u : 0u; bl[j][x] = 0u; }
+    if (W23_ABL & 2) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
-            }
-        }
-
-        // ---- the previous group's outputs: this wave's quarter (NB register quads) of Y = sum_i A^T[.][i] Z_i ----------------
-        if (e_have && !(W23_ABL & 8)) {
-            const float esc = u_inv / w23_vscale(g.amax_in[e_s]);
-            unsigned mx = 0;
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int u = wv * NB + k, n = u >> 2, rq = u & 3;
-                f32x4 Z[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) Z[i][c] = *(const f32x4 *)(xch + ((((i * 2 + c) * NB + n) * 4 + rq) * 64 + lane) * 16);
-                const int cl = 32 * n + 8 * rq + 4 * half;  // first of the lane's 4 output channels inside the block
-                const f32x4 sc = *(const f32x4 *)(bnp + cl) * esc, sh = *(const f32x4 *)(bnp + 32 * NB + cl);
-                f32x4 Y[2][2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    Y[0][c] = (Z[0][c] + Z[1][c]) + Z[2][c];
-                    Y[1][c] = (Z[1][c] - Z[2][c]) - Z[3][c];
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) Y[r][c] = __builtin_elementwise_max(Y[r][c] * sc + sh, (f32x4)(0.0f));
-                }
-                const int co = cb * 32 * NB + cl;
-                if (POOL) {
-                    const int oh = 2 * e_band + ty, ow = 16 * e_txb + tx;
-                    if (oh < g.Ho && ow < g.Wo) {
-                        const f32x4 v = (((Y[0][0] + Y[0][1]) + Y[1][0]) + Y[1][1]) * 0.25f;
-                        *(f32x4 *)(out + act_off(e_s, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
-                        mx = max(mx, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])), max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            const int hh = 4 * e_band + 2 * ty + r, ww = 32 * e_txb + 2 * tx + c;
-                            if (hh < g.H && ww < g.W) {
-                                const f32x4 v = Y[r][c];
-                                *(f32x4 *)(out + act_off(e_s, co, hh, ww, g.Cout, g.H, g.W)) = v;
-                                mx = max(mx, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])), max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
-                            }
-                        }
-                }
-            }
-            if (g.amax_out != nullptr) {  // one atomic per wave and group at most (the maximum only grows: skip when covered)
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
-                if (lane == 0 && mx > __hip_atomic_load(g.amax_out + e_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.amax_out + e_s, mx);
-            }
-        }
-
-        if (have) {
-            // ---- four k-steps: transform in registers, 6 NB products per position ---------------------------------------------
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                int e = ent + ks;
-                e = e >= W23_RING ? e - W23_RING : e;
-                const char *eb = ring + e * W23_ENTRY;
-                unsigned vh[4][4], vl[4][4];  // B operands of the four positions: 8 channels as f16 hi / lo
-                if (!(W23_ABL & 1)) {
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        f32x4 t[4];
-#pragma unroll
-                        for (int bb = 0; bb < 4; ++bb) {
-                            const f32x4 d1 = *(const f32x4 *)(eb + rd1 + W23_RDOFF(bb, qq));
-                            const f32x4 d2 = *(const f32x4 *)(eb + rd2 + W23_RDOFF(bb, qq));
-                            const f32x2 lo = pk_fma(P2(d2, 0), sg2, P2(d1, 0)), hi = pk_fma(P2(d2, 1), sg2, P2(d1, 1));
-                            t[bb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-                        }
-                        f32x4 V[4];
-#define W23_PK4(OP, A_, B_) __builtin_shufflevector(OP(P2(A_, 0), P2(B_, 0)), OP(P2(A_, 1), P2(B_, 1)), 0, 1, 2, 3)
-                        V[0] = W23_PK4(pk_sub, t[0], t[2]);
-                        V[1] = W23_PK4(pk_add, t[1], t[2]);
-                        V[2] = W23_PK4(pk_sub, t[2], t[1]);
-                        V[3] = W23_PK4(pk_sub, t[1], t[3]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            W23_SPLIT(vh[j][2 * qq], vl[j][2 * qq], V[j][0], sv, 0)
-                            W23_SPLIT(vh[j][2 * qq], vl[j][2 * qq], V[j][1], sv, 1)
-                            W23_SPLIT(vh[j][2 * qq + 1], vl[j][2 * qq + 1], V[j][2], sv, 0)
-                            W23_SPLIT(vh[j][2 * qq + 1], vl[j][2 * qq + 1], V[j][3], sv, 1)
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) { vh[j][x] = 0x3c003c00u; vl[j][x] = 0; }
-                }
-                if (!(W23_ABL & 2)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const ru4 h4 = {vh[j][0], vh[j][1], vh[j][2], vh[j][3]}, l4 = {vl[j][0], vl[j][1], vl[j][2], vl[j][3]};
-                        const rh8 bh = __builtin_bit_cast(rh8, h4), bl = __builtin_bit_cast(rh8, l4);
-#pragma unroll
-                        for (int n = 0; n < NB; ++n) {
-                            if (ks == 0) { W23_MFMA0(acc[j][n], Wt[j][ks][n][1], bh) } else { W23_MFMA(acc[j][n], Wt[j][ks][n][1], bh) }
-                            W23_MFMA(acc[j][n], Wt[j][ks][n][0], bl)
-                            W23_MFMA(acc[j][n], Wt[j][ks][n][0], bh)
-                        }
-                    }
-                }
-                if (ks == 0) {
-                    W23_BARRIER()  // B2: every wave has read k-step 0 of this group and the previous group's Z
-                    if (more) { W23_DMA_KSTEP(3, e0n) }
-                }
-            }
-            if constexpr (NB == 2)
-                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
-            else
-                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
-            // ---- Z_i[c] = sum_j M(i, j) A[j][c]:  c = 0: M0 + M1 + M2,  c = 1: M1 - M2 - M3; into the exchange buffer -----------------
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    f32x4 m[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) m[j] = (f32x4){acc[j][n][4 * rq], acc[j][n][4 * rq + 1], acc[j][n][4 * rq + 2], acc[j][n][4 * rq + 3]};
-                    const f32x4 z0 = (m[0] + m[1]) + m[2], z1 = (m[1] - m[2]) - m[3];
-                    *(f32x4 *)(xch + ((((wv * 2 + 0) * NB + n) * 4 + rq) * 64 + lane) * 16) = z0;
-                    *(f32x4 *)(xch + ((((wv * 2 + 1) * NB + n) * 4 + rq) * 64 + lane) * 16) = z1;
-                }
-        } else {
-            W23_BARRIER()  // keep the barrier count of the other trips
-        }
-        e_have = have;
-        e_s = gs; e_band = gband; e_txb = gtxb;
-        ent += 4;
-        ent = ent >= W23_RING ? ent - W23_RING : ent;
+                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
     }
+
+    // ---- epilogue of a group (the group before the one being multiplied): this wave's NB register quads of the outputs -------
+    int e_s = 0, e_band = 0, e_txb = 0;
+    bool e_have = false;
+    const char *ex = xch;
+    f32x4 e_sc, e_sh, Zr[4], Yk[2][2];
+    float e_esc = 1.0f;
+    int e_co8 = 0;
+    unsigned mx = 0;   // largest stored output of this lane since the last flush, of stream mx_s
+    int mx_s = -1;
+    // per-lane part of the output offset (floats) and validity limits
+    const int o_lane = POOL ? (ty * g.Wo + tx) * 8 + 4 * half : ((2 * ty) * g.W + 2 * tx) * 8 + 4 * half;
+#define W23_AMAX_FLUSH()                                                                                         \
+    if (g.amax_out != nullptr && mx_s >= 0) {                                                                    \
+        unsigned m_ = mx;                                                                                        \
+        _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) m_ = max(m_, (unsigned)__shfl_xor((int)m_, o_, 64)); \
+        if (lane == 0 && m_ > __hip_atomic_load(g.amax_out + mx_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.amax_out + mx_s, m_); \
+    }
+#define W23_E_BEGIN()                                                                                            \
+    if (!(W23_ABL & 8)) {                                                                                        \
+        e_esc = u_inv / w23_vscale_s(g.amax_in[e_s]);                                                            \
+        if (e_s != mx_s) { W23_AMAX_FLUSH() mx = 0; mx_s = e_s; }                                                \
+    }
+#define W23_E_SETUP(K_)                                                                                          \
+    if (!(W23_ABL & 8)) {                                                                                        \
+        const int u_ = wv * NB + (K_), n_ = u_ >> 2, rq_ = u_ & 3;                                               \
+        ex = xch + ((n_ * 4 + rq_) * 64 + lane) * 16;                                                            \
+        const int cl_ = 32 * n_ + 8 * rq_ + 4 * half;                                                            \
+        e_sc = *(const f32x4 *)(bnp + cl_) * e_esc;                                                              \
+        e_sh = *(const f32x4 *)(bnp + 32 * NB + cl_);                                                            \
+        e_co8 = cb * 4 * NB + 4 * n_ + rq_;                                                                      \
+    }
+#define W23_E_LD(C_)                                                                                             \
+    if (!(W23_ABL & 8)) {                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Zr[i_] = *(const f32x4 *)(ex + ((i_ * 2 + (C_)) * NB * 4 * 64) * 16); \
+    }
+#define W23_A4(A_, B_) W23_PK4(pk_add, A_, B_)
+#define W23_S4(A_, B_) W23_PK4(pk_sub, A_, B_)
+#define W23_F4(A_, B_, C_) __builtin_shufflevector(pk_fma(P2(A_, 0), P2(B_, 0), P2(C_, 0)), pk_fma(P2(A_, 1), P2(B_, 1), P2(C_, 1)), 0, 1, 2, 3)
+#define W23_E_Y(C_)                                                                                              \
+    if (!(W23_ABL & 8)) {                                                                                        \
+        const f32x4 y0_ = W23_A4(W23_A4(Zr[0], Zr[1]), Zr[2]), y1_ = W23_S4(W23_S4(Zr[1], Zr[2]), Zr[3]);        \
+        Yk[0][C_] = __builtin_elementwise_max(W23_F4(y0_, e_sc, e_sh), (f32x4)(0.0f));                           \
+        Yk[1][C_] = __builtin_elementwise_max(W23_F4(y1_, e_sc, e_sh), (f32x4)(0.0f));                           \
+    }
+#define W23_MAX4(V_) max(max(__float_as_uint((V_)[0]), __float_as_uint((V_)[1])), max(__float_as_uint((V_)[2]), __float_as_uint((V_)[3])))
+#define W23_E_ST(K_)                                                                                             \
+    if (!(W23_ABL & 8)) {                                                                                        \
+        if (POOL) {                                                                                              \
+            const int64_t ob_ = ((((int64_t)e_s * (g.Cout >> 3) + e_co8) * g.Ho + 2 * e_band) * g.Wo + 16 * e_txb) * 8; \
+            if (e_have && 2 * e_band + ty < g.Ho && 16 * e_txb + tx < g.Wo) {                                    \
+                const f32x2 q2_ = {0.25f, 0.25f};                                                                \
+                const f32x4 s_ = W23_A4(W23_A4(W23_A4(Yk[0][0], Yk[0][1]), Yk[1][0]), Yk[1][1]);                  \
+                const f32x4 v_ = __builtin_shufflevector(pk_mul(P2(s_, 0), q2_), pk_mul(P2(s_, 1), q2_), 0, 1, 2, 3); \
+                *(f32x4 *)(out + ob_ + o_lane) = v_;                                                             \
+                mx = max(mx, W23_MAX4(v_));                                                                      \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            const int64_t ob_ = ((((int64_t)e_s * (g.Cout >> 3) + e_co8) * g.H + 4 * e_band) * g.W + 32 * e_txb) * 8; \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                     \
+                _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                 \
+                    if (e_have && 4 * e_band + 2 * ty + r_ < g.H && 32 * e_txb + 2 * tx + c_ < g.W) {            \
+                        *(f32x4 *)(out + ob_ + o_lane + (r_ * g.W + c_) * 8) = Yk[r_][c_];                       \
+                        mx = max(mx, W23_MAX4(Yk[r_][c_]));                                                      \
+                    }                                                                                            \
+        }                                                                                                        \
+    }
+// Z_i[c] = sum_j M(i, j) A[j][c]:  c = 0: M0 + M1 + M2,  c = 1: M1 - M2 - M3 -> exchange buffer.  The drain (>= 18 wait states
+// behind the last 16-pass MFMA) stands in front of the first VALU read of an accumulator; the barrier behind the writes makes
+// them visible to the next phase 0, where every wave finishes its share of this group's outputs.
+#define W23_ZSTORE()                                                                                             \
+    if (!(W23_ABL & 16)) {                                                                                       \
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1])); \
+        _Pragma("unroll") for (int n_ = 0; n_ < NB; ++n_)                                                        \
+            _Pragma("unroll") for (int rq_ = 0; rq_ < 4; ++rq_) {                                                \
+                f32x4 m_[4];                                                                                     \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) m_[j_] = (f32x4){acc[j_][n_][4 * rq_], acc[j_][n_][4 * rq_ + 1], acc[j_][n_][4 * rq_ + 2], acc[j_][n_][4 * rq_ + 3]}; \
+                const f32x4 z0_ = W23_A4(W23_A4(m_[0], m_[1]), m_[2]), z1_ = W23_S4(W23_S4(m_[1], m_[2]), m_[3]); \
+                *(f32x4 *)(xch + ((((wv * 2 + 0) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = z0_;                 \
+                *(f32x4 *)(xch + ((((wv * 2 + 1) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = z1_;                 \
+            }                                                                                                    \
+    }                                                                                                            \
+    W23_BARRIER()
+
+    // coordinates / scale of the group being multiplied and of the next one
+    int gs, gband, gtxb, ns = 0, nband = 0, ntxb = 0;
+    float sv, sv_n = 1.0f;
+#define W23_NEXT_COORDS() { W23_COORDS(gi + 1, ns, nband, ntxb) sv_n = w23_vscale_s(g.amax_in[ns]); }
+#define W23_ROTATE()                                                                                             \
+    {                                                                                                            \
+        e_have = true; e_s = gs; e_band = gband; e_txb = gtxb;                                                   \
+        gs = ns; gband = nband; gtxb = ntxb; sv = sv_n;                                                          \
+        ent = W23_ENT(ent + 4);                                                                                  \
+    }
+
+    // ---- prologue: the first group's four k-steps (entries 0..3) and the second group's first two (entries 4, 5); t and the
+    // position-0 operands of the first k-step ------------------------------------------------------------------------------
+    int ent = 0;  // ring entry of the current group's k-step 0
+    W23_DMA_SETUP(g_lo)
+    W23_DMA_KSTEP(0, 0) W23_DMA_KSTEP(1, 1) W23_DMA_KSTEP(2, 2) W23_DMA_KSTEP(3, 3)
+    if (g_lo + 1 < g_hi) {
+        W23_DMA_SETUP(g_lo + 1)
+        W23_DMA_KSTEP(0, 4) W23_DMA_KSTEP(1, 5)
+    }
+    W23_COORDS(g_lo, gs, gband, gtxb)
+    sv = w23_vscale_s(g.amax_in[gs]);
+    W23_X()
+    W23_SETP(0)
+    W23_LD(0, 0) W23_LD(0, 1) W23_TT(0, 0) W23_TT(0, 1) W23_LD(0, 2) W23_LD(0, 3) W23_TT(0, 2) W23_TT(0, 3)
+    W23_LD(1, 0) W23_LD(1, 1) W23_TT(1, 0) W23_TT(1, 1) W23_LD(1, 2) W23_LD(1, 3) W23_TT(1, 2) W23_TT(1, 3)
+    W23_VV(0, 0, 0) W23_SH(0, 0, 0, sv) W23_VV(1, 0, 1) W23_SH(1, 0, 1, sv) W23_SL(0, 0, 0, sv) W23_SL(1, 0, 1, sv)
+    W23_FENCE()
+
+#include "conv_wino23r_body.inc"
+
+    // ---- the last group's outputs (its Z are behind W23_ZSTORE's barrier; e_have is true: the loop ran at least once) -------------
+    W23_E_BEGIN()
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        W23_E_SETUP(k) W23_E_LD(0) W23_E_Y(0) W23_E_LD(1) W23_E_Y(1) W23_E_ST(k)
+    }
+    W23_AMAX_FLUSH()
 }
 
 // ---- weights: U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], float64, rounded once to float32), scaled by the layer's
