@@ -44,7 +44,7 @@ static constexpr int W23_ENTRY = 4 * 4 * W23_PLANE * 16;    // bytes of one k-st
 static constexpr int W23_RING = 6;  // k-step entries: the four of the group being read + two in flight (see conv_wino23r_body.inc)
 
 #ifndef W23_ABL
-#define W23_ABL 0  // timing-experiment bit mask (1 no transform, 2 no MFMAs, 4 no DMA, 8 no epilogue); 0 in every build that ships
+#define W23_ABL 0  // timing-experiment bit mask (1 no transform, 2 no MFMAs, 4 no DMA, 8 no epilogue, 16 no Z exchange); 0 in every build that ships
 #endif
 
 // power-of-two scale of a stream's transformed input: |B^T d B| <= 4 max|d|, amax < 2^e -> 2^(12 - e): below 2^14
@@ -67,17 +67,8 @@ struct W23Geom {
     const unsigned *amax_in;   // per stream: largest input activation (bit pattern)
     unsigned *amax_out;        // or NULL: per stream, the largest output (atomicMax; zeroed by the caller)
     const float *u_inv;        // 1 / weight scale (header of the packed weights)
+    long long *clk;            // or NULL (STITO_W23_CLK=1, a measurement aid): {shader clock, 100 MHz clock} at the start / end of one workgroup
 };
-
-// hi = rn16(s v), lo = rn16(s v - hi) into the low (E = 0) or high (E = 1) half of one register each
-#define W23_SPLIT(HI, LO, V, SC, E)                                                                              \
-    if ((E) == 0) {                                                                                              \
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(HI) : "v"(V), "s"(SC));                             \
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(LO) : "v"(V), "s"(SC), "v"(HI)); \
-    } else {                                                                                                     \
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(HI) : "v"(V), "s"(SC));                             \
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(LO) : "v"(V), "s"(SC), "v"(HI)); \
-    }
 
 #define W23_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 // The products are inline asm so that the weight operand can be pinned to the AGPR half of the register file ("a": hipcc
@@ -89,6 +80,7 @@ struct W23Geom {
 #define W23_MFMA0(ACC, A_, B_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "a"(A_), "v"(B_));
 #define W23_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(A_), "v"(B_));
 #define P2(v, h) __builtin_shufflevector(v, v, 2 * (h), 2 * (h) + 1)
+#define H2(v, h) ((f32x2){(v)[2 * (h)], (v)[2 * (h) + 1]})   // the same with an index that is only constant after unrolling
 
 // scale as a bit pattern built with integer arithmetic only (the value stays in a scalar register: it is the SGPR operand of
 // every v_fma_mix of the transform)
@@ -99,51 +91,17 @@ __device__ __forceinline__ float w23_vscale_s(unsigned amax_bits) {
     return __uint_as_float((unsigned)(127 + 12 - e) << 23);
 }
 
-template <int J>
-__device__ __forceinline__ f32x4 w23_vcomb(const f32x4 (&t)[4]) {  // V(i, j) = sum_b t[b] B[b][j],  B^T rows as in the kernel header
 #define W23_PK4(OP, A_, B_) __builtin_shufflevector(OP(P2(A_, 0), P2(B_, 0)), OP(P2(A_, 1), P2(B_, 1)), 0, 1, 2, 3)
-    if (J == 0) return W23_PK4(pk_sub, t[0], t[2]);
-    if (J == 1) return W23_PK4(pk_add, t[1], t[2]);
-    if (J == 2) return W23_PK4(pk_sub, t[2], t[1]);
-    return W23_PK4(pk_sub, t[1], t[3]);
-}
-
 #define W23_FENCE() __builtin_amdgcn_sched_barrier(0);
 #define W23_ENT(E_) ((E_) >= W23_RING ? (E_) - W23_RING : (E_))
 #define W23_X() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); W23_BARRIER()
-#define W23_BH(J) __builtin_bit_cast(rh8, (ru4){bh[J][0], bh[J][1], bh[J][2], bh[J][3]})
-#define W23_BL(J) __builtin_bit_cast(rh8, (ru4){bl[J][0], bl[J][1], bl[J][2], bl[J][3]})
-// product P of position J, channel half N, k-step KS_: lo' hi, hi' lo, hi' hi (the large term last); the first one of a group
-// starts the accumulator from the inline constant 0
-#define W23_MF(J, N, P, KS_)                                                                                     \
-    if (!(W23_ABL & 2)) {                                                                                        \
-        if ((P) == 0) { if ((KS_) == 0) { W23_MFMA0(acc[J][N], Wt[J][KS_][N][1], W23_BH(J)) } else { W23_MFMA(acc[J][N], Wt[J][KS_][N][1], W23_BH(J)) } } \
-        else if ((P) == 1) { W23_MFMA(acc[J][N], Wt[J][KS_][N][0], W23_BL(J)) }                                  \
-        else { W23_MFMA(acc[J][N], Wt[J][KS_][N][0], W23_BH(J)) }                                                \
-    }
+#define W23_BH(J) __builtin_bit_cast(rh8, bhv[J])
+#define W23_BL(J) __builtin_bit_cast(rh8, blv[J])
 // the k-step whose patch rows are read next lives in ring entry E_ (< 2 W23_RING)
 #define W23_SETP(E_) { const int eo_ = W23_ENT(E_) * W23_ENTRY; pa = ring + eo_ + rd1; pb = ring + eo_ + rd2; }
-#define W23_LD(QQ, B_) if (!(W23_ABL & 1)) { dA[(B_) & 1] = *(const f32x4 *)(pa + W23_RDOFF(B_, QQ)); dB[(B_) & 1] = *(const f32x4 *)(pb + W23_RDOFF(B_, QQ)); }
-#define W23_TT(QQ, B_) if (!(W23_ABL & 1)) { tt[QQ][B_] = __builtin_shufflevector(pk_fma(P2(dB[(B_) & 1], 0), sg2, P2(dA[(B_) & 1], 0)), pk_fma(P2(dB[(B_) & 1], 1), sg2, P2(dA[(B_) & 1], 1)), 0, 1, 2, 3); }
-#define W23_VV(QQ, J, T_) if (!(W23_ABL & 1)) { vv[T_] = w23_vcomb<J>(tt[QQ]); }
-// hi halves of the four values of a unit: registers 2 QQ (values 0, 1) and 2 QQ + 1 (values 2, 3); the two writes of a register
-// (low half, high half) are kept apart.  The low-half write is declared a plain output ("=v": v_fma_mixlo_f16 keeps the upper
-// half of its destination, but whatever was there is overwritten by the mixhi that follows), so an operand register is dead
-// between its last product and its next transform instead of live for the whole loop
-#define W23_SH(QQ, J, T_, SV_)                                                                                   \
-    if (!(W23_ABL & 1)) {                                                                                        \
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[J][2 * (QQ)]) : "v"(vv[T_][0]), "s"(SV_));        \
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[J][2 * (QQ) + 1]) : "v"(vv[T_][2]), "s"(SV_));    \
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[J][2 * (QQ)]) : "v"(vv[T_][1]), "s"(SV_));        \
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[J][2 * (QQ) + 1]) : "v"(vv[T_][3]), "s"(SV_));    \
-    }
-#define W23_SL(QQ, J, T_, SV_)                                                                                   \
-    if (!(W23_ABL & 1)) {                                                                                        \
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(bl[J][2 * (QQ)]) : "v"(vv[T_][0]), "s"(SV_), "v"(bh[J][2 * (QQ)])); \
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(bl[J][2 * (QQ) + 1]) : "v"(vv[T_][2]), "s"(SV_), "v"(bh[J][2 * (QQ) + 1])); \
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[J][2 * (QQ)]) : "v"(vv[T_][1]), "s"(SV_), "v"(bh[J][2 * (QQ)])); \
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[J][2 * (QQ) + 1]) : "v"(vv[T_][3]), "s"(SV_), "v"(bh[J][2 * (QQ) + 1])); \
-    }
+#define W23_LD(QQ, B_) { dA[(B_) & 1] = *(const f32x4 *)(pa + W23_RDOFF(B_, QQ)); dB[(B_) & 1] = *(const f32x4 *)(pb + W23_RDOFF(B_, QQ)); }
+
+struct W23Cur { int s, band, txb; };  // pixel group = (stream, band of 2 tile rows, block of 16 tile columns)
 
 template <int KS, int NB, bool POOL>
 __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__restrict__ in, const char *__restrict__ wpk,
@@ -167,6 +125,9 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     const int wi = (b & 7) + 8 * ((b >> 3) / g.n_cb);
     const int g_lo = (int)((int64_t)g.n_groups * wi / g.wg_per_cb), g_hi = (int)((int64_t)g.n_groups * (wi + 1) / g.wg_per_cb);
     if (g_lo >= g_hi) return;
+    const bool clk_on = g.clk != nullptr && blockIdx.x == (gridDim.x >> 1) && wv == 0;
+    long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_on) { clk_c0 = (long long)__builtin_readcyclecounter(); clk_r0 = (long long)__builtin_amdgcn_s_memrealtime(); }
 
     // ---- weights: [cb][wave][j][ks][n][hi | lo][lane] x 16 B, read once, pinned to the AGPRs by the products' "a" operands ------
     rh8 Wt[4][KS][NB][2];
@@ -185,7 +146,7 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
         bnp[tid] = scale[cb * 32 * NB + tid];
         bnp[32 * NB + tid] = shift[cb * 32 * NB + tid];
     }
-    const float u_inv = g.u_inv[0];
+    const unsigned u_inv_bits = __float_as_uint(g.u_inv[0]);  // 1 / weight scale: a power of two
 
     // ---- lane -> tile: the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) each get one
     // tile row (16 consecutive 16-byte slots of a parity plane)
@@ -203,65 +164,71 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     const int rd2 = rd_lane + (((a2 & 1) * 2) * W23_PLANE + (a2 >> 1) * 17) * 16;
 #define W23_RDOFF(B_, QQ_) ((((QQ_) * 4 + ((B_) & 1)) * W23_PLANE + ((B_) >> 1)) * 16)
 
-    // ---- patch copies: wave w copies parity plane w; lane L < 51 -> plane pixel (L / 17, L % 17) -> patch pixel (y, x) -------
+    // ---- pixel-group cursors: advanced by compare-and-wrap, no divisions in the loop (one instruction costs this wave ~8 cycles
+    // whatever it is: the per-group bookkeeping of the first version -- three pairs of divisions -- was 1 400 cycles) ---------------
+#define W23_ADV(C_) { if (++(C_).txb == g.n_txb) { (C_).txb = 0; if (++(C_).band == g.n_bands) { (C_).band = 0; ++(C_).s; } } }
+    W23Cur cC, cB, cA, cD = {0, 0, 0};  // the group being multiplied, the next one, the one after, the previous one
+    {
+        int r_;
+        cC.s = fdiv(g_lo, g.fGPS, r_);
+        cC.band = fdiv(r_, g.fTXB, cC.txb);
+    }
+    cB = cC; W23_ADV(cB)
+    cA = cB; W23_ADV(cA)
+
+    // ---- patch copies: wave w copies parity plane w; lane L < 51 -> plane pixel (L / 17, L % 17) -> patch pixel (dy, dx).  A lane
+    // has a pixel unless its group touches the map's border: four launch-constant lane masks (top row of bands, bottom row,
+    // leftmost column of groups, rightmost) ------------------------------------------------------------------------------------
     const int dy = 2 * (lane / 17) + (wv >> 1), dx = 2 * (lane % 17) + (wv & 1);
     const unsigned dma_voff = (unsigned)((dy * g.W + dx) * 32);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned dma_lds = lds0 + (unsigned)(wv * W23_PLANE * 16);
-    const int64_t plane8 = (int64_t)g.H * g.W * 32;  // bytes per channel octet of one stream
-
-#define W23_COORDS(G_, S_, BAND_, TXB_)                                                                          \
-    {                                                                                                            \
-        int r_;                                                                                                  \
-        S_ = fdiv((G_), g.fGPS, r_);                                                                             \
-        BAND_ = fdiv(r_, g.fTXB, TXB_);                                                                          \
-    }
-    // DMA state of the group set up last
+    char *const zf_lane = ring + wv * W23_PLANE * 16 + lane * 16;  // this lane's slot of plane wv, quad 0, entry 0
+    const int64_t plane8 = (int64_t)g.H * g.W * 32;               // bytes per channel octet of one stream
+    const int64_t in_ss = (int64_t)(g.Cin >> 3) * plane8;          // bytes per stream
+    const int in_bs = 4 * g.W * 32, in_o0 = -(g.W + 1) * 32;       // bytes per band; patch origin (-1, -1) of group (0, 0)
+    const uint64_t m_all = (1ull << W23_PLANE) - 1;
+    const uint64_t m_top = __builtin_amdgcn_ballot_w64(lane < W23_PLANE && dy >= 1);
+    const uint64_t m_bot = __builtin_amdgcn_ballot_w64(lane < W23_PLANE && 4 * (g.n_bands - 1) - 1 + dy < g.H);
+    const uint64_t m_left = __builtin_amdgcn_ballot_w64(lane < W23_PLANE && dx >= 1);
+    const uint64_t m_right = __builtin_amdgcn_ballot_w64(lane < W23_PLANE && 32 * (g.n_txb - 1) - 1 + dx < g.W);
     uint64_t dma_mask = 0;
     const char *dma_base = nullptr;
     bool dma_edge = false;
-#define W23_DMA_SETUP(G_)                                                                                        \
+#define W23_DMA_PREP(C_)                                                                                         \
     {                                                                                                            \
-        int s_, band_, txb_;                                                                                     \
-        W23_COORDS(G_, s_, band_, txb_)                                                                          \
-        const int h0_ = 4 * band_ - 1, w0_ = 32 * txb_ - 1;                                                      \
-        const bool ok_ = lane < W23_PLANE && h0_ + dy >= 0 && h0_ + dy < g.H && w0_ + dx >= 0 && w0_ + dx < g.W; \
-        dma_mask = __builtin_amdgcn_ballot_w64(ok_);                                                             \
-        dma_edge = dma_mask != ((1ull << W23_PLANE) - 1);                                                        \
-        dma_base = (const char *)in + (int64_t)s_ * (g.Cin >> 3) * plane8 + ((int64_t)h0_ * g.W + w0_) * 32;     \
+        uint64_t m_ = m_all;                                                                                     \
+        if ((C_).band == 0) m_ &= m_top;                                                                         \
+        if ((C_).band == g.n_bands - 1) m_ &= m_bot;                                                             \
+        if ((C_).txb == 0) m_ &= m_left;                                                                         \
+        if ((C_).txb == g.n_txb - 1) m_ &= m_right;                                                              \
+        dma_mask = m_;                                                                                           \
+        dma_edge = m_ != m_all;                                                                                  \
+        dma_base = (const char *)in + ((int64_t)(C_).s * in_ss + ((C_).band * in_bs + (C_).txb * 1024 + in_o0)); \
     }
-// k-step KS_ of the group set up last -> ring entry E_ (< 2 W23_RING): four masked 1 KB copies (one per channel quad) under one
-// EXEC change; lanes of the plane without a pixel get zeros
-#define W23_DMA_KSTEP(KS_, E_)                                                                                   \
+// channel quad Q_ of k-step KS_ of the group prepared last -> ring entry E_ (< 2 W23_RING): one masked 1 KB copy; the lanes of the
+// plane without a pixel get zeros
+#define W23_DMA_Q(KS_, E_, Q_)                                                                                   \
     if (!(W23_ABL & 4)) {                                                                                        \
-        const char *sb0_ = dma_base + (int64_t)(2 * (KS_)) * plane8, *sb2_ = sb0_ + plane8;                      \
-        const unsigned dst_ = dma_lds + (unsigned)(W23_ENT(E_) * W23_ENTRY);                                     \
+        const char *sb_ = dma_base + (int64_t)(2 * (KS_) + ((Q_) >> 1)) * plane8 + ((Q_) & 1) * 16;               \
+        const int eo_ = W23_ENT(E_) * W23_ENTRY + (Q_) * 4 * W23_PLANE * 16;                                     \
         uint64_t keep_;                                                                                          \
-        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %10\n\t"                                            \
-                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"                         \
-                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"                         \
-                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"                         \
-                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"                         \
-                     "s_mov_b64 exec, %0"                                                                        \
-                     : "=&s"(keep_)                                                                              \
-                     : "v"(dma_voff), "s"(sb0_), "s"(sb0_ + 16), "s"(sb2_), "s"(sb2_ + 16),                      \
-                       "s"(dst_), "s"(dst_ + 4 * W23_PLANE * 16), "s"(dst_ + 8 * W23_PLANE * 16), "s"(dst_ + 12 * W23_PLANE * 16), \
-                       "s"(dma_mask)                                                                             \
-                     : "memory");                                                                                \
-        if (dma_edge && lane < W23_PLANE && !((dma_mask >> lane) & 1)) {                                         \
-            char *z_ = ring + W23_ENT(E_) * W23_ENTRY + wv * W23_PLANE * 16 + lane * 16;                         \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) *(f32x4 *)(z_ + q_ * 4 * W23_PLANE * 16) = (f32x4)(0.0f); \
-        }                                                                                                        \
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"              \
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                      \
+                     : "=&s"(keep_) : "v"(dma_voff), "s"(sb_), "s"(dma_lds + (unsigned)eo_), "s"(dma_mask) : "memory"); \
+        if (dma_edge && lane < W23_PLANE && !((dma_mask >> lane) & 1)) *(f32x4 *)(zf_lane + eo_) = (f32x4)(0.0f); \
     }
 
     f32x16 acc[4][NB];
-    unsigned bh[4][4], bl[4][4];        // B operands of the four positions: 8 channels as f16 hi / lo (2 per register)
-    f32x4 tt[2][4], dA[2], dB[2], vv[2];
+    ru4 bhv[4], blv[4];            // B operands of the four positions: 8 channels as f16 hi / lo (2 per register)
+    f32x2 tt[2][4][2];             // t[quad][patch column][channel pair]
+    f32x4 dA[2], dB[2];            // patch rows a1 / a2 in flight
+    float vtmp[4];
     const char *pa = ring, *pb = ring;
+    if (W23_ABL & 1) {   // timing experiments only: constant operands / accumulators in place of the ablated producers
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { bh[j][x] = (W23_ABL & 1) ? 0x3c003c00u : 0u; bl[j][x] = 0u; }
+        for (int j = 0; j < 4; ++j) { bhv[j] = (ru4)(0x3c003c00u); blv[j] = (ru4)(0u); }
+    }
     if (W23_ABL & 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -271,34 +238,37 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
                 for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
     }
 
-    // ---- epilogue of a group (the group before the one being multiplied): this wave's NB register quads of the outputs -------
-    int e_s = 0, e_band = 0, e_txb = 0;
+    // ---- epilogue of a group (cD: the group before the one being multiplied): this wave's NB register quads of the outputs -----
     bool e_have = false;
     const char *ex = xch;
-    f32x4 e_sc, e_sh, Zr[4], Yk[2][2];
-    float e_esc = 1.0f;
-    int e_co8 = 0;
+    f32x4 e_sc, e_sh, Zr[4];
+    f32x2 Yk[2][2][2];             // [output row][output column][channel pair]
+    unsigned e_esc_bits = 0x3f800000u;
+    int e_esc_s = -1, e_co8 = 0;
     unsigned mx = 0;   // largest stored output of this lane since the last flush, of stream mx_s
     int mx_s = -1;
-    // per-lane part of the output offset (floats) and validity limits
-    const int o_lane = POOL ? (ty * g.Wo + tx) * 8 + 4 * half : ((2 * ty) * g.W + 2 * tx) * 8 + 4 * half;
+    const int o_lane = POOL ? (ty * g.Wo + tx) * 8 + 4 * half : ((2 * ty) * g.W + 2 * tx) * 8 + 4 * half;  // per-lane part of the output offset
 #define W23_AMAX_FLUSH()                                                                                         \
     if (g.amax_out != nullptr && mx_s >= 0) {                                                                    \
         unsigned m_ = mx;                                                                                        \
         _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) m_ = max(m_, (unsigned)__shfl_xor((int)m_, o_, 64)); \
         if (lane == 0 && m_ > __hip_atomic_load(g.amax_out + mx_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.amax_out + mx_s, m_); \
     }
+// 1 / (u_scale v_scale(stream)) = u_inv * 2^(e - 12): both powers of two, so the exponents add (integer arithmetic on scalars)
 #define W23_E_BEGIN()                                                                                            \
     if (!(W23_ABL & 8)) {                                                                                        \
-        e_esc = u_inv / w23_vscale_s(g.amax_in[e_s]);                                                            \
-        if (e_s != mx_s) { W23_AMAX_FLUSH() mx = 0; mx_s = e_s; }                                                \
+        if (cD.s != e_esc_s) {                                                                                   \
+            e_esc_s = cD.s;                                                                                      \
+            e_esc_bits = u_inv_bits + 0x3f800000u - __float_as_uint(w23_vscale_s(g.amax_in[cD.s]));              \
+        }                                                                                                        \
+        if (cD.s != mx_s) { W23_AMAX_FLUSH() mx = 0; mx_s = cD.s; }                                              \
     }
 #define W23_E_SETUP(K_)                                                                                          \
     if (!(W23_ABL & 8)) {                                                                                        \
         const int u_ = wv * NB + (K_), n_ = u_ >> 2, rq_ = u_ & 3;                                               \
         ex = xch + ((n_ * 4 + rq_) * 64 + lane) * 16;                                                            \
         const int cl_ = 32 * n_ + 8 * rq_ + 4 * half;                                                            \
-        e_sc = *(const f32x4 *)(bnp + cl_) * e_esc;                                                              \
+        e_sc = *(const f32x4 *)(bnp + cl_) * __uint_as_float(e_esc_bits);                                        \
         e_sh = *(const f32x4 *)(bnp + 32 * NB + cl_);                                                            \
         e_co8 = cb * 4 * NB + 4 * n_ + rq_;                                                                      \
     }
@@ -306,81 +276,98 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     if (!(W23_ABL & 8)) {                                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Zr[i_] = *(const f32x4 *)(ex + ((i_ * 2 + (C_)) * NB * 4 * 64) * 16); \
     }
-#define W23_A4(A_, B_) W23_PK4(pk_add, A_, B_)
-#define W23_S4(A_, B_) W23_PK4(pk_sub, A_, B_)
-#define W23_F4(A_, B_, C_) __builtin_shufflevector(pk_fma(P2(A_, 0), P2(B_, 0), P2(C_, 0)), pk_fma(P2(A_, 1), P2(B_, 1), P2(C_, 1)), 0, 1, 2, 3)
+// Y[0][c] = relu(bn(Z0 + Z1 + Z2)), Y[1][c] = relu(bn(Z1 - Z2 - Z3)): per channel pair six packed instructions in ONE asm
+// statement (no compiler s_nop between dependent statements), then eight v_max (asm: the compiler canonicalises in front of its own)
 #define W23_E_Y(C_)                                                                                              \
     if (!(W23_ABL & 8)) {                                                                                        \
-        const f32x4 y0_ = W23_A4(W23_A4(Zr[0], Zr[1]), Zr[2]), y1_ = W23_S4(W23_S4(Zr[1], Zr[2]), Zr[3]);        \
-        Yk[0][C_] = __builtin_elementwise_max(W23_F4(y0_, e_sc, e_sh), (f32x4)(0.0f));                           \
-        Yk[1][C_] = __builtin_elementwise_max(W23_F4(y1_, e_sc, e_sh), (f32x4)(0.0f));                           \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                       \
+            f32x2 t0_, t1_;                                                                                      \
+            asm volatile("v_pk_add_f32 %2, %4, %5\n\tv_pk_add_f32 %3, %5, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"      \
+                         "v_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"      \
+                         "v_pk_fma_f32 %0, %2, %8, %9\n\tv_pk_fma_f32 %1, %3, %8, %9"                            \
+                         : "=&v"(Yk[0][C_][h_]), "=&v"(Yk[1][C_][h_]), "=&v"(t0_), "=&v"(t1_)                    \
+                         : "v"(H2(Zr[0], h_)), "v"(H2(Zr[1], h_)), "v"(H2(Zr[2], h_)), "v"(H2(Zr[3], h_)), "v"(H2(e_sc, h_)), "v"(H2(e_sh, h_))); \
+        }                                                                                                        \
+        asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3\n\t" \
+                     "v_max_f32 %4, 0, %4\n\tv_max_f32 %5, 0, %5\n\tv_max_f32 %6, 0, %6\n\tv_max_f32 %7, 0, %7"  \
+                     : "+v"(Yk[0][C_][0][0]), "+v"(Yk[0][C_][0][1]), "+v"(Yk[0][C_][1][0]), "+v"(Yk[0][C_][1][1]), \
+                       "+v"(Yk[1][C_][0][0]), "+v"(Yk[1][C_][0][1]), "+v"(Yk[1][C_][1][0]), "+v"(Yk[1][C_][1][1])); \
     }
 #define W23_MAX4(V_) max(max(__float_as_uint((V_)[0]), __float_as_uint((V_)[1])), max(__float_as_uint((V_)[2]), __float_as_uint((V_)[3])))
+#define W23_Y4(R_, C_) __builtin_shufflevector(Yk[R_][C_][0], Yk[R_][C_][1], 0, 1, 2, 3)
 #define W23_E_ST(K_)                                                                                             \
     if (!(W23_ABL & 8)) {                                                                                        \
         if (POOL) {                                                                                              \
-            const int64_t ob_ = ((((int64_t)e_s * (g.Cout >> 3) + e_co8) * g.Ho + 2 * e_band) * g.Wo + 16 * e_txb) * 8; \
-            if (e_have && 2 * e_band + ty < g.Ho && 16 * e_txb + tx < g.Wo) {                                    \
-                const f32x2 q2_ = {0.25f, 0.25f};                                                                \
-                const f32x4 s_ = W23_A4(W23_A4(W23_A4(Yk[0][0], Yk[0][1]), Yk[1][0]), Yk[1][1]);                  \
-                const f32x4 v_ = __builtin_shufflevector(pk_mul(P2(s_, 0), q2_), pk_mul(P2(s_, 1), q2_), 0, 1, 2, 3); \
+            const int64_t ob_ = ((((int64_t)cD.s * (g.Cout >> 3) + e_co8) * g.Ho + 2 * cD.band) * g.Wo + 16 * cD.txb) * 8; \
+            f32x2 p_[2];                                                                                         \
+            const f32x2 q2_ = {0.25f, 0.25f};                                                                    \
+            _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                     \
+                asm volatile("v_pk_add_f32 %0, %1, %2\n\tv_pk_add_f32 %0, %0, %3\n\tv_pk_add_f32 %0, %0, %4\n\tv_pk_mul_f32 %0, %0, %5" \
+                             : "=&v"(p_[h_]) : "v"(Yk[0][0][h_]), "v"(Yk[0][1][h_]), "v"(Yk[1][0][h_]), "v"(Yk[1][1][h_]), "v"(q2_)); \
+            if (e_have && 2 * cD.band + ty < g.Ho && 16 * cD.txb + tx < g.Wo) {                                  \
+                const f32x4 v_ = __builtin_shufflevector(p_[0], p_[1], 0, 1, 2, 3);                              \
                 *(f32x4 *)(out + ob_ + o_lane) = v_;                                                             \
                 mx = max(mx, W23_MAX4(v_));                                                                      \
             }                                                                                                    \
         } else {                                                                                                 \
-            const int64_t ob_ = ((((int64_t)e_s * (g.Cout >> 3) + e_co8) * g.H + 4 * e_band) * g.W + 32 * e_txb) * 8; \
+            const int64_t ob_ = ((((int64_t)cD.s * (g.Cout >> 3) + e_co8) * g.H + 4 * cD.band) * g.W + 32 * cD.txb) * 8; \
             _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                     \
                 _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                 \
-                    if (e_have && 4 * e_band + 2 * ty + r_ < g.H && 32 * e_txb + 2 * tx + c_ < g.W) {            \
-                        *(f32x4 *)(out + ob_ + o_lane + (r_ * g.W + c_) * 8) = Yk[r_][c_];                       \
-                        mx = max(mx, W23_MAX4(Yk[r_][c_]));                                                      \
+                    if (e_have && 4 * cD.band + 2 * ty + r_ < g.H && 32 * cD.txb + 2 * tx + c_ < g.W) {          \
+                        const f32x4 v_ = W23_Y4(r_, c_);                                                         \
+                        *(f32x4 *)(out + ob_ + o_lane + (r_ * g.W + c_) * 8) = v_;                               \
+                        mx = max(mx, W23_MAX4(v_));                                                              \
                     }                                                                                            \
         }                                                                                                        \
     }
 // Z_i[c] = sum_j M(i, j) A[j][c]:  c = 0: M0 + M1 + M2,  c = 1: M1 - M2 - M3 -> exchange buffer.  The drain (>= 18 wait states
-// behind the last 16-pass MFMA) stands in front of the first VALU read of an accumulator; the barrier behind the writes makes
-// them visible to the next phase 0, where every wave finishes its share of this group's outputs.
+// behind the last 16-pass MFMA) stands in front of the first VALU read of an accumulator; four packed adds per channel pair in
+// one asm statement, the two 16-byte stores of a register quad right behind their sums (the LDS takes ~13 cycles per store and
+// wave: the sums of the next quad issue meanwhile); the barrier behind the writes makes them visible to the next phase 0,
+// where every wave finishes its share of this group's outputs.
+#define W23_ACC2(J_, N_, R_) ((f32x2){acc[J_][N_][R_], acc[J_][N_][(R_) + 1]})
 #define W23_ZSTORE()                                                                                             \
     if (!(W23_ABL & 16)) {                                                                                       \
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1])); \
         _Pragma("unroll") for (int n_ = 0; n_ < NB; ++n_)                                                        \
             _Pragma("unroll") for (int rq_ = 0; rq_ < 4; ++rq_) {                                                \
-                f32x4 m_[4];                                                                                     \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) m_[j_] = (f32x4){acc[j_][n_][4 * rq_], acc[j_][n_][4 * rq_ + 1], acc[j_][n_][4 * rq_ + 2], acc[j_][n_][4 * rq_ + 3]}; \
-                const f32x4 z0_ = W23_A4(W23_A4(m_[0], m_[1]), m_[2]), z1_ = W23_S4(W23_S4(m_[1], m_[2]), m_[3]); \
-                *(f32x4 *)(xch + ((((wv * 2 + 0) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = z0_;                 \
-                *(f32x4 *)(xch + ((((wv * 2 + 1) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = z1_;                 \
+                f32x2 z0_[2], z1_[2];                                                                            \
+                _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                 \
+                    asm volatile("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %1, %3, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+                                 "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %5 neg_lo:[0,1] neg_hi:[0,1]"  \
+                                 : "=&v"(z0_[h_]), "=&v"(z1_[h_])                                                \
+                                 : "v"(W23_ACC2(0, n_, 4 * rq_ + 2 * h_)), "v"(W23_ACC2(1, n_, 4 * rq_ + 2 * h_)), \
+                                   "v"(W23_ACC2(2, n_, 4 * rq_ + 2 * h_)), "v"(W23_ACC2(3, n_, 4 * rq_ + 2 * h_))); \
+                *(f32x4 *)(xch + ((((wv * 2 + 0) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = __builtin_shufflevector(z0_[0], z0_[1], 0, 1, 2, 3); \
+                *(f32x4 *)(xch + ((((wv * 2 + 1) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = __builtin_shufflevector(z1_[0], z1_[1], 0, 1, 2, 3); \
             }                                                                                                    \
     }                                                                                                            \
     W23_BARRIER()
 
-    // coordinates / scale of the group being multiplied and of the next one
-    int gs, gband, gtxb, ns = 0, nband = 0, ntxb = 0;
-    float sv, sv_n = 1.0f;
-#define W23_NEXT_COORDS() { W23_COORDS(gi + 1, ns, nband, ntxb) sv_n = w23_vscale_s(g.amax_in[ns]); }
+    // scale of the transformed input of the group being multiplied and of the next one (reloaded only when the stream changes)
+    float sv = w23_vscale_s(g.amax_in[cC.s]), sv_n = sv;
+#define W23_NEXT_SV() { sv_n = cB.s != cC.s ? w23_vscale_s(g.amax_in[cB.s]) : sv; }
 #define W23_ROTATE()                                                                                             \
     {                                                                                                            \
-        e_have = true; e_s = gs; e_band = gband; e_txb = gtxb;                                                   \
-        gs = ns; gband = nband; gtxb = ntxb; sv = sv_n;                                                          \
+        e_have = true; cD = cC; cC = cB; cB = cA; W23_ADV(cA)                                                    \
+        sv = sv_n;                                                                                               \
         ent = W23_ENT(ent + 4);                                                                                  \
     }
 
     // ---- prologue: the first group's four k-steps (entries 0..3) and the second group's first two (entries 4, 5); t and the
     // position-0 operands of the first k-step ------------------------------------------------------------------------------
     int ent = 0;  // ring entry of the current group's k-step 0
-    W23_DMA_SETUP(g_lo)
-    W23_DMA_KSTEP(0, 0) W23_DMA_KSTEP(1, 1) W23_DMA_KSTEP(2, 2) W23_DMA_KSTEP(3, 3)
+    W23_DMA_PREP(cC)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { W23_DMA_Q(k, k, 0) W23_DMA_Q(k, k, 1) W23_DMA_Q(k, k, 2) W23_DMA_Q(k, k, 3) }
     if (g_lo + 1 < g_hi) {
-        W23_DMA_SETUP(g_lo + 1)
-        W23_DMA_KSTEP(0, 4) W23_DMA_KSTEP(1, 5)
+        W23_DMA_PREP(cB)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { W23_DMA_Q(k, 4 + k, 0) W23_DMA_Q(k, 4 + k, 1) W23_DMA_Q(k, 4 + k, 2) W23_DMA_Q(k, 4 + k, 3) }
     }
-    W23_COORDS(g_lo, gs, gband, gtxb)
-    sv = w23_vscale_s(g.amax_in[gs]);
     W23_X()
     W23_SETP(0)
-    W23_LD(0, 0) W23_LD(0, 1) W23_TT(0, 0) W23_TT(0, 1) W23_LD(0, 2) W23_LD(0, 3) W23_TT(0, 2) W23_TT(0, 3)
-    W23_LD(1, 0) W23_LD(1, 1) W23_TT(1, 0) W23_TT(1, 1) W23_LD(1, 2) W23_LD(1, 3) W23_TT(1, 2) W23_TT(1, 3)
-    W23_VV(0, 0, 0) W23_SH(0, 0, 0, sv) W23_VV(1, 0, 1) W23_SH(1, 0, 1, sv) W23_SL(0, 0, 0, sv) W23_SL(1, 0, 1, sv)
+#include "conv_wino23r_pro.inc"
     W23_FENCE()
 
 #include "conv_wino23r_body.inc"
@@ -392,6 +379,10 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
         W23_E_SETUP(k) W23_E_LD(0) W23_E_Y(0) W23_E_LD(1) W23_E_Y(1) W23_E_ST(k)
     }
     W23_AMAX_FLUSH()
+    if (clk_on && lane == 0) {
+        g.clk[0] = clk_c0; g.clk[1] = (long long)__builtin_readcyclecounter();
+        g.clk[2] = clk_r0; g.clk[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- weights: U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], float64, rounded once to float32), scaled by the layer's
@@ -518,7 +509,14 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
     if (const char *e = getenv("STITO_W23_WG")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) per_cb = v; }  // tuning aid
     g.wg_per_cb = per_cb;
     const unsigned *amax = amax_in;
-    if (amax_in == nullptr) {
+    // measurement aid (tools/conv_bench.py): STITO_W23_AMAX_ONCE=1 keeps the maxima a previous call left in the same workspace
+    // for the same input instead of scanning the input again (inside the trunk the producing layer reports them: no scan at all)
+    static const bool amax_once = [] { const char *e = getenv("STITO_W23_AMAX_ONCE"); return e && atoi(e) != 0; }();
+    static thread_local const void *amax_have_in = nullptr, *amax_have_ws = nullptr;
+    if (amax_in == nullptr && amax_once && amax_have_in == (const void *)in && amax_have_ws == (const void *)ws) {
+        amax = (const unsigned *)ws;
+    } else if (amax_in == nullptr) {
+        amax_have_in = in; amax_have_ws = ws;
         unsigned *amax_ws = (unsigned *)ws;
         amax = amax_ws;
         STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
@@ -535,8 +533,20 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
     auto kern = k_conv_wino23r<KS, NB, POOL>;
     const size_t lds = (size_t)W23_RING * W23_ENTRY + (size_t)4 * 2 * NB * 4 * 1024 + (size_t)2 * 32 * NB * sizeof(float);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const bool clk_probe = [] { const char *e = getenv("STITO_W23_CLK"); return e && atoi(e) != 0; }();
+    static long long *clk_dev = nullptr;
+    if (clk_probe && clk_dev == nullptr) STITO_HIP_CHECK(hipMalloc(&clk_dev, 4 * sizeof(long long)));
+    g.clk = clk_probe ? clk_dev : nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_cb * g.n_cb)), dim3(W23_THREADS), lds, st, in, (const char *)wpk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
+    if (clk_probe) {   // measurement aid: synchronises
+        long long v[4];
+        STITO_HIP_CHECK(hipStreamSynchronize(st));
+        STITO_HIP_CHECK(hipMemcpy(v, clk_dev, sizeof(v), hipMemcpyDeviceToHost));
+        const double us = (double)(v[3] - v[2]) / 100.0;
+        fprintf(stderr, "[stito clock] k_conv_wino23r %dx%d %d->%d: workgroup in the middle of the grid ran %.1f us, %lld shader cycles, %.0f MHz\n", c.H, c.W,
+                c.Cin, c.Cout, us, v[1] - v[0], us > 0 ? (double)(v[1] - v[0]) / us : 0.0);
+    }
     return STITO_OK;
 }
 

@@ -624,7 +624,8 @@ def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
         W, _, _ = pm._ensure()
         algos = [int(W.conv_wino_algo[i]) for i in range(12)]
         if pre == "split":
-            assert algos[1:4] == [_hip.CONV_WINOGRAD_F4] * 3 and algos[4:7] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 3 and algos[7:] == [_hip.CONV_WINOGRAD_F4_SPLIT2] * 5
+            assert algos[1:3] == [_hip.CONV_WINOGRAD_F2_REG] * 2 and algos[3] == _hip.CONV_WINOGRAD_F4   # the 64-input-channel layers: register-resident F(2x2,3x3)
+            assert algos[4:7] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 3 and algos[7:] == [_hip.CONV_WINOGRAD_F4_SPLIT2] * 5
         else:
             assert algos[1:6] == [_hip.CONV_WINOGRAD_F4] * 5
             assert algos[6:] == [_hip.CONV_WINOGRAD_F4_PRE if pre else _hip.CONV_WINOGRAD_F4] * 6

@@ -1,87 +1,175 @@
 #!/usr/bin/env python
 """Generates st-ito_amd/csrc/conv_wino23r_body.inc: the group loop of k_conv_wino23r (conv_wino23r.hip) as an explicit
-software pipeline -- one MFMA per slot, the other work dealt to the slots by hand, a scheduling fence after every slot.
+software pipeline of inline-asm blocks, one matrix product per block.
 
-Why generated: a workgroup is ONE wave per SIMD (512 registers each), so nothing but the wave's own instruction order hides
-LDS latency, VALU dependency latency (8 cycles for a lone wave) or the matrix pipe: the first version of the kernel (transform,
-then products, then epilogue, in program order) spent 19 000 cycles per pixel group against 3 072 of matrix pipe (profiles/
-round4_w23_ablation.txt).  Here a group is 4 phases (one k-step of 16 input channels each) of 24 slots (4 positions x 2
-channel halves x 3 products):
+Why generated, and why asm blocks.  A workgroup is ONE wave per SIMD (512 registers each), so nothing but the wave's own
+instruction order hides LDS latency or the matrix pipe, and the wave issues ONE instruction per ~8 cycles whatever its type
+(tools/ubench/w23_shadow.hip, profiles/round4_w23_shadow_ubench.txt: three plain VALU instructions hide under a 32-cycle
+v_mfma_f32_32x32x16_f16, every further one costs 8 cycles; a packed-f32 instruction in the shadow of a product costs 12 - 20
+cycles more; s_mov 8; ds_read_b128 16 from the third per product on; ds_write_b128 ~50 with four waves writing).  With ~900
+instructions per pixel group against 96 products (3 072 cycles of matrix pipe) the loop is bound by instruction issue, so what
+counts is the instruction count: hipcc puts an s_nop between any two inline-asm statements of which the second reads a
+register the first defines (it has to assume a partial-register write), ~140 per group when every instruction is its own
+statement -- here a block carries its product AND the 12 transform instructions of a (position, channel quad) unit, with the
+one real hazard of that kind (v_fma_mixlo/hi_f16 writes half a register: one instruction between it and a reader) kept by the
+order inside the block.
 
-  slots  0..11  the B operands of positions 1, 2, 3 of THIS k-step from t (one (position, channel quad) unit per two slots:
-                2 packed adds + 4 v_fma_mixlo/hi for the hi halves, then 4 for the lo halves) -- position j's registers are
-                rewritten only after its products of the previous phase (slots 6 j .. 6 j + 5) and before its own (slot 6 j);
-  slots 10..19  the next k-step's patch rows: 16 ds_read_b128 two columns ahead of the 16 packed fmas that turn them into t
-                (t of the current k-step is dead after slot 11);
-  slots 18..21  the B operands of position 0 of the next k-step;
-  phase 1 / 3, slot 10: s_waitcnt vmcnt(0) + barrier (X), then the LDS-DMA copies of the k-steps whose ring entries that frees
-                (phase 1: k-steps 2, 3 of the next group into this group's entries 0, 1; phase 3: k-steps 0, 1 of the group
-                after next into this group's entries 2, 3): every copy has half a group to land, six entries suffice;
-  phase 0, slots 0..17: the PREVIOUS group's outputs (its Z went to the exchange buffer behind its phase 3, with a barrier):
-                reads, Y = sum_i A^T Z_i, BN + ReLU (+ pool), stores -- in the phase where the accumulators of positions 1..3
-                are still dead, so that its temporaries cost no registers;
+A group is 4 phases (one k-step of 16 input channels each) of 24 blocks (4 positions x [n0 n1] x 3 products, the two channel
+halves alternating so that consecutive blocks never chain on one accumulator):
+
+  blocks 0, 2, .. 10   the B operands of positions 1, 2, 3 of THIS k-step from t: unit (j, quad) = 4 adds (V = t[b1] +- t[b2]),
+                       4 v_fma_mixlo/hi (hi halves), 4 more (lo halves).  Position j's registers are rewritten only after its
+                       products of the previous phase (blocks 6 j .. 6 j + 5) and before its own (block 6 j);
+  blocks 10 .. 17      the next k-step's patch rows: two ds_read_b128 per block (compiler-visible loads between the asm blocks),
+  blocks 12 .. 19      ... and two blocks later the two packed fmas that turn them into t (t of this k-step is dead after block 10);
+  blocks 20, 22        the B operands of position 0 of the next k-step;
+  phase 1 / 3, block 10: s_waitcnt vmcnt(0) + barrier (X), then, one per block, the eight LDS-DMA copies whose ring entries that
+                       frees (phase 1: k-steps 2, 3 of the next group into this group's entries 0, 1; phase 3: k-steps 0, 1 of the
+                       group after next into this group's entries 2, 3): every copy has half a group to land, six entries suffice;
+  phase 0, odd blocks 1 .. 17: the PREVIOUS group's outputs (its Z went to the exchange buffer behind its phase 3, with a barrier):
+                       reads, Y = sum_i A^T Z_i, BN + ReLU (+ pool), stores -- in the phase where the accumulators of positions
+                       1..3 are still dead, so that its temporaries cost no registers;
   after phase 3: the accumulators drain, Z_i of this group go to the exchange buffer, barrier.
 
     python tools/gen/gen_w23_body.py > st-ito_amd/csrc/conv_wino23r_body.inc"""
+import sys
+
 NB = 2
-UNITS = [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)]   # (position j, channel quad) units of slots 0..11
+NO_T = NO_M = False   # ablation variants (W23_ABL & 1: no transform instructions, & 2: no products)
+VCOMB = {0: (0, 2, "sub"), 1: (1, 2, "add"), 2: (2, 1, "sub"), 3: (1, 3, "sub")}   # V(i, j) = t[a] -+ t[c]
 
-def phase(ks):
+class Asm:
+    """One asm volatile statement: instruction strings with {name} operand references, operands registered by name."""
+    def __init__(self):
+        self.ins, self.outs, self.inps = [], [], []
+    def out(self, name, cons, expr): self.outs.append((name, cons, expr)); return "%[" + name + "]"
+    def inp(self, name, cons, expr): self.inps.append((name, cons, expr)); return "%[" + name + "]"
+    def add(self, s): self.ins.append(s)
+    def emit(self, indent="        "):
+        if not self.ins: return indent + "/* (ablated) */"
+        body = "\\n\\t".join(self.ins)
+        o = ", ".join(f'[{n}] "{c}"({e})' for n, c, e in self.outs)
+        i = ", ".join(f'[{n}] "{c}"({e})' for n, c, e in self.inps)
+        return f'{indent}asm volatile("{body}"\n{indent}             : {o}\n{indent}             : {i});'
+
+def mfma(a, j, n, p, ks):
+    """product p of position j, channel half n: lo' hi, hi' lo, hi' hi (the large term last); the first product of a group
+    starts the accumulator from the inline constant 0"""
+    if NO_M: return
+    w = f"Wt[{j}][{ks}][{n}][{1 if p == 0 else 0}]"
+    b = f"W23_BL({j})" if p == 1 else f"W23_BH({j})"
+    wa, ba = a.inp("w", "a", w), a.inp("b", "v", b)
+    if ks == 0 and p == 0:
+        acc = a.out("acc", "=&v", f"acc[{j}][{n}]")
+        a.add(f"v_mfma_f32_32x32x16_f16 {acc}, {wa}, {ba}, 0")
+    else:
+        acc = a.out("acc", "+v", f"acc[{j}][{n}]")
+        a.add(f"v_mfma_f32_32x32x16_f16 {acc}, {wa}, {ba}, {acc}")
+
+def unit(a, q, j, sv):
+    """B operand registers 2 q, 2 q + 1 of position j (hi and lo halves) from t[q]: 12 instructions"""
+    if NO_T: return
+    ta, tc, op = VCOMB[j]
+    s = a.inp("sv", "s", sv)
+    v = [a.out(f"v{e}", "=&v", f"vtmp[{e}]") for e in range(4)]
+    for e in range(4):
+        x = a.inp(f"ta{e}", "v", f"tt[{q}][{ta}][{e >> 1}][{e & 1}]")
+        y = a.inp(f"tc{e}", "v", f"tt[{q}][{tc}][{e >> 1}][{e & 1}]")
+        a.add(f"v_{op}_f32 {v[e]}, {x}, {y}")
+    h = [a.out(f"h{r}", "=&v", f"bhv[{j}][{2 * q + r}]") for r in range(2)]
+    l = [a.out(f"l{r}", "=&v", f"blv[{j}][{2 * q + r}]") for r in range(2)]
+    a.add(f"v_fma_mixlo_f16 {h[0]}, {v[0]}, {s}, 0")
+    a.add(f"v_fma_mixlo_f16 {h[1]}, {v[2]}, {s}, 0")
+    a.add(f"v_fma_mixhi_f16 {h[0]}, {v[1]}, {s}, 0")
+    a.add(f"v_fma_mixhi_f16 {h[1]}, {v[3]}, {s}, 0")
+    a.add(f"v_fma_mixlo_f16 {l[0]}, {v[0]}, {s}, -{h[0]} op_sel:[0,0,0] op_sel_hi:[0,0,1]")
+    a.add(f"v_fma_mixlo_f16 {l[1]}, {v[2]}, {s}, -{h[1]} op_sel:[0,0,0] op_sel_hi:[0,0,1]")
+    a.add(f"v_fma_mixhi_f16 {l[0]}, {v[1]}, {s}, -{h[0]} op_sel:[0,0,1] op_sel_hi:[0,0,1]")
+    a.add(f"v_fma_mixhi_f16 {l[1]}, {v[3]}, {s}, -{h[1]} op_sel:[0,0,1] op_sel_hi:[0,0,1]")
+
+def tcomb(a, q, b):
+    """t[q][b] = d[a1][b] + sg d[a2][b]: two packed fmas on the load buffer b & 1"""
+    if NO_T: return
+    sg = a.inp("sg", "v", "sg2")
+    for h in range(2):
+        t = a.out(f"t{h}", "=&v", f"tt[{q}][{b}][{h}]")   # early clobber: the second fma still reads its inputs
+        d2 = a.inp(f"db{h}", "v", f"P2(dB[{b & 1}], {h})")
+        d1 = a.inp(f"da{h}", "v", f"P2(dA[{b & 1}], {h})")
+        a.add(f"v_pk_fma_f32 {t}, {d2}, {sg}, {d1}")
+
+UNITS = [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)]   # (position j, channel quad) units of blocks 0, 2, .. 10
+ORDER = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (1, 3)]   # (quad, patch column) of the loads / row combinations
+EPI = {1: "W23_E_BEGIN() W23_E_SETUP(0)", 3: "W23_E_LD(0)", 5: "W23_E_Y(0) W23_E_LD(1)", 7: "W23_E_Y(1)", 9: "W23_E_ST(0) W23_E_SETUP(1)",
+       11: "W23_E_LD(0)", 13: "W23_E_Y(0) W23_E_LD(1)", 15: "W23_E_Y(1)", 17: "W23_E_ST(1)"}
+
+def phase(ks, out):
     last = ks == 3
-    sv = "sv"
-    out = []
     for s in range(24):
-        j, n, p = s // 6, (s % 6) // 3, s % 3
-        items = []
-        # ---- barrier + copies --------------------------------------------------------------------------------------
-        if s == 10 and ks == 1:
-            items.append("W23_X() if (more1) { W23_DMA_SETUP(gi + 1) W23_DMA_KSTEP(2, ent) W23_DMA_KSTEP(3, ent + 1) }")
-        if s == 10 and ks == 3:
-            items.append("W23_X() if (more2) { W23_DMA_SETUP(gi + 2) W23_DMA_KSTEP(0, ent + 2) W23_DMA_KSTEP(1, ent + 3) }")
-            items.append("if (more1) { W23_NEXT_COORDS() }")
-        # ---- B operands of positions 1..3 of this k-step -------------------------------------------------------------
-        if s < 12:
+        j, p, n = s // 6, (s % 6) // 2, s % 2      # channel halves alternate
+        pre, post = [], []
+        a = Asm()
+        mfma(a, j, n, p, ks)
+        guard = None
+        if s < 12 and s % 2 == 0:
             uj, uq = UNITS[s // 2]
-            t = (s // 2) & 1
-            if s % 2 == 0:
-                items.append(f"W23_VV({uq}, {uj}, {t}) W23_SH({uq}, {uj}, {t}, {sv})")
-            else:
-                items.append(f"W23_SL({uq}, {uj}, {t}, {sv})")
-        # ---- next k-step: loads two slots ahead of the row combinations ------------------------------------------------
-        nxt = []
-        order = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (1, 3)]
-        if s == 10:
-            nxt.append(f"W23_SETP(ent + {ks + 1})")
+            unit(a, uq, uj, "sv")
+        if s == 10 and ks in (1, 3):
+            pre.append("W23_X()")
+            pre.append("if (more1) { W23_DMA_PREP(cB) }" if ks == 1 else "if (more2) { W23_DMA_PREP(cA) }")
+        if 11 <= s <= 18 and ks in (1, 3):
+            k, q = divmod(s - 11, 4)
+            if ks == 1: post.append(f"if (more1) {{ W23_DMA_Q({2 + k}, ent + {k}, {q}) }}")
+            else: post.append(f"if (more2) {{ W23_DMA_Q({k}, ent + {2 + k}, {q}) }}")
+        nxt_pre = []
+        if s == 10: nxt_pre.append(f"W23_SETP(ent + {ks + 1})")
         if 10 <= s <= 17:
-            q, b = order[s - 10]
-            nxt.append(f"W23_LD({q}, {b})")
+            q, b = ORDER[s - 10]
+            nxt_post = None if NO_T else f"W23_LD({q}, {b})"
+        else:
+            nxt_post = None
         if 12 <= s <= 19:
-            q, b = order[s - 12]
-            nxt.insert(0, f"W23_TT({q}, {b})")   # frees the load buffer the LD of this slot refills
-        svn = "sv_n" if last else "sv"
-        if s == 18: nxt.append(f"W23_VV(0, 0, 0) W23_SH(0, 0, 0, {svn})")
-        if s == 19: nxt.append(f"W23_SL(0, 0, 0, {svn})")
-        if s == 20: nxt.append(f"W23_VV(1, 0, 1) W23_SH(1, 0, 1, {svn})")
-        if s == 21: nxt.append(f"W23_SL(1, 0, 1, {svn})")
-        if nxt:
-            items.append(("if (more1) { " + " ".join(nxt) + " }") if last else " ".join(nxt))
-        # ---- the previous group's outputs ---------------------------------------------------------------------------
-        # (phase 0: the accumulators of positions 1..3 are dead until their first product of the group -- slots 6, 12, 18 --
-        # so the epilogue's temporaries cost no registers there)
-        ep = {(0, 0): "W23_E_BEGIN() W23_E_SETUP(0)", (0, 1): "W23_E_LD(0)", (0, 3): "W23_E_Y(0)", (0, 4): "W23_E_LD(1)",
-              (0, 6): "W23_E_Y(1)", (0, 8): "W23_E_ST(0)", (0, 9): "W23_E_SETUP(1)",
-              (0, 10): "W23_E_LD(0)", (0, 12): "W23_E_Y(0)", (0, 13): "W23_E_LD(1)", (0, 15): "W23_E_Y(1)", (0, 17): "W23_E_ST(1)"}
-        if (ks, s) in ep:
-            items.append(ep[(ks, s)])   # unconditional (only the stores look at e_have): a temporary written under one branch and
-                                        # read under another would be live around the whole loop for the register allocator
-        out.append(f"        /* {ks}.{s:2d} */ W23_MF({j}, {n}, {p}, {ks}) " + " ".join(items) + " W23_FENCE()")
-    return "\n".join(out)
+            q, b = ORDER[s - 12]
+            tcomb(a, q, b)
+        if s in (20, 22):
+            unit(a, (s - 20) // 2, 0, "sv_n" if last else "sv")
+        if ks == 0 and s in EPI: post.append(EPI[s])
+        if last and s == 11: post.append("if (more1) { W23_NEXT_SV() }")
+        lines = list(pre)
+        # (the last phase works ahead for the NEXT group; behind the last group that work runs on stale LDS contents and is never
+        # used -- cheaper than a branch around it, which would also make hipcc copy the accumulators between the two arms)
+        if nxt_pre: lines.append(" ".join(nxt_pre))
+        if guard:   # the last phase works ahead for the NEXT group: without one, only the product
+            b_ = Asm(); mfma(b_, j, n, p, ks)
+            lines.append(f"if ({guard}) {{\n" + a.emit("            ") + "\n        } else {\n" + b_.emit("            ") + "\n        }")
+        else:
+            lines.append(a.emit().lstrip())
+        if nxt_post: lines.append(nxt_post)
+        lines += post
+        out.append(f"        /* {ks}.{s:2d} */ " + "\n        ".join(lines) + "\n        W23_FENCE()")
 
-print("// GENERATED by tools/gen/gen_w23_body.py -- do not edit (NB = 2, 4 k-steps per group)")
-print("    for (int gi = g_lo; gi < g_hi; ++gi) {")
-print("        const bool more1 = gi + 1 < g_hi, more2 = gi + 2 < g_hi;")
-for ks in range(4):
-    print(phase(ks))
-print("        W23_ZSTORE()")
-print("        W23_ROTATE()")
-print("    }")
+def body(proto):
+    out = []
+    if proto:
+        # t and the position-0 operands of the first group's first k-step (no products yet)
+        for q, b in ORDER:
+            if not NO_T: out.append(f"    W23_LD({q}, {b})")
+            a = Asm(); tcomb(a, q, b); out.append(a.emit("    "))
+        for q in range(2):
+            a = Asm(); unit(a, q, 0, "sv"); out.append(a.emit("    "))
+        return out
+    out.append("    for (int gi = g_lo; gi < g_hi; ++gi) {")
+    out.append("        const bool more1 = gi + 1 < g_hi, more2 = gi + 2 < g_hi;")
+    for ks in range(4):
+        phase(ks, out)
+    out.append("        W23_ZSTORE()")
+    out.append("        W23_ROTATE()")
+    out.append("    }")
+    return out
+
+proto = len(sys.argv) > 1 and sys.argv[1] == "prologue"
+print("// GENERATED by tools/gen/gen_w23_body.py -- do not edit (NB = 2, 4 k-steps per group; the W23_ABL & 3 variants are timing experiments)")
+for abl in range(4):
+    NO_T, NO_M = bool(abl & 1), bool(abl & 2)
+    print(("#if" if abl == 0 else "#elif") + f" (W23_ABL & 3) == {abl}")
+    print("\n".join(body(proto)))
+print("#endif")
