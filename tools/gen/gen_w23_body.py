@@ -35,6 +35,7 @@ halves alternating so that consecutive blocks never chain on one accumulator):
 import sys
 
 NB = 2
+DMA_STEP = 1   # blocks between two copies (measured at 512 streams, conv_block1.conv2: 1 -> 5.40 ms, 4 -> 5.73 ms: the copies need the time to land, not a lower issue rate)
 NO_T = NO_M = False   # ablation variants (W23_ABL & 1: no transform instructions, & 2: no products)
 VCOMB = {0: (0, 2, "sub"), 1: (1, 2, "add"), 2: (2, 1, "sub"), 3: (1, 3, "sub")}   # V(i, j) = t[a] -+ t[c]
 
@@ -116,10 +117,16 @@ def phase(ks, out):
         if s == 10 and ks in (1, 3):
             pre.append("W23_X()")
             pre.append("if (more1) { W23_DMA_PREP(cB) }" if ks == 1 else "if (more2) { W23_DMA_PREP(cA) }")
-        if 11 <= s <= 18 and ks in (1, 3):
-            k, q = divmod(s - 11, 4)
-            if ks == 1: post.append(f"if (more1) {{ W23_DMA_Q({2 + k}, ent + {k}, {q}) }}")
-            else: post.append(f"if (more2) {{ W23_DMA_Q({k}, ent + {2 + k}, {q}) }}")
+        # the eight copies behind a barrier, DMA_STEP blocks apart: 8 KB per wave issued back to back is more than a CU keeps in
+        # flight (~20 KB): the issuing waves -- all of them -- stood still for ~1 400 cycles per burst
+        for i in range(8):
+            at = 11 + DMA_STEP * i                      # block index counted from block 0 of the phase with the barrier
+            if (ks, s) == ((1 + at // 24) % 4, at % 24):   # behind X of phase 1: k-steps 2, 3 of the next group
+                post.append(f"if (more1) {{ W23_DMA_Q({2 + i // 4}, ent + {i // 4}, {i % 4}) }}")
+            if (ks, s) == ((3 + at // 24) % 4, at % 24):   # behind X of phase 3: k-steps 0, 1 of the group after next
+                if at < 24: post.append(f"if (more2) {{ W23_DMA_Q({i // 4}, ent + {2 + i // 4}, {i % 4}) }}")
+                else:       # ... continued in the next trip of the loop: that group is now "the next one", ent has moved on by 4
+                    post.append(f"if (e_have && more1) {{ W23_DMA_Q({i // 4}, ent + {4 + i // 4}, {i % 4}) }}")
         nxt_pre = []
         if s == 10: nxt_pre.append(f"W23_SETP(ent + {ks + 1})")
         if 10 <= s <= 17:
