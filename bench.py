@@ -13,14 +13,27 @@ not available offline).  For N > 1 every GPU evaluates its own 256 candidates of
 population (weak scaling, configs[3] shape) and the fitness scalars are all-gathered over RCCL.
 
 The JSON line also carries
-  roofline     : the f32-MFMA conv kernel family (k_conv_wino43 / k_conv_wino8 / k_conv3x3, the 11 MFMA conv launches of
-                 a trunk pass = ~75 % of the step).  achieved = FLOPs of the MFMA instructions those launches actually
-                 ISSUE (tile padding included; stito_conv3x3_issued_flops) / their summed duration, measured with HIP
-                 events the library records on its launch stream around every such launch of the TIMED steps
-                 (stito_conv_timing_enable/read); peak = 157.3 TFLOP/s (dense f32 MFMA); frac = achieved / peak <= 1.
-                 algorithmic_tflops counts the direct-convolution FLOPs 2*9*cin*cout*H*W of the same launches (the
-                 Winograd kernels need 2.25 / 4 of them), so it may exceed the peak.  traffic = HBM bytes per launch
-                 from the committed rocprofv3 PMC passes, used only if they were taken on THIS kernel source (hash check);
+  roofline     : one object per conv KERNEL FAMILY, never mixed: "f32" = the exact-f32 MFMA layers (peak 157.3 TFLOP/s),
+                 "f16-stream" = the split-precision streaming convolutions (f16 hi + lo operands, peak 2 500 TFLOP/s dense,
+                 bound by filling LDS: `bound` says so and `lds_fill` carries bytes copied into LDS / time against the L2 -> LDS
+                 rate measured with tools/ubench/split_mfma.hip, 24 TB/s, and the guide's L2 figure, 34.5 TB/s),
+                 "f16-reg" = the register-resident F(2x2,3x3) layers (same pipe; bound by the instruction issue of ONE wave
+                 per SIMD: tools/ubench/w23_shadow.hip).  `roofline` is the family with the largest share of the step, the others sit
+                 in `roofline_other`.  achieved = FLOPs of the MFMA instructions those launches actually ISSUE (tile padding and
+                 all three split products included; stito_conv3x3_issued_flops) / their summed duration, measured with HIP events
+                 the library records on its launch stream around every such launch of the TIMED steps
+                 (stito_conv_timing_enable / _read_each); frac = achieved / peak <= 1.
+                 time_at_peak_frac = (time all conv launches would take at the peak of the pipe each runs on) / measured conv time:
+                 the one scalar that says how far the conv stack is from its matrix pipes.
+                 algorithmic_tflops / end_to_end_algorithmic_frac count the DIRECT-convolution FLOPs 2*9*cin*cout*H*W
+                 against the f32 peak: they exceed 1 because Winograd issues 2.25 / 9 (F(4x4,3x3)) or 4 / 9 (F(2x2,3x3)) of those
+                 MACs and most layers run on the 16 x faster f16 pipe -- not because work is skipped (the parity tests show it is done).
+                 traffic = HBM bytes per launch from the committed rocprofv3 PMC passes, used only if they were taken on THIS
+                 kernel source (hash check);
+  roofline_dsp : render + log-mel against HBM: SURVEY 8(d)'s algorithmic bytes (8.16 MB per 10 s stereo candidate: shared input
+                 read, rendered audio written, log-mel written) / the time of those kernels (HIP events around the two stages
+                 of a separate, untimed pass) against 8 TB/s;
+  stages       : per-rank (evaluate, gather, tell) milliseconds per step, min / max over ranks (diagnosis of a first multi-GPU run);
   cpu_baseline : the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample of the
                  same workload (rank 0, N = 1 only): mode A = the reference's serial loop (parallel=False), and
                  parallel_pool16 = its mp.Pool(16) render re-created per evaluate call (style_transfer.py:499-502).
@@ -41,7 +54,10 @@ import torch  # noqa: E402
 SR = 48000
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_32x32x16_f16), 1024 FLOP/clk/SIMD
-PIPE_PEAK = {"f32": MFMA_F32_PEAK_TFLOPS, "f16": MFMA_F16_PEAK_TFLOPS}
+PIPE_PEAK = {"f32": MFMA_F32_PEAK_TFLOPS, "f16-stream": MFMA_F16_PEAK_TFLOPS, "f16-reg": MFMA_F16_PEAK_TFLOPS}
+FAMILY_BOUND = {"f32": "mfma", "f16-stream": "lds-fill", "f16-reg": "issue"}
+HBM_PEAK_TBPS = 8.0           # MI355X_MICROARCH.md (6.29 measured-achievable)
+DSP_BYTES_PER_CAND_10S = 8.16e6   # 4 C L (input) + 4 C L (audio) + 4 C T M (log-mel) at L = 480 000
 
 
 def synth_audio(seed, chs, n):
@@ -167,7 +183,7 @@ def conv_layer_times(model, n_streams, T, reps=3):
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         fl = r["flops"] * n_streams
         issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
-        pipe = "f16" if algo in (4, 5, 6, 7, 8) else "f32"
+        pipe = "f16-reg" if algo == 8 else ("f16-stream" if algo in (4, 5, 6, 7) else "f32")
         # split-precision kernel: every operand element of every product travels L2 -> LDS as 4 bytes (hi + lo); per workgroup
         # 36 positions x (32 tiles + 64 couts) x cin elements, i.e. 4 / (2 * 32 * 64 / 96) bytes per f32-equivalent MAC
         # (two-sweep kernel: 128 elements per 64 x 64 MACs)
@@ -262,13 +278,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started from a bare shell: launch one rank per GPU through torch.distributed.run (what the driver does itself
         # for its scaling runs) and hand its exit code back; rank 0 of the children prints the JSON line
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher picks a free rendezvous port itself (binding one here and closing it again would leave a
+        # window for another process to take it)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -286,14 +300,20 @@ def main():
             dist.barrier()
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         seen = [None] * world
+        stages_ms = [10.0 * (rank + 1), 1.0 + rank, 0.5]   # stands in for (evaluate, gather, tell) of the real run
+        stages_all = [stages_ms]
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_gather_object(seen, rank)
+            stages_all = [None] * world
+            dist.all_gather_object(stages_all, stages_ms)
         else:
             seen = [0]
+        stages = {name: {"min": min(s_[i] for s_ in stages_all), "max": max(s_[i] for s_ in stages_all)}
+                  for i, name in enumerate(("evaluate_ms", "gather_ms", "tell_ms"))}
         if rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": seen, "max_over_ranks": float(t.item()),
-                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+                              "steps": args.steps, "warmup": args.warmup, "stages": stages}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -336,13 +356,22 @@ def main():
     P_total = args.pop_per_gpu * world
     es = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P_total, "seed": 42})
 
+    stage_s = [0.0, 0.0, 0.0]  # evaluate (ask + launches + the sync that ends them), gather, tell -- host clocks of this rank
+
     def step():
+        t_a = time.perf_counter()
         W = es.ask()
         lo, hi = shard_bounds(P_total, rank, world)
         loss, _, _ = ev.evaluate(W[lo:hi])
         es.prefetch()  # the next generation's normal deviates, drawn while the GPU works (as run_es does)
-        f = gather_fitness(loss, P_total)
-        es.tell(W, f.tolist())  # .tolist() = the device->host sync the optimiser needs anyway
+        if world > 1:
+            torch.cuda.synchronize()   # N > 1 only: separates this rank's own work from its wait for the slowest rank
+        t_b = time.perf_counter()
+        f = gather_fitness(loss, P_total).tolist()  # .tolist() = the device->host sync the optimiser needs anyway
+        t_c = time.perf_counter()
+        es.tell(W, f)
+        t_d = time.perf_counter()
+        stage_s[0] += t_b - t_a; stage_s[1] += t_c - t_b; stage_s[2] += t_d - t_c
 
     def fence():
         torch.cuda.synchronize()
@@ -356,11 +385,13 @@ def main():
     timing = rank == 0 and not args.no_roofline
     if timing:  # the library records HIP events around every MFMA conv launch of the timed steps
         _hip.check(_hip.lib().stito_conv_timing_enable(1))
+    stage_s[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    stages_ms = [1e3 * v / args.steps for v in stage_s]
     conv_each, conv_launches = (ctypes.c_double * 65536)(), ctypes.c_int(0)
     if timing:
         _hip.check(_hip.lib().stito_conv_timing_enable(0))
@@ -398,9 +429,21 @@ def main():
                   "ms_per_step": round(dt512 / args.steps * 1e3, 3), "steps": args.steps, "warmup": 1}
 
     ranks_seen = [0]
+    stages_all = [stages_ms]
     if dist is not None:
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, (rank, torch.cuda.get_device_properties(dev).name, local_dev))
+        stages_all = [None] * world
+        dist.all_gather_object(stages_all, stages_ms)
+    stages = {name: {"min": round(min(s_[i] for s_ in stages_all), 3), "max": round(max(s_[i] for s_ in stages_all), 3)}
+              for i, name in enumerate(("evaluate_ms", "gather_ms", "tell_ms"))}
+    stages["note"] = ("host clocks per rank and step; evaluate = ask + every launch of the evaluate-population step" +
+                      (" + a device sync (N > 1 only, so that gather_ms is the wait for the slowest rank + the all-gather)" if world > 1 else
+                       " (asynchronous at N = 1: the device time shows up in gather_ms, whose .tolist() is the step's only sync)"))
+    try:
+        stages["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and backend == "nccl") else None
+    except Exception:  # noqa: BLE001 -- informational
+        stages["rccl_version"] = None
 
     out = {
         "metric": "candidate-evals/sec (pop x iters), 48 kHz 10 s stereo, 5-effect chain",
@@ -416,6 +459,7 @@ def main():
                    "parallelism": f"population sharded over {world} GPU(s), fitness all-gather",
                    "backend": backend if world > 1 else None, "ranks": ranks_seen},
     }
+    out["stages"] = stages
     if pop512 is not None:
         out["north_star_pop512"] = pop512
     if rank == 0:
@@ -430,7 +474,7 @@ def main():
             # the timed launches repeat the pass's launch order; the last pass of a step may be partial (fewer streams): its
             # issued work is scaled by its share of the streams
             per_pass = len(order)
-            fam = {p: dict(ms=0.0, flops=0.0, fill=0.0, n=0) for p in ("f32", "f16")}
+            fam = {p: dict(ms=0.0, flops=0.0, fill=0.0, n=0) for p in PIPE_PEAK}
             n_full, rem = divmod(2 * args.pop_per_gpu, streams_per_launch)
             pass_scale = [1.0] * n_full + ([rem / streams_per_launch] if rem else [])
             conv_ms_total = 0.0
@@ -448,37 +492,71 @@ def main():
                     return None
                 ach = f["flops"] / f["ms"] / 1e9
                 names = sorted({l["algo"] for l in layers if l.get("pipe") == pipe})
-                d = {"bound": "mfma", "pipe": pipe,
-                     "kernel": f"the {f['n'] // max(args.steps * passes_per_step, 1)} 3x3-conv launches of a trunk pass on the {pipe} matrix pipe (" + "; ".join(names) +
+                d = {"bound": FAMILY_BOUND[pipe], "pipe": pipe,
+                     "kernel": f"the {f['n'] // max(args.steps * passes_per_step, 1)} 3x3-conv launches of a trunk pass in this family (" + "; ".join(names) +
                                "). achieved = FLOPs of the MFMA instructions actually issued (tile padding included) / launch time",
                      "achieved": round(ach, 2), "peak": PIPE_PEAK[pipe], "unit": "TFLOP/s", "frac": round(ach / PIPE_PEAK[pipe], 4),
                      "flops_per_launch": f["flops"] / f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 4), "launches_timed": f["n"],
                      "share_of_step": round(f["ms"] / (dt * 1e3), 4)}
-                if pipe == "f16":
-                    d["note"] = ("this family is bound by filling LDS from L2, not by the matrix pipe: 4 bytes per operand element (f16 hi + lo) "
-                                 "for 21.3 MACs; lds_fill is those bytes / launch time (the transform pass included in the time), against "
-                                 "24 TB/s measured for L2-resident streams (tools/ubench/split_mfma.hip)")
-                    d["lds_fill"] = {"achieved": round(f["fill"] / f["ms"] / 1e9, 2), "peak": 24.0, "unit": "TB/s",
-                                     "frac": round(f["fill"] / f["ms"] / 1e9 / 24.0, 4)}
+                if pipe == "f16-stream":
+                    d["bound_note"] = ("bound by filling LDS from L2, not by the matrix pipe: 4 bytes per operand element (f16 hi + lo) for 21.3 "
+                                       "(one sweep) / 32 (two sweeps) MACs; lds_fill = those bytes / launch time (the transform pass is inside the "
+                                       "time).  Ceilings: 24 TB/s = the L2 -> LDS rate this build measured for L2-resident streams "
+                                       "(tools/ubench/split_mfma.hip, profiles/round3_split_mfma_ubench.txt); 34.5 TB/s = the guide's L2 bandwidth")
+                    fill_tbps = f["fill"] / f["ms"] / 1e9
+                    d["lds_fill"] = {"achieved": round(fill_tbps, 2), "peak": 24.0, "peak_source": "self-measured (split_mfma ubench)", "unit": "TB/s",
+                                     "frac": round(fill_tbps / 24.0, 4), "frac_of_guide_l2_34.5": round(fill_tbps / 34.5, 4)}
+                if pipe == "f16-reg":
+                    d["bound_note"] = ("one wave per SIMD (512 registers: the transformed weights live in them) issues one instruction per ~8 cycles "
+                                       "whatever its type (tools/ubench/w23_shadow.hip): ~900 instructions per 96 products of 32 cycles each")
                 return d
 
-            f32_fam, f16_fam = family("f32"), family("f16")
-            dominant, other = (f32_fam, f16_fam) if (f16_fam is None or (f32_fam and fam["f32"]["ms"] >= fam["f16"]["ms"])) else (f16_fam, f32_fam)
-            out["roofline"] = dict(dominant)
+            fams = {p_: family(p_) for p_ in PIPE_PEAK}
+            ranked = sorted((p_ for p_ in fams if fams[p_] is not None), key=lambda p_: -fam[p_]["ms"])
+            at_peak_ms = sum(fam[p_]["flops"] / (PIPE_PEAK[p_] * 1e9) for p_ in ranked)
+            out["roofline"] = dict(fams[ranked[0]])
             out["roofline"].update({
+                "time_at_peak_frac": round(at_peak_ms / conv_ms_total, 4),
+                "time_at_peak_note": "time all MFMA conv launches would take at the dense peak of the pipe each runs on / their measured time",
                 "algorithmic_tflops": round(fl_step * args.steps / conv_ms_total / 1e9, 2),
-                "algorithmic_note": "direct-convolution FLOPs (2*9*cin*cout*H*W) of ALL MFMA conv launches / their time; the Winograd "
-                                    "kernels need 2.25 / 9 of them, so this may exceed any peak",
+                "algorithmic_note": "direct-convolution FLOPs (2*9*cin*cout*H*W) of ALL MFMA conv launches / their time; above any peak "
+                                    "because Winograd issues 2.25 / 9 or 4 / 9 of those MACs and most layers run on the 16 x faster f16 pipe",
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE), all conv launches", "traffic_source": traffic_note,
                 "n_streams": streams_per_launch,
                 "conv_share_of_step": round(conv_ms_total / (dt * 1e3), 4),
                 "conv_ms_per_step": round(conv_ms_total / args.steps, 3),
                 # whole path (DSP + front end + trunk + host) in direct-convolution FLOPs against the f32 peak
                 "end_to_end_algorithmic_frac": round(fl_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "end_to_end_note": "> 1 is Winograd + the pipe change (see algorithmic_note), not skipped work",
                 "layers": layers,
             })
-            if other is not None:
-                out["roofline_other_pipe"] = other
+            if len(ranked) > 1:
+                out["roofline_other"] = [fams[p_] for p_ in ranked[1:]]
+            # ---- render + log-mel against HBM (a separate, untimed pass with events around the two stages) ----
+            from st_ito.engine import render_population
+            Wd = torch.rand((args.pop_per_gpu, D), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(2025))
+            xin = ev._input(False, np.random)[0]
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            audio = peaks = None
+            for it in range(2):   # the second pass is the measured one
+                evs[0].record()
+                audio, peaks = render_population(plugins, xin, Wd, SR, chain=ev.chain)
+                evs[1].record()
+                step_c = max(1, model.max_streams_per_pass // audio.shape[1])
+                for b0 in range(0, audio.shape[0], step_c):
+                    model.logmel(audio[b0:b0 + step_c], peaks[b0:b0 + step_c].contiguous(), 2)
+                evs[2].record()
+                torch.cuda.synchronize()
+            r_ms, l_ms = evs[0].elapsed_time(evs[1]), evs[1].elapsed_time(evs[2])
+            dsp_bytes = DSP_BYTES_PER_CAND_10S * (n / 480000.0) * args.pop_per_gpu
+            out["roofline_dsp"] = {"bound": "hbm", "kernel": "effect-chain render (k_eq, compressor, k_reverb, k_eq + gain + peak) + k_logmel_wave",
+                                   "achieved": round(dsp_bytes / ((r_ms + l_ms) * 1e-3) / 1e12, 3), "peak": HBM_PEAK_TBPS, "unit": "TB/s",
+                                   "frac": round(dsp_bytes / ((r_ms + l_ms) * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4),
+                                   "algorithmic_bytes": dsp_bytes, "render_ms": round(r_ms, 3), "logmel_ms": round(l_ms, 3),
+                                   "share_of_step": round((r_ms + l_ms) / (dt / args.steps * 1e3), 4),
+                                   "note": "algorithmic bytes of SURVEY 8(d) (input read once, audio written once, log-mel written) / time; the "
+                                           "time-serial effects (float64 biquad cascade, envelope follower, comb / all-pass lines) are latency- "
+                                           "and issue-bound as SURVEY 8(d) expected: DESIGN.md 4.2 gives the per-kernel account"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, kinds)
         print(json.dumps(out), flush=True)

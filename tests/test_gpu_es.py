@@ -508,3 +508,8 @@ def test_bench_gpus2_self_launches_its_ranks(dev):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert [r[0] for r in d["config"]["ranks"]] == [0, 1] and d["config"]["backend"] == "gloo"
     assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-2 * d["value"]
+    # the per-rank stage breakdown of a multi-GPU run (what would diagnose rank skew / host jitter on a first 8-GPU run)
+    st = d["stages"]
+    for k in ("evaluate_ms", "gather_ms", "tell_ms"):
+        assert 0.0 <= st[k]["min"] <= st[k]["max"]
+    assert st["evaluate_ms"]["max"] + st["gather_ms"]["min"] <= 1.05 * d["ms_per_step"] + 5.0 and "rccl_version" in st

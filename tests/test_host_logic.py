@@ -481,6 +481,9 @@ def test_bench_measurement_bookkeeping(tmp_path, monkeypatch):
         assert os.path.basename(bench.PMC_TRAFFIC_JSON) in note
     else:  # kernels edited since the last PMC pass (tools/profile_round.sh): the bench line must say so instead of quoting it
         assert t is None and "was taken on kernel sources" in note
+        import warnings
+        warnings.warn(f"{os.path.basename(bench.PMC_TRAFFIC_JSON)} is stale (kernel sources changed): roofline.traffic will be null until "
+                      "tools/profile_round.sh is run again on the GPU box")
     assert bench.pmc_traffic_per_launch(committed["n_streams"] + 1)[0] is None
     stale = dict(committed, kernel_source_hash="0" * 16)
     p = tmp_path / "pmc.json"
@@ -503,7 +506,9 @@ def test_bench_self_launches_ranks_dryrun():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d == {"dryrun": True, "n_gpus": 2, "ranks_seen": [0, 1], "max_over_ranks": 2.0, "steps": 3, "warmup": 1}
+    # ... with the per-rank stage breakdown gathered the way the real run gathers it (min / max over ranks of evaluate / gather / tell)
+    assert d == {"dryrun": True, "n_gpus": 2, "ranks_seen": [0, 1], "max_over_ranks": 2.0, "steps": 3, "warmup": 1,
+                 "stages": {"evaluate_ms": {"min": 10.0, "max": 20.0}, "gather_ms": {"min": 1.0, "max": 2.0}, "tell_ms": {"min": 0.5, "max": 0.5}}}
     # a rank count that disagrees with the launcher's WORLD_SIZE is refused, not silently benchmarked
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
