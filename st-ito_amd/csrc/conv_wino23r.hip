@@ -94,6 +94,15 @@ __device__ __forceinline__ float w23_vscale_s(unsigned amax_bits) {
 #define W23_PK4(OP, A_, B_) __builtin_shufflevector(OP(P2(A_, 0), P2(B_, 0)), OP(P2(A_, 1), P2(B_, 1)), 0, 1, 2, 3)
 #define W23_FENCE() __builtin_amdgcn_sched_barrier(0);
 #define W23_ENT(E_) ((E_) >= W23_RING ? (E_) - W23_RING : (E_))
+#ifndef W23_TRACE
+#define W23_TRACE 0  // measurement build (tools/ab_build.sh trace -DW23_TRACE=1 + STITO_W23_CLK=1): s_memtime stamps of one wave at the phase
+                     // starts, around the two waits and around the Z exchange of four consecutive groups; 0 in every build that ships
+#endif
+#if W23_TRACE
+#define W23_STAMP(N_) if (clk_on && lane == 0 && gi - g_lo >= 8 && gi - g_lo < 12) g.clk[4 + (gi - g_lo - 8) * 16 + (N_)] = (long long)__builtin_readcyclecounter();
+#else
+#define W23_STAMP(N_)
+#endif
 #define W23_X() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); W23_BARRIER()
 #define W23_BH(J) __builtin_bit_cast(rh8, bhv[J])
 #define W23_BL(J) __builtin_bit_cast(rh8, blv[J])
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
 // where every wave finishes its share of this group's outputs.
 #define W23_ACC2(J_, N_, R_) ((f32x2){acc[J_][N_][R_], acc[J_][N_][(R_) + 1]})
 #define W23_ZSTORE()                                                                                             \
+    W23_STAMP(8)                                                                                                 \
     if (!(W23_ABL & 16)) {                                                                                       \
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1])); \
         _Pragma("unroll") for (int n_ = 0; n_ < NB; ++n_)                                                        \
@@ -342,7 +352,9 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
                 *(f32x4 *)(xch + ((((wv * 2 + 1) * NB + n_) * 4 + rq_) * 64 + lane) * 16) = __builtin_shufflevector(z1_[0], z1_[1], 0, 1, 2, 3); \
             }                                                                                                    \
     }                                                                                                            \
-    W23_BARRIER()
+    W23_STAMP(9)                                                                                                 \
+    W23_BARRIER()                                                                                                \
+    W23_STAMP(10)
 
     // scale of the transformed input of the group being multiplied and of the next one (reloaded only when the stream changes)
     float sv = w23_vscale_s(g.amax_in[cC.s]), sv_n = sv;
@@ -535,17 +547,25 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const bool clk_probe = [] { const char *e = getenv("STITO_W23_CLK"); return e && atoi(e) != 0; }();
     static long long *clk_dev = nullptr;
-    if (clk_probe && clk_dev == nullptr) STITO_HIP_CHECK(hipMalloc(&clk_dev, 4 * sizeof(long long)));
+    if (clk_probe && clk_dev == nullptr) { STITO_HIP_CHECK(hipMalloc(&clk_dev, 68 * sizeof(long long))); STITO_HIP_CHECK(hipMemset(clk_dev, 0, 68 * sizeof(long long))); }
     g.clk = clk_probe ? clk_dev : nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_cb * g.n_cb)), dim3(W23_THREADS), lds, st, in, (const char *)wpk, scale, shift, out, g);
     STITO_LAUNCH_CHECK();
     if (clk_probe) {   // measurement aid: synchronises
-        long long v[4];
+        long long v[68];
         STITO_HIP_CHECK(hipStreamSynchronize(st));
         STITO_HIP_CHECK(hipMemcpy(v, clk_dev, sizeof(v), hipMemcpyDeviceToHost));
         const double us = (double)(v[3] - v[2]) / 100.0;
         fprintf(stderr, "[stito clock] k_conv_wino23r %dx%d %d->%d: workgroup in the middle of the grid ran %.1f us, %lld shader cycles, %.0f MHz\n", c.H, c.W,
                 c.Cin, c.Cout, us, v[1] - v[0], us > 0 ? (double)(v[1] - v[0]) / us : 0.0);
+#if W23_TRACE
+        // stamps: 0 phase 0, 1 phase 1, 2 | 3 before / after its wait + barrier, 4 phase 2, 5 phase 3, 6 | 7 its wait, 8 Z exchange, 9 its barrier, 10 done
+        for (int gq = 0; gq < 4; ++gq) {
+            const long long *q = v + 4 + gq * 16;
+            fprintf(stderr, "[stito trace] group %d: ph0 %lld  ph1 %lld (wait %lld)  ph2 %lld  ph3 %lld (wait %lld)  Z %lld  barrier %lld  | group %lld cycles\n", gq,
+                    q[1] - q[0], q[4] - q[1], q[3] - q[2], q[5] - q[4], q[8] - q[5], q[7] - q[6], q[9] - q[8], q[10] - q[9], q[10] - q[0]);
+        }
+#endif
     }
     return STITO_OK;
 }

@@ -114,8 +114,9 @@ def phase(ks, out):
         if s < 12 and s % 2 == 0:
             uj, uq = UNITS[s // 2]
             unit(a, uq, uj, "sv")
+        if s == 0: pre.append(f"W23_STAMP({[0, 1, 4, 5][ks]})")
         if s == 10 and ks in (1, 3):
-            pre.append("W23_X()")
+            pre.append(f"W23_STAMP({2 if ks == 1 else 6}) W23_X() W23_STAMP({3 if ks == 1 else 7})")
             pre.append("if (more1) { W23_DMA_PREP(cB) }" if ks == 1 else "if (more2) { W23_DMA_PREP(cA) }")
         # the eight copies behind a barrier, DMA_STEP blocks apart: 8 KB per wave issued back to back is more than a CU keeps in
         # flight (~20 KB): the issuing waves -- all of them -- stood still for ~1 400 cycles per burst

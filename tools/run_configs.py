@@ -3,7 +3,7 @@
 timed like bench.py (ask -> evaluate -> tell, inputs resident in HBM, synthetic audio, seeded random
 AFx-Rep weights).  bench.py itself only runs configs[1]; this tool is the evidence that the other
 shapes run and what they cost.
-    python tools/run_configs.py [--steps 3] [--only 1,2,3,4,5]"""
+    python tools/run_configs.py [--steps 3] [--only 1,2,3,4,5,6,7]   (6, 7: the reference's own operating points, whole run_es calls)"""
 import argparse
 import functools
 import os
@@ -62,10 +62,31 @@ def run(label, spec, chs, seconds, pop, pairs, steps, model):
           f"({pairs * pop * seconds / dt:8.0f} audio-seconds/s)", flush=True)
 
 
+def run_es_point(label, plugins, pop, iters, seconds, random_crop, find_w0, model):
+    """One whole run_es call (the reference's user path: style_transfer.py:399-692) at one of the reference's own operating
+    points, timed from the call to the result: candidate evaluations (the find_w0 batch included) / wall time."""
+    from st_ito.style_transfer import load_plugins, run_es
+    plugins = load_plugins(plugins)
+    D = sum(p["num_params"] for p in plugins.values())
+    n = int(seconds * SR)
+    x = synth_audio(300, 2, n)[None]
+    tg = torch.from_numpy(process_audio(synth_audio(301, 2, n).numpy(), np.random.default_rng(3).random(D), SR, plugins))[None]
+    kw = dict(max_iters=iters, popsize=pop, sigma0=0.33, random_crop=random_crop, find_w0=find_w0, seed=11, early_stop=False)
+    run_es(x.clone(), tg.clone(), SR, plugins, model, get_param_embeds, **dict(kw, max_iters=2))   # warm (packing, workspaces)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = run_es(x.clone(), tg.clone(), SR, plugins, model, get_param_embeds, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    evals = pop * (len(r["fval_history"]) - 1) + (pop if find_w0 else 0)
+    print(f"{label:58s} D={D:3d}  {pop:5d} cand/step  {dt * 1e3 / max(len(r['fval_history']) - 1, 1):9.1f} ms/iter  {evals / dt:9.1f} cand/s  "
+          f"(run_es: {evals} evaluations of 262144 samples in {dt:.2f} s, fopt {r['fopt']:.4f})", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--only", default="1,2,3,4,5")
+    ap.add_argument("--only", default="1,2,3,4,5,6,7")
     a = ap.parse_args()
     only = {int(v) for v in a.only.split(",")}
     model = make_synthetic_param_model(seed=0, input_norm="minmax")
@@ -81,8 +102,18 @@ def main():
         5: ("configs[4] per-GPU share: pop 128, stereo 30 s, conv reverb 96000 taps", conv, 2, 30.0, 128, 1),
     }
     for k in sorted(only):
-        label, spec, chs, sec, pop, pairs = cfgs[k]
-        run(label, spec, chs, sec, pop, pairs, a.steps, model)
+        if k in cfgs:
+            label, spec, chs, sec, pop, pairs = cfgs[k]
+            run(label, spec, chs, sec, pop, pairs, a.steps, model)
+    # the reference's own operating points (not BASELINE configs): scripts/eval/eval_pst.py:974-991 (pop 128, 262144-sample random
+    # crops, general-pb chain, 32 iterations per example) and the CLI default scripts/run_optim.py:304-306 (pop 32, basic chain,
+    # find_w0, input padded / cropped to 262144 samples)
+    if 6 in only:
+        sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+        from eval_pst import get_plugins
+        run_es_point("PST harness: pop 128, 10 s stereo -> random crop 262144, general-pb", get_plugins("general-pb"), 128, 16, 10.0, True, False, model)
+    if 7 in only:
+        run_es_point("CLI default: pop 32, 5 s stereo padded to 262144, basic chain, find_w0", E.make_plugins("basic"), 32, 24, 5.0, False, True, model)
 
 
 if __name__ == "__main__":
