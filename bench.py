@@ -91,7 +91,7 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round3_conv_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round4_conv_pmc_traffic.json")
 
 
 def kernel_source_hash():

@@ -45,6 +45,8 @@ def mode_of(kname):
 
 
 def kind_of(kname):
+    if "k_conv_wino23r" in kname:
+        return "F(2x2,3x3), f16 hi + lo operands, weights resident in registers"
     if "k_conv_wino43s2" in kname:
         return "F(4x4,3x3), f16 hi + lo operands, two sweeps (64 x 64 tiles)"
     if "k_conv_wino43s" in kname:
@@ -76,7 +78,7 @@ for b in range(6):
 layers, cur = [], []
 for i, (name, _, _) in enumerate(f):
     cur.append(i)
-    if mode_of(name) in (0, 1) or "k_conv_wino43s" in name or "k_conv_wino43h" in name or "wino43" not in name:
+    if mode_of(name) in (0, 1) or "k_conv_wino43s" in name or "k_conv_wino43h" in name or "wino43" not in name or "k_conv_wino23r" in name:
         layers.append(cur)
         cur = []
 assert not cur and len(layers) == len(shapes), (len(layers), len(shapes), [x[0][:40] for x in f])

@@ -23,12 +23,27 @@
 //     goes through LDS (each wave writes its Z, 16 KB, and finishes a quarter of the group's outputs: BN + ReLU (+ pool) + stores).
 //
 // Pixel group = 2 tile rows x 16 tile columns (output 4 x 32 pixels before pooling), halo patch 6 x 34 pixels, staged by
-// LDS-DMA one k-step (16 channels = 4 channel quads, 13 KB) at a time into a ring of W23_RING entries.  Patch layout per
+// LDS-DMA one k-step (16 channels = 4 channel quads, 13 KB) at a time into a ring of W23_RING = 6 entries.  Patch layout per
 // entry: [quad][row parity, column parity][3 x 17 pixels] x 16 bytes -- the four parity planes make the 16 tiles of a
 // ds_read_b128 lane group (a tile row; lanes are mapped to tiles group by group) read 16 consecutive 16-byte slots: no bank
 // conflicts; wave w copies plane w (51 lanes per instruction, pixels outside the map masked off through EXEC and zeroed by hand).
-// Two barriers per group: B1 at its top (its patch has landed; the previous group's Z are written), B2 after its first k-step
-// (that entry is free for the next group's last k-step; the exchange buffer may be rewritten at the end of the group).
+//
+// The group loop is GENERATED (tools/gen/gen_w23_body.py -> conv_wino23r_body.inc / conv_wino23r_pro.inc): one wave per SIMD
+// issues about one instruction per 8 cycles (tools/ubench/w23_shadow.hip, profiles/round4_w23_shadow_ubench.txt), so what
+// stands between two MFMAs is placed by hand, one asm block per MFMA "slot".  A group is four phases (one per k-step) of 24
+// MFMAs; software pipeline over groups g:
+//   phase 0      products of k-step 0 | the epilogue of group g - 1 (Z sums of the four waves from LDS -> Y = A^T . A -> BN + ReLU
+//                (+ pool) -> stores) in the odd slots: the accumulators of three positions are dead there
+//   phase 1      products of k-step 1 | vmcnt(0) + barrier, then the copies of k-steps 2, 3 of group g + 1
+//   phase 2      products of k-step 2
+//   phase 3      products of k-step 3 | vmcnt(0) + barrier, then the copies of k-steps 0, 1 of group g + 2; the transform of
+//                position 0 of the NEXT group's k-step 0 (look-ahead, unconditional: a branch here makes hipcc copy accumulators)
+//   then         drain, Z_i = sums over j of this wave's row -> LDS (16 ds_write_b128), barrier, ring rotates by 4 entries
+// so an entry is rewritten two phases after its last read, every copy has two phases (~6000 cycles, measured latency under
+// load ~5000) to land, and the only waits are the two vmcnt(0) + barrier pairs (the no-partial-wait rule of conv_wino43.hip:
+// LDS-DMA copies complete out of order) and the barrier behind the Z writes.  The transform of position p + 1 runs in the
+// slots of position p's products (unit = 4 adds + 8 v_fma_mix per B operand pair; tcomb = 2 v_pk_fma_f32 per patch column).
+// Measured timeline and ablations: profiles/round4_w23_ablation.txt.
 #include "conv_layout.h"
 
 #include <cstdlib>
