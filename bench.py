@@ -95,12 +95,16 @@ PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round4_conv_pmc_traffic.json"
 
 
 def kernel_source_hash():
-    """sha256 over the conv kernels' sources: a PMC measurement is only quoted for the source it was taken on."""
+    """sha256 over the conv kernels' CODE (// comments and blank lines dropped, so that editing a comment does not orphan a
+    measurement): a PMC measurement is only quoted for the source it was taken on."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "st-ito_amd", "csrc")
     for name in ("cnn14.hip", "conv_wino43.hip", "conv_wino23r.hip", "conv_wino23r_body.inc", "conv_wino23r_pro.inc", "conv_direct_split.hip", "conv_layout.h", "common.h"):
-        h.update(open(os.path.join(d, name), "rb").read())
+        for line in open(os.path.join(d, name), "r", encoding="utf-8", errors="replace"):
+            code = line.split("//", 1)[0].rstrip()
+            if code:
+                h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 

@@ -198,10 +198,10 @@ class Cnn14(nn.Module):
                         algo = _hip.CONV_WINOGRAD_F4_SPLIT2
                     if not split and not pre and self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cout <= self.conv_splitk_max_cout:
                         algo = _hip.CONV_WINOGRAD_F4_SPLITK
-                    if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cin % 16 == 0 and cin <= self.conv_dsplit_max_cin:
-                        algo = _hip.CONV_DIRECT_SPLIT
                     if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and self.conv_f2reg and cin == 64 and cout % 64 == 0:
                         algo = _hip.CONV_WINOGRAD_F2_REG
+                    if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cin % 16 == 0 and cin <= self.conv_dsplit_max_cin:
+                        algo = _hip.CONV_DIRECT_SPLIT   # opt-in experiment: wins over the defaults
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)
                     _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()

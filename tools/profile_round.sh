@@ -43,7 +43,7 @@ rm -rf $R/gpurun_out/r4p/prof32
 cd $R
 head -30 gpurun_out/r4p/pop32_kernel_stats.txt | cut -c1-70,100-170
 cat gpurun_out/r4p/stream_lds_pmc.txt | cut -c1-130
-tail -2 gpurun_out/r4p/conv_stress.txt gpurun_out/r4p/conv_fuzz.txt
+tail -n 2 gpurun_out/r4p/conv_stress.txt; tail -n 2 gpurun_out/r4p/conv_fuzz.txt
 cat gpurun_out/r4p/run_configs.txt
 head -34 gpurun_out/r4p/kernel_stats.txt | cut -c1-70,100-170
 tail -4 gpurun_out/r4p/kernel_stats.txt

@@ -66,8 +66,9 @@ def run_es_point(label, plugins, pop, iters, seconds, random_crop, find_w0, mode
     """One whole run_es call (the reference's user path: style_transfer.py:399-692) at one of the reference's own operating
     points, timed from the call to the result: candidate evaluations (the find_w0 batch included) / wall time."""
     from st_ito.style_transfer import load_plugins, run_es
-    plugins = load_plugins(plugins)
-    D = sum(p["num_params"] for p in plugins.values())
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):   # load_plugins prints every parameter, like the reference
+        plugins, D, _ = load_plugins(plugins)
     n = int(seconds * SR)
     x = synth_audio(300, 2, n)[None]
     tg = torch.from_numpy(process_audio(synth_audio(301, 2, n).numpy(), np.random.default_rng(3).random(D), SR, plugins))[None]
