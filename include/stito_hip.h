@@ -79,11 +79,11 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 7 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+/* ABI version: 8 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
  * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT;
- * 7: STITO_CONV_WINOGRAD_F2_REG). */
+ * 7: STITO_CONV_WINOGRAD_F2_REG; 8: stito_conv_block1_f2reg + stito_cnn14_weights.conv1_f2reg_w_dev (appended)). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -241,6 +241,9 @@ typedef struct {
     const float *fc_side_b_dev;  /* (embed_dim) */
     const float *conv1_fused_w_dev; /* stito_cnn14_pack_conv1_fused, or NULL.  With it and an F(4x4,3x3) packing of conv index 1
                                        the forward runs conv_block1 as ONE launch (stito_conv_block1_fused) */
+    const float *conv1_f2reg_w_dev; /* stito_cnn14_pack_conv1_f2reg, or NULL (ABI v8).  With it and a
+                                       STITO_CONV_WINOGRAD_F2_REG packing of conv index 1 the forward runs conv_block1 as ONE
+                                       launch (stito_conv_block1_f2reg): the 64-channel full-resolution map is never stored */
 } stito_cnn14_weights;
 
 /* Number of floats of a packed conv weight for (cout, cin) and algorithm. */
@@ -281,6 +284,24 @@ int stito_conv_block1_fused_supported(int n, int H, int W, int c1, int cout, int
 int stito_conv_block1_fused(const float *x_dev, const float *fused_w1_dev, const float *shift1_dev, const float *packed_w2_dev,
                             const float *scale2_dev, const float *shift2_dev, float *out_dev, int n, int H, int W, int c1,
                             int cout, int pool, void *stream);
+/* conv_block1 in one launch on the register-resident F(2x2,3x3) kernel (STITO_CONV_WINOGRAD_F2_REG; ABI v8): same function
+ * as stito_conv_block1_fused.  The first conv (c1 = 64 channels, bn1, ReLU) is evaluated on the f16 matrix pipe (4 x 4 window
+ * x 32 channels x 32 pixels per product; operands split into f16 hi + lo like the second conv's, three products, f32
+ * accumulate) straight into the LDS patch ring of the second conv, in the instruction slots where the unfused kernel issues
+ * its patch copies.
+ *   packed_w1_dev  stito_cnn14_pack_conv1_f2reg(w1 (c1,1,3,3), bn1 scale, bn1 shift): stito_cnn14_packed_conv1_f2reg_floats()
+ *   packed_w2_dev  STITO_CONV_WINOGRAD_F2_REG packing of w2 (cout, c1, 3, 3);  scale2_dev / shift2_dev (cout)
+ *   workspace      stito_conv_block1_f2reg_workspace_bytes (per-stream scales of the log-mel operand)
+ *   amax_out_dev   NULL, or n zeroed words: per-stream maxima of the output (bit patterns) for a split-precision layer behind
+ * |x| must stay below 2^29 (log-mel values do: dB); needs c1 == 64, cout % 64 == 0. */
+size_t stito_cnn14_packed_conv1_f2reg_floats(void);
+int stito_cnn14_pack_conv1_f2reg(const float *w_oihw_dev, const float *scale_dev, const float *shift_dev, int c1, float *packed_dev,
+                                 void *stream);
+int stito_conv_block1_f2reg_supported(int n, int H, int W, int c1, int cout, int pool);
+size_t stito_conv_block1_f2reg_workspace_bytes(int n, int H, int W, int c1, int cout, int pool);
+int stito_conv_block1_f2reg(const float *x_dev, const float *packed_w1_dev, const float *packed_w2_dev, const float *scale2_dev,
+                            const float *shift2_dev, float *out_dev, int n, int H, int W, int c1, int cout, int pool,
+                            void *workspace_dev, size_t workspace_bytes, void *stream, unsigned *amax_out_dev);
 /* Profiling aid: with buf_dev != NULL the Winograd launches use an instrumented instantiation whose
  * workgroup 100 records s_memtime stamps of 32 chunks x 12 waves x 8 phases (int64) into buf_dev;
  * NULL (default) restores the plain kernel.  Thread-local.  See tools/wino_timeline.py. */

@@ -1099,6 +1099,32 @@ extern "C" int stito_conv_block1_fused(const float *x_dev, const float *fused_w1
                                ConvShape{n, H, W, c1, cout}, pool != 0, (hipStream_t)stream);
 }
 
+extern "C" size_t stito_cnn14_packed_conv1_f2reg_floats(void) { return conv1_f2reg_packed_floats(); }
+
+extern "C" int stito_cnn14_pack_conv1_f2reg(const float *w_oihw_dev, const float *scale_dev, const float *shift_dev, int c1,
+                                            float *packed_dev, void *stream) {
+    return pack_conv1_f2reg(w_oihw_dev, scale_dev, shift_dev, c1, packed_dev, (hipStream_t)stream);
+}
+
+extern "C" int stito_conv_block1_f2reg_supported(int n, int H, int W, int c1, int cout, int pool) {
+    if (n <= 0 || H <= 0 || W <= 0) return 0;
+    return wino23r_fused1_supported(ConvShape{n, H, W, c1, cout}, pool != 0) ? 1 : 0;
+}
+
+extern "C" size_t stito_conv_block1_f2reg_workspace_bytes(int n, int H, int W, int c1, int cout, int pool) {
+    if (n <= 0 || H <= 0 || W <= 0) return 0;
+    return wino23r_fused1_workspace_bytes(ConvShape{n, H, W, c1, cout}, pool != 0);
+}
+
+extern "C" int stito_conv_block1_f2reg(const float *x_dev, const float *packed_w1_dev, const float *packed_w2_dev,
+                                       const float *scale2_dev, const float *shift2_dev, float *out_dev, int n, int H, int W, int c1,
+                                       int cout, int pool, void *workspace_dev, size_t workspace_bytes, void *stream,
+                                       unsigned *amax_out_dev) {
+    STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
+    return launch_wino23r_fused1(x_dev, packed_w1_dev, packed_w2_dev, scale2_dev, shift2_dev, out_dev, ConvShape{n, H, W, c1, cout},
+                                 pool != 0, workspace_dev, workspace_bytes, (hipStream_t)stream, amax_out_dev);
+}
+
 extern "C" int stito_bn_fold(const float *gamma_dev, const float *beta_dev, const float *mean_dev, const float *var_dev,
                              double eps, int n, float *scale_dev, float *shift_dev, void *stream) {
     hipLaunchKernelGGL(k_bn_fold, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma_dev, beta_dev, mean_dev, var_dev, (float)eps, n, scale_dev, shift_dev);
@@ -1286,6 +1312,10 @@ static size_t cnn14_pre_bytes(const stito_cnn14_weights *w, int n_streams, const
         const size_t need = stito_conv3x3_workspace_bytes(n_streams, H[blk], W[blk], ci, w->channels[blk + 1], pool, algo);
         v = need > v ? need : v;
     }
+    if (w->conv1_f2reg_w_dev != nullptr && w->channels[0] == 1) {   // conv_block1 in one launch: per-stream scales of the log-mel operand
+        const size_t need = stito_conv_block1_f2reg_workspace_bytes(n_streams, H[0], W[0], w->channels[1], w->channels[1], 1);
+        v = need > v ? need : v;
+    }
     return align_up(v, 256);
 }
 
@@ -1383,8 +1413,44 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     const bool fuse1 = w->conv1_fused_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
                        w->conv_wino_algo[1] == STITO_CONV_WINOGRAD_F4 && w->channels[0] == 1 &&
                        stito_conv_block1_fused_supported(S, H[0], W[0], w->channels[1], w->channels[1], 1);
+    // ... or on the register-resident F(2x2,3x3) kernel, which computes the first conv into its patch ring
+    const bool fuse1r = !fuse1 && w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
+                        w->conv_wino_algo[1] == STITO_CONV_WINOGRAD_F2_REG && w->channels[0] == 1 &&
+                        stito_conv_block1_f2reg_supported(S, H[0], W[0], w->channels[1], w->channels[1], 1) &&
+                        vbytes >= stito_conv_block1_f2reg_workspace_bytes(S, H[0], W[0], w->channels[1], w->channels[1], 1);
     for (int blk = 0; blk < 6; ++blk) {
         const int cin = w->channels[blk], cout = w->channels[blk + 1];
+        if (blk == 0 && fuse1r) {
+            const bool timed = g_conv_timing.on;
+            if (timed) {
+                if (g_conv_timing.used == g_conv_timing.pool.size()) {
+                    hipEvent_t e0, e1;
+                    STITO_HIP_CHECK(hipEventCreate(&e0));
+                    STITO_HIP_CHECK(hipEventCreate(&e1));
+                    g_conv_timing.pool.emplace_back(e0, e1);
+                }
+                STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
+            }
+            unsigned *amax_out = nullptr;   // maxima for conv_block2.conv1 when it runs a split-precision kernel
+            {
+                const int nalgo = w->conv_wino_algo[2];
+                if (w->conv_wino_dev[2] != nullptr &&
+                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLITK ||
+                     nalgo == STITO_CONV_DIRECT_SPLIT || nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
+                    stito_conv3x3_supported(S, H[1], W[1], w->channels[1], w->channels[2], 0, nalgo)) {
+                    amax_out = amax_buf[amax_next];
+                    STITO_HIP_CHECK(hipMemsetAsync(amax_out, 0, (size_t)S * sizeof(unsigned), st));
+                }
+            }
+            const int rc = stito_conv_block1_f2reg(cur, w->conv1_f2reg_w_dev, w->conv_wino_dev[1], w->bn_scale_dev[1], w->bn_shift_dev[1], actB,
+                                                   S, H[0], W[0], cout, cout, 1, vbuf, vbytes, stream, amax_out);
+            if (rc) return rc;
+            amax_have = amax_out;
+            if (amax_out != nullptr) amax_next ^= 1;
+            if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
+            cur = actB;
+            continue;
+        }
         if (blk == 0 && fuse1) {
             const bool timed = g_conv_timing.on;
             if (timed) {

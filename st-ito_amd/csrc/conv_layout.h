@@ -116,6 +116,14 @@ size_t wino23r_packed_floats(int cout, int cin);
 int pack_wino23r(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
 int launch_wino23r(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c, bool pool,
                    void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+// conv_block1 in one launch on that kernel: the first conv (1 -> 64 channels, bn1, ReLU) is computed on the matrix pipe into
+// the patch ring in the slots where the unfused kernel issues its copies (c: the second conv's shape)
+bool wino23r_fused1_supported(const ConvShape &c, bool pool);
+size_t wino23r_fused1_workspace_bytes(const ConvShape &c, bool pool);
+size_t conv1_f2reg_packed_floats();
+int pack_conv1_f2reg(const float *w_dev, const float *scale_dev, const float *shift_dev, int c1, float *packed, hipStream_t st);
+int launch_wino23r_fused1(const float *logmel, const float *c1pk, const float *wpk, const float *scale, const float *shift, float *out,
+                          const ConvShape &c, bool pool, void *ws, size_t ws_bytes, hipStream_t st, unsigned *amax_out);
 bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv
 int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st);
 int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,

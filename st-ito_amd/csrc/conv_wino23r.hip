@@ -83,7 +83,14 @@ struct W23Geom {
     unsigned *amax_out;        // or NULL: per stream, the largest output (atomicMax; zeroed by the caller)
     const float *u_inv;        // 1 / weight scale (header of the packed weights)
     long long *clk;            // or NULL (STITO_W23_CLK=1, a measurement aid): {shader clock, 100 MHz clock} at the start / end of one workgroup
+    // FUSE1 (conv_block1 in one launch): `in` is the 1-channel log-mel image (S, H, W); the 64-channel input of this layer is
+    // relu(bn1(conv3x3(in))), computed on the matrix pipe into the patch ring instead of being copied
+    const char *c1w;           // first-conv operands (pack_conv1_f2reg): [channel block of 32][hi | lo][lane] x 16 B
+    const unsigned *c1_sm;     // per stream: power-of-two scale of the log-mel operand (bit pattern)
+    const unsigned *c1_kinv;   // per stream: 1 / (that scale x the first-conv weight scale): the ring holds K x the activations
 };
+static constexpr int W23_MELROW = 256;                 // bytes per row of a staged log-mel window (64 floats, 38 used)
+static constexpr int W23_MELBUF = 9 * W23_MELROW;      // rows 4 band - 2 .. 4 band + 6
 
 #define W23_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 // The products are inline asm so that the weight operand can be pinned to the AGPR half of the register file ("a": hipcc
@@ -127,7 +134,7 @@ __device__ __forceinline__ float w23_vscale_s(unsigned amax_bits) {
 
 struct W23Cur { int s, band, txb; };  // pixel group = (stream, band of 2 tile rows, block of 16 tile columns)
 
-template <int KS, int NB, bool POOL>
+template <int KS, int NB, bool POOL, bool FUSE1>
 __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__restrict__ in, const char *__restrict__ wpk,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 float *__restrict__ out, W23Geom g) {
@@ -137,6 +144,8 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     char *const ring = smem;
     char *const xch = smem + W23_RING * W23_ENTRY;
     float *const bnp = (float *)(xch + XCH);  // [scale | shift][32 NB]
+    char *const c1a = (char *)(bnp + 2 * 32 * NB);   // FUSE1: first-conv weight operands (4 KB), two log-mel windows
+    char *const melbuf = c1a + 4096;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,6 +251,124 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
                      : "=&s"(keep_) : "v"(dma_voff), "s"(sb_), "s"(dma_lds + (unsigned)eo_), "s"(dma_mask) : "memory"); \
         if (dma_edge && lane < W23_PLANE && !((dma_mask >> lane) & 1)) *(f32x4 *)(zf_lane + eo_) = (f32x4)(0.0f); \
     }
+
+    // ---- FUSE1: the first conv on the matrix pipe.  D[channel, pixel] = sum_k A[channel, k] B[k, pixel], k = 4 r + c over the
+    // 4 x 4 log-mel window at the pixel (the 3 x 3 taps of relu(bn1(conv3x3)) with bn1's scale folded in, zero weights on the
+    // fourth row / column; slot 15 carries bn1's shift against a constant operand, slot 7 a zero against the same constant).
+    // Wave w computes ITS parity plane (the pixels it would have copied): pixel block nb = plane pixels 32 nb .. 32 nb + 31
+    // (lane % 32; window rows 2 (lane / 32), + 1 = the lane's k octet), channel block mb = 32 channels = two k-steps of the ring.
+    // Operands are f16 hi + lo like the main products' (weights x a per-layer power of two, log-mel x a per-stream one):
+    // three products, f32 accumulate; the ring holds K x relu(..), K = the product of the two scales -- a power of two that the
+    // transform's scale takes back out (W23_SV), so no instruction is spent on it.  An accumulator register quad = 4
+    // consecutive channels of the lane's pixel = one 16-byte slot of the ring's [quad][plane][pixel] layout.
+    const int c1_ps1 = 32 + t31 < W23_PLANE ? 32 + t31 : W23_PLANE - 1;
+    const int mrd0 = ((2 * (t31 / 17) + (wv >> 1) + 2 * half) * 64 + 2 * (t31 % 17) + (wv & 1)) * 4;
+    const int mrd1 = ((2 * (c1_ps1 / 17) + (wv >> 1) + 2 * half) * 64 + 2 * (c1_ps1 % 17) + (wv & 1)) * 4;
+    const unsigned mel_voff = (unsigned)lane * 4u;
+    const int mel_ss = g.H * g.W * 4;              // bytes per stream of the log-mel image (wino23r_supported: H W 32 < 2^31)
+    const unsigned c1_wo = lds0 + (unsigned)(((half * 4 + wv) * W23_PLANE + t31) * 16);   // LDS address of (quad lane / 32, plane wv, pixel lane % 32), entry 0
+    const uint64_t mel_call = (1ull << 40) - 1;
+    const uint64_t mel_cleft = __builtin_amdgcn_ballot_w64(lane >= 2);
+    const uint64_t mel_cright = __builtin_amdgcn_ballot_w64(32 * (g.n_txb - 1) - 2 + lane < g.W);
+    const uint64_t mel_cright2 = __builtin_amdgcn_ballot_w64(32 * (g.n_txb - 2) - 2 + lane < g.W);   // the window is 40 wide: the last but one block can cross the edge too
+    uint64_t c1_keep0 = 0, c1_keep1 = 0;
+    float c1_smf = 1.0f;
+    int mel_pB = 1;                // window buffer of the NEXT group (cB); the group after it (cA) uses the other one
+    float c1m[8];
+    ru4 c1bh, c1bl;
+    rh8 c1wh, c1wl;
+    f32x16 c1acc;
+#define W23_C1_PREP(C_)                                                                                          \
+    {                                                                                                            \
+        uint64_t m_ = m_all;                                                                                     \
+        if ((C_).band == 0) m_ &= m_top;                                                                         \
+        if ((C_).band == g.n_bands - 1) m_ &= m_bot;                                                             \
+        if ((C_).txb == 0) m_ &= m_left;                                                                         \
+        if ((C_).txb == g.n_txb - 1) m_ &= m_right;                                                              \
+        c1_keep0 = (m_ & 0xffffffffull) | (m_ << 32);                                                            \
+        c1_keep1 = (m_ >> 32) & 0x7ffffull;                                                                      \
+        c1_keep1 |= c1_keep1 << 32;                                                                              \
+        c1_smf = __uint_as_float(g.c1_sm[(C_).s]);                                                               \
+    }
+// row RR_ (wave-uniform) of the log-mel window of group C_ -> window buffer P_: one masked LDS-DMA of <= 40 dwords; what lies
+// outside the map is the first conv's zero padding, written by hand.  (Rows 0..7 x columns 0..35 carry weights; row 8 and
+// the columns behind only ever meet the zero weights of the 4 x 4 window: they are zeroed once, in the prologue.)
+#define W23_MEL_ROW(C_, P_, RR_)                                                                                 \
+    {                                                                                                            \
+        const int rg_ = 4 * (C_).band - 2 + (RR_);                                                               \
+        const bool rok_ = (unsigned)rg_ < (unsigned)g.H;                                                         \
+        char *const mr_ = melbuf + (P_) * W23_MELBUF + (RR_) * W23_MELROW;                                       \
+        if (rok_) {                                                                                              \
+            const char *sb_ = mel_sb_ + (rg_ * g.W + 32 * (C_).txb - 2) * 4;   /* 32-bit inside a stream */      \
+            uint64_t keep_;                                                                                      \
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"             \
+                         "global_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"                                    \
+                         : "=&s"(keep_) : "v"(mel_voff), "s"(sb_), "s"(lds0 + (unsigned)(mr_ - smem)), "s"(mel_cm_) : "memory"); \
+        }                                                                                                        \
+        if ((!rok_ || mel_cm_ != mel_call) && lane < 40 && !(rok_ && ((mel_cm_ >> lane) & 1))) *(float *)(mr_ + lane * 4) = 0.0f; \
+    }
+#define W23_MEL_DMA(C_, P_)                                                                                      \
+    {                                                                                                            \
+        uint64_t mel_cm_ = mel_call;                                                                             \
+        const char *mel_sb_ = (const char *)in + (int64_t)(C_).s * mel_ss;                                       \
+        if ((C_).txb == 0) mel_cm_ &= mel_cleft;                                                                 \
+        if ((C_).txb == g.n_txb - 1) mel_cm_ &= mel_cright;                                                      \
+        if ((C_).txb == g.n_txb - 2) mel_cm_ &= mel_cright2;                                                     \
+        W23_MEL_ROW(C_, P_, wv) W23_MEL_ROW(C_, P_, wv + 4)                                                      \
+    }
+#define W23_C1_A(MB_) { c1wh = *(const rh8 *)(c1a + ((MB_) * 2 + 0) * 1024 + lane * 16); c1wl = *(const rh8 *)(c1a + ((MB_) * 2 + 1) * 1024 + lane * 16); }
+#define W23_C1_MLD(NB_, P_)                                                                                      \
+    {                                                                                                            \
+        const char *mp_ = melbuf + (P_) * W23_MELBUF + ((NB_) ? mrd1 : mrd0);                                    \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) c1m[k_] = *(const float *)(mp_ + (k_ >> 2) * W23_MELROW + (k_ & 3) * 4); \
+    }
+// the lane's 8 window values -> scaled f16 halves; element 7 is the constant operand (the stream's scale itself: f16-exact).
+// Lanes whose pixel lies outside the map scale by 0: operand 0, constant slot included -> accumulator 0 -> relu 0 = this
+// layer's zero padding, with no second store.
+#define W23_C1_B(NB_)                                                                                            \
+    {                                                                                                            \
+        float vs_;                                                                                               \
+        asm volatile("v_mov_b32 %8, %18\n\tv_cndmask_b32 %8, 0, %8, %17\n\t"                                    \
+                     "v_fma_mixlo_f16 %0, %9, %8, 0\n\tv_fma_mixlo_f16 %1, %11, %8, 0\n\tv_fma_mixlo_f16 %2, %13, %8, 0\n\tv_fma_mixlo_f16 %3, %15, %8, 0\n\t" \
+                     "v_fma_mixhi_f16 %0, %10, %8, 0\n\tv_fma_mixhi_f16 %1, %12, %8, 0\n\tv_fma_mixhi_f16 %2, %14, %8, 0\n\tv_fma_mixhi_f16 %3, %8, 1.0, 0\n\t" \
+                     "v_fma_mixlo_f16 %4, %9, %8, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %5, %11, %8, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t" \
+                     "v_fma_mixlo_f16 %6, %13, %8, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %7, %15, %8, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t" \
+                     "v_fma_mixhi_f16 %4, %10, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %5, %12, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
+                     "v_fma_mixhi_f16 %6, %14, %8, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %7, 0, 0, 0"  \
+                     : "=&v"(c1bh[0]), "=&v"(c1bh[1]), "=&v"(c1bh[2]), "=&v"(c1bh[3]), "=&v"(c1bl[0]), "=&v"(c1bl[1]), "=&v"(c1bl[2]), "=&v"(c1bl[3]), "=&v"(vs_) \
+                     : "v"(c1m[0]), "v"(c1m[1]), "v"(c1m[2]), "v"(c1m[3]), "v"(c1m[4]), "v"(c1m[5]), "v"(c1m[6]), "v"(c1m[7]), \
+                       "s"((NB_) ? c1_keep1 : c1_keep0), "s"(c1_smf));                                           \
+    }
+// lo' hi, hi' lo, hi' hi (the large term last) on ONE accumulator, one product per block of the main stream (a product that
+// follows the one it accumulates on directly waits for it)
+#define W23_C1_MM(P_)                                                                                            \
+    if ((P_) == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c1acc) : "v"(c1wl), "v"(__builtin_bit_cast(rh8, c1bh)));            \
+    else if ((P_) == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c1acc) : "v"(c1wh), "v"(__builtin_bit_cast(rh8, c1bl)));       \
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c1acc) : "v"(c1wh), "v"(__builtin_bit_cast(rh8, c1bh)));
+#define W23_C1_DRAIN() asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c1acc));
+// ReLU as a signed-integer max on the bit patterns (no canonicalising instruction in front of it), then the four register quads
+// -> ring entries E_, E_ + 1 (channels 16 apart), quads 2 (g & 1) + lane / 32; in pixel block 1 only 19 of the 32 lanes have a pixel
+#define W23_C1_ST(NB_, E_)                                                                                       \
+    {                                                                                                            \
+        asm volatile("s_nop 3" : "+v"(c1acc));                                                                   \
+        f32x4 y_[4];                                                                                             \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) y_[r_ >> 2][r_ & 3] = __int_as_float(max(__float_as_int(c1acc[r_]), 0)); \
+        const unsigned d0_ = c1_wo + (unsigned)(W23_ENT(E_) * W23_ENTRY + (NB_) * 512);                          \
+        const unsigned d1_ = c1_wo + (unsigned)(W23_ENT((E_) + 1) * W23_ENTRY + (NB_) * 512);                    \
+        if (NB_) {                                                                                               \
+            uint64_t keep_;                                                                                      \
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %7\n\t"                                         \
+                         "ds_write_b128 %1, %3\n\tds_write_b128 %1, %4 offset:%8\n\tds_write_b128 %2, %5\n\tds_write_b128 %2, %6 offset:%8\n\t" \
+                         "s_mov_b64 exec, %0"                                                                    \
+                         : "=&s"(keep_) : "v"(d0_), "v"(d1_), "v"(y_[0]), "v"(y_[1]), "v"(y_[2]), "v"(y_[3]), "s"(0x0007ffff0007ffffull), \
+                           "n"(2 * 4 * W23_PLANE * 16) : "memory");                                              \
+        } else {                                                                                                 \
+            asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %0, %3 offset:%6\n\tds_write_b128 %1, %4\n\tds_write_b128 %1, %5 offset:%6" \
+                         :: "v"(d0_), "v"(d1_), "v"(y_[0]), "v"(y_[1]), "v"(y_[2]), "v"(y_[3]), "n"(2 * 4 * W23_PLANE * 16) : "memory"); \
+        }                                                                                                        \
+    }
+// the transform's scale: that of the stream's activations (w23_vscale_s of their bound) / K -- powers of two: the exponents add
+#define W23_SV(S_) (FUSE1 ? __uint_as_float(__float_as_uint(w23_vscale_s(g.amax_in[S_])) + g.c1_kinv[S_] - 0x3f800000u) : w23_vscale_s(g.amax_in[S_]))
 
     f32x16 acc[4][NB];
     ru4 bhv[4], blv[4];            // B operands of the four positions: 8 channels as f16 hi / lo (2 per register)
@@ -372,32 +499,61 @@ __global__ __launch_bounds__(W23_THREADS) void k_conv_wino23r(const float *__res
     W23_STAMP(10)
 
     // scale of the transformed input of the group being multiplied and of the next one (reloaded only when the stream changes)
-    float sv = w23_vscale_s(g.amax_in[cC.s]), sv_n = sv;
-#define W23_NEXT_SV() { sv_n = cB.s != cC.s ? w23_vscale_s(g.amax_in[cB.s]) : sv; }
+    float sv = W23_SV(cC.s), sv_n = sv;
+#define W23_NEXT_SV() { sv_n = cB.s != cC.s ? W23_SV(cB.s) : sv; }
 #define W23_ROTATE()                                                                                             \
     {                                                                                                            \
         e_have = true; cD = cC; cC = cB; cB = cA; W23_ADV(cA)                                                    \
         sv = sv_n;                                                                                               \
         ent = W23_ENT(ent + 4);                                                                                  \
+        mel_pB = 1 - mel_pB;                                                                                     \
     }
 
     // ---- prologue: the first group's four k-steps (entries 0..3) and the second group's first two (entries 4, 5); t and the
     // position-0 operands of the first k-step ------------------------------------------------------------------------------
     int ent = 0;  // ring entry of the current group's k-step 0
-    W23_DMA_PREP(cC)
+    if constexpr (FUSE1) {
+        // first-conv operands and the windows of the first two groups -> LDS; then the first group's four k-steps (entries 0..3)
+        // and the second group's first two (entries 4, 5) are computed
+        *(f32x4 *)(c1a + tid * 16) = *(const f32x4 *)(g.c1w + tid * 16);
+        for (int i = tid; i < 2 * W23_MELBUF / 16; i += W23_THREADS) *(f32x4 *)(melbuf + i * 16) = (f32x4)(0.0f);   // row 8, columns 40..: zero for good
+        W23_BARRIER()
+        W23_MEL_DMA(cC, 0)
+        if (g_lo + 1 < g_hi) { W23_MEL_DMA(cB, 1) }
+        W23_X()
+        W23_C1_PREP(cC)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { W23_DMA_Q(k, k, 0) W23_DMA_Q(k, k, 1) W23_DMA_Q(k, k, 2) W23_DMA_Q(k, k, 3) }
-    if (g_lo + 1 < g_hi) {
-        W23_DMA_PREP(cB)
+        for (int mb = 0; mb < 2; ++mb) {
+            W23_C1_A(mb)
+            W23_C1_MLD(0, 0) W23_C1_B(0) W23_C1_MM(0) W23_C1_MM(1) W23_C1_MM(2) W23_C1_DRAIN() W23_C1_ST(0, 2 * mb)
+            W23_C1_MLD(1, 0) W23_C1_B(1) W23_C1_MM(0) W23_C1_MM(1) W23_C1_MM(2) W23_C1_DRAIN() W23_C1_ST(1, 2 * mb)
+        }
+        if (g_lo + 1 < g_hi) {
+            W23_C1_PREP(cB)
+            W23_C1_A(0)
+            W23_C1_MLD(0, 1) W23_C1_B(0) W23_C1_MM(0) W23_C1_MM(1) W23_C1_MM(2) W23_C1_DRAIN() W23_C1_ST(0, 4)
+            W23_C1_MLD(1, 1) W23_C1_B(1) W23_C1_MM(0) W23_C1_MM(1) W23_C1_MM(2) W23_C1_DRAIN() W23_C1_ST(1, 4)
+        }
+    } else {
+        W23_DMA_PREP(cC)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { W23_DMA_Q(k, 4 + k, 0) W23_DMA_Q(k, 4 + k, 1) W23_DMA_Q(k, 4 + k, 2) W23_DMA_Q(k, 4 + k, 3) }
+        for (int k = 0; k < 4; ++k) { W23_DMA_Q(k, k, 0) W23_DMA_Q(k, k, 1) W23_DMA_Q(k, k, 2) W23_DMA_Q(k, k, 3) }
+        if (g_lo + 1 < g_hi) {
+            W23_DMA_PREP(cB)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { W23_DMA_Q(k, 4 + k, 0) W23_DMA_Q(k, 4 + k, 1) W23_DMA_Q(k, 4 + k, 2) W23_DMA_Q(k, 4 + k, 3) }
+        }
     }
     W23_X()
     W23_SETP(0)
 #include "conv_wino23r_pro.inc"
     W23_FENCE()
 
+    if constexpr (FUSE1) {
+#include "conv_wino23r_body_f1.inc"
+    } else {
 #include "conv_wino23r_body.inc"
+    }
 
     // ---- the last group's outputs (its Z are behind W23_ZSTORE's barrier; e_have is true: the loop ran at least once) -------------
     W23_E_BEGIN()
@@ -511,9 +667,11 @@ __global__ __launch_bounds__(256) void k_stream_absmax23(const float *__restrict
     if ((threadIdx.x & 63) == 0 && m) atomicMax(amax + blockIdx.y, m);
 }
 
-template <bool POOL>
+struct W23Fuse1 { const char *c1w; const unsigned *sm, *kinv; };   // FUSE1 launch: `in` is the log-mel image, amax_in the bound of the first conv's output
+
+template <bool POOL, bool FUSE1 = false>
 static int launch_w23(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                      char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
+                      char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out, const W23Fuse1 *f1 = nullptr) {
     constexpr int KS = 4, NB = 2;
     W23Geom g{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
@@ -557,8 +715,10 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
     g.amax_in = amax;
     g.amax_out = amax_out;
     g.u_inv = wpk + (size_t)16 * c.Cout * c.Cin + 1;
-    auto kern = k_conv_wino23r<KS, NB, POOL>;
-    const size_t lds = (size_t)W23_RING * W23_ENTRY + (size_t)4 * 2 * NB * 4 * 1024 + (size_t)2 * 32 * NB * sizeof(float);
+    if (FUSE1) { g.c1w = f1->c1w; g.c1_sm = f1->sm; g.c1_kinv = f1->kinv; }
+    auto kern = k_conv_wino23r<KS, NB, POOL, FUSE1>;
+    const size_t lds = (size_t)W23_RING * W23_ENTRY + (size_t)4 * 2 * NB * 4 * 1024 + (size_t)2 * 32 * NB * sizeof(float) +
+                       (FUSE1 ? (size_t)4096 + 2 * W23_MELBUF : 0);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const bool clk_probe = [] { const char *e = getenv("STITO_W23_CLK"); return e && atoi(e) != 0; }();
     static long long *clk_dev = nullptr;
@@ -571,7 +731,7 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
         STITO_HIP_CHECK(hipStreamSynchronize(st));
         STITO_HIP_CHECK(hipMemcpy(v, clk_dev, sizeof(v), hipMemcpyDeviceToHost));
         const double us = (double)(v[3] - v[2]) / 100.0;
-        fprintf(stderr, "[stito clock] k_conv_wino23r %dx%d %d->%d: workgroup in the middle of the grid ran %.1f us, %lld shader cycles, %.0f MHz\n", c.H, c.W,
+        fprintf(stderr, "[stito clock] k_conv_wino23r%s %dx%d %d->%d: workgroup in the middle of the grid ran %.1f us, %lld shader cycles, %.0f MHz\n", FUSE1 ? " (first conv fused)" : "", c.H, c.W,
                 c.Cin, c.Cout, us, v[1] - v[0], us > 0 ? (double)(v[1] - v[0]) / us : 0.0);
 #if W23_TRACE
         // stamps: 0 phase 0, 1 phase 1, 2 | 3 before / after its wait + barrier, 4 phase 2, 5 phase 3, 6 | 7 its wait, 8 Z exchange, 9 its barrier, 10 done
@@ -593,6 +753,108 @@ int launch_wino23r(const float *in, const float *wpk, const float *scale, const 
                   "conv (winograd F(2x2,3x3), register-resident weights): workspace have %zu need %zu", ws_bytes, wino23r_workspace_bytes(c, pool));
     return pool ? launch_w23<true>(in, wpk, scale, shift, out, c, (char *)ws, st, amax_in, amax_out)
                 : launch_w23<false>(in, wpk, scale, shift, out, c, (char *)ws, st, amax_in, amax_out);
+}
+
+// ---- conv_block1 in one launch (FUSE1) ------------------------------------------------------------------------------------------
+// First-conv operands: A[channel][k = 4 r + c] over the 4 x 4 window = bn1 scale x w1[channel][r][c] (r, c < 3), bn1 shift in
+// slot 15, zero elsewhere; x a power of two (max |A| < 2^e -> 2^(14 - e)), f16 hi + lo, in the A-operand order of
+// v_mfma_f32_32x32x16_f16: [channel block of 32][hi | lo][lane = 32 octet + m] x 16 B (k = 8 octet .. + 7 of channel 32 mb + m).
+// hdr (behind the 4 KB): {scale bits, 1 / scale, max_ch sum_k<15 |A|, max_ch |shift|}.  One wave does it all.
+__global__ __launch_bounds__(64) void k_pack_conv1_f2reg(const float *__restrict__ w, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          char *__restrict__ o) {
+    const int ch = threadIdx.x;
+    float a[16];
+    float sum = 0.0f, mxa = 0.0f;
+    for (int k = 0; k < 16; ++k) {
+        const int r = k >> 2, c = k & 3;
+        a[k] = (r < 3 && c < 3) ? w[ch * 9 + r * 3 + c] * scale[ch] : (k == 15 ? shift[ch] : 0.0f);
+        if (k < 15) sum += fabsf(a[k]);
+        mxa = fmaxf(mxa, fabsf(a[k]));
+    }
+    float bsh = fabsf(shift[ch]);
+    for (int of = 32; of > 0; of >>= 1) {
+        sum = fmaxf(sum, __shfl_xor(sum, of, 64));
+        mxa = fmaxf(mxa, __shfl_xor(mxa, of, 64));
+        bsh = fmaxf(bsh, __shfl_xor(bsh, of, 64));
+    }
+    const unsigned mb_ = __float_as_uint(mxa);
+    int e = (int)((mb_ >> 23) & 0xff) - 126;
+    if (mb_ == 0u) e = 14;
+    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+    const float su = __builtin_ldexpf(1.0f, 14 - e);
+    for (int k = 0; k < 16; ++k) {
+        const float us = a[k] * su;
+        const _Float16 hi = (_Float16)us, lo = (_Float16)(us - (float)hi);
+        char *d = o + ((ch >> 5) * 2) * 1024 + ((k >> 3) * 32 + (ch & 31)) * 16 + (k & 7) * 2;
+        *(_Float16 *)d = hi;
+        *(_Float16 *)(d + 1024) = lo;
+    }
+    if (ch == 0) {
+        float *hdr = (float *)(o + 4096);
+        hdr[0] = su;
+        hdr[1] = __builtin_ldexpf(1.0f, e - 14);
+        hdr[2] = sum;
+        hdr[3] = bsh;
+    }
+}
+
+size_t conv1_f2reg_packed_floats() { return 1024 + 64; }
+
+int pack_conv1_f2reg(const float *w_dev, const float *scale_dev, const float *shift_dev, int c1, float *packed, hipStream_t st) {
+    STITO_REQUIRE(c1 == 64, STITO_E_UNSUPPORTED, "fused first conv (register-resident F(2x2,3x3) block): %d channels", c1);
+    hipLaunchKernelGGL(k_pack_conv1_f2reg, dim3(1), dim3(64), 0, st, w_dev, scale_dev, shift_dev, (char *)packed);
+    STITO_LAUNCH_CHECK();
+    return STITO_OK;
+}
+
+// per stream: the log-mel operand's scale (max |x| < 2^e -> 2^(12 - e), kept inside f16's normal range: it is also the constant
+// operand of the shift slot), a bound of the first conv's output (sum |A| max |x| + max |shift|: the scale of the transformed
+// input is taken from it, as the other layers take it from the measured maximum), 1 / (log-mel scale x weight scale)
+__global__ __launch_bounds__(256) void k_w23_mel_params(const float *__restrict__ x, int64_t per_stream, const float *__restrict__ hdr,
+                                                        unsigned *__restrict__ amax_in, unsigned *__restrict__ sm, unsigned *__restrict__ kinv) {
+    __shared__ unsigned red[4];
+    const float *xs = x + (int64_t)blockIdx.x * per_stream;
+    unsigned m = 0;
+    for (int64_t i = threadIdx.x; i < per_stream; i += 256) m = max(m, __float_as_uint(xs[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, of, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        int e = (int)((m >> 23) & 0xff) - 126;
+        if (m == 0u) e = 12;
+        e = e < -3 ? -3 : (e > 26 ? 26 : e);                 // 2^-14 <= scale <= 2^15
+        const float s_m = __builtin_ldexpf(1.0f, 12 - e);
+        const float bound = (hdr[2] * __uint_as_float(m) + hdr[3]) * 1.001f;
+        amax_in[blockIdx.x] = __float_as_uint(bound);
+        sm[blockIdx.x] = __float_as_uint(s_m);
+        kinv[blockIdx.x] = __float_as_uint(hdr[1] / s_m);    // powers of two: exact
+    }
+}
+
+bool wino23r_fused1_supported(const ConvShape &c, bool pool) {   // c: the SECOND conv's shape (Cin = the first conv's channels)
+    return c.Cin == 64 && wino23r_supported(c, pool);
+}
+
+size_t wino23r_fused1_workspace_bytes(const ConvShape &c, bool pool) {
+    return wino23r_fused1_supported(c, pool) ? 3 * align_up((size_t)(c.S + 2) * sizeof(unsigned), 256) : 0;
+}
+
+int launch_wino23r_fused1(const float *logmel, const float *c1pk, const float *wpk, const float *scale, const float *shift, float *out,
+                          const ConvShape &c, bool pool, void *ws, size_t ws_bytes, hipStream_t st, unsigned *amax_out) {
+    STITO_REQUIRE(wino23r_fused1_supported(c, pool), STITO_E_UNSUPPORTED,
+                  "fused conv block (winograd F(2x2,3x3), register-resident weights): %dx%d map, %d -> %d channels not covered", c.H, c.W, c.Cin, c.Cout);
+    STITO_REQUIRE(ws != nullptr && ws_bytes >= wino23r_fused1_workspace_bytes(c, pool), STITO_E_WORKSPACE,
+                  "fused conv block (winograd F(2x2,3x3), register-resident weights): workspace have %zu need %zu", ws_bytes, wino23r_fused1_workspace_bytes(c, pool));
+    const size_t part = align_up((size_t)(c.S + 2) * sizeof(unsigned), 256);
+    unsigned *amax_in = (unsigned *)ws, *sm = (unsigned *)((char *)ws + part), *kinv = (unsigned *)((char *)ws + 2 * part);
+    STITO_HIP_CHECK(hipMemsetAsync(ws, 0, 3 * part, st));   // the two entries behind the last stream are read (not used) by the look-ahead
+    hipLaunchKernelGGL(k_w23_mel_params, dim3((unsigned)c.S), dim3(256), 0, st, logmel, (int64_t)c.H * c.W, c1pk + 1024, amax_in, sm, kinv);
+    STITO_LAUNCH_CHECK();
+    const W23Fuse1 f1{(const char *)c1pk, sm, kinv};
+    return pool ? launch_w23<true, true>(logmel, wpk, scale, shift, out, c, (char *)ws, st, amax_in, amax_out, &f1)
+                : launch_w23<false, true>(logmel, wpk, scale, shift, out, c, (char *)ws, st, amax_in, amax_out, &f1);
 }
 
 }  // namespace stito

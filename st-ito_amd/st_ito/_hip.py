@@ -50,6 +50,7 @@ class Cnn14Weights(Structure):
         ("fc_mid_wt_dev", c_void_p), ("fc_mid_b_dev", c_void_p),
         ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
         ("conv1_fused_w_dev", c_void_p),
+        ("conv1_f2reg_w_dev", c_void_p),
     ]
 
 
@@ -93,6 +94,12 @@ SIGNATURES = {
     "stito_conv_block1_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv_block1_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_void_p]),
+    "stito_cnn14_packed_conv1_f2reg_floats": (c_size_t, []),
+    "stito_cnn14_pack_conv1_f2reg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "stito_conv_block1_f2reg_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "stito_conv_block1_f2reg_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "stito_conv_block1_f2reg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "stito_conv3x3_issued_flops": (c_double, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stito_conv3x3_bn_relu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -146,6 +146,8 @@ class Cnn14(nn.Module):
         # transformed weights resident in registers and the input transform done in registers (CONV_WINOGRAD_F2_REG), unless
         # STITO_CONV_F2REG=0
         self.conv_f2reg = os.environ.get("STITO_CONV_F2REG", "1") != "0"
+        # conv_block1 as ONE launch of that kernel (the first conv computed into its patch ring); STITO_CONV_FUSE1=0: two launches
+        self.conv_fuse1 = os.environ.get("STITO_CONV_FUSE1", "1") != "0"
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -227,6 +229,16 @@ class Cnn14(nn.Module):
                     _hip.check(L.stito_cnn14_pack_conv1_fused(_hip.ptr(w), _hip.ptr(scale), cout, _hip.ptr(fw), st))
                     W.conv1_fused_w_dev = fw.data_ptr()
                     keep.append(fw)
+        if (self.conv_fuse1 and int(W.conv_wino_algo[1]) == _hip.CONV_WINOGRAD_F2_REG and W.conv_wino_dev[1] and
+                self.conv_block1.conv1.weight.shape[:2] == (64, 1)):
+            # conv_block1 in one launch (stito_conv_block1_f2reg): the first conv is computed on the matrix pipe into the second
+            # conv's patch ring, in the slots where the unfused kernel issues its copies; the 64-channel full-resolution map
+            # (7.9 GB at 512 streams, written once and read 1.5 times) never exists
+            w1 = self.conv_block1.conv1.weight.detach().to(torch.float32).contiguous()
+            fw = torch.empty(L.stito_cnn14_packed_conv1_f2reg_floats(), dtype=torch.float32, device=dev)
+            _hip.check(L.stito_cnn14_pack_conv1_f2reg(_hip.ptr(w1), W.bn_scale_dev[0], W.bn_shift_dev[0], 64, _hip.ptr(fw), st))
+            W.conv1_f2reg_w_dev = fw.data_ptr()
+            keep += [w1, fw]
         for name in ("mid", "side"):
             fc = getattr(self, f"fc_{name}")
             w = fc.weight.detach().to(torch.float32).contiguous()           # (E, 2048)

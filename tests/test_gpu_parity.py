@@ -5,6 +5,7 @@ reference.  Tolerances: bit-level for index/shape logic, float tolerances stated
 
 Run with:  python -m pytest tests -m gpu
 """
+import ctypes
 import os
 
 import numpy as np
@@ -609,6 +610,90 @@ def test_conv_block1_fused_vs_torch(dev, n, H, W, c1, cout, pool):
     assert (out - out2).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("n,H,W,cout,pool", [(2, 33, 128, 64, 1), (3, 9, 64, 64, 1), (5, 6, 32, 128, 1), (2, 21, 40, 128, 0),
+                                              (1, 469, 128, 64, 1), (4, 13, 128, 64, 1), (3, 7, 130, 64, 0), (6, 4, 16, 64, 1),
+                                              (2, 2, 2, 64, 1), (1, 1, 1, 64, 0), (40, 10, 34, 64, 1)])
+def test_conv_block1_f2reg_vs_torch(dev, n, H, W, cout, pool):
+    """stito_conv_block1_f2reg (ABI v8; the model's default for conv_block1): relu(bn1(conv3x3(x))) -> relu(bn2(conv3x3(.)))
+    (+ 2x2 average pool) of a 1-channel map in ONE launch of the register-resident F(2x2,3x3) kernel -- the first conv is
+    computed on the f16 matrix pipe (split operands) into the second conv's patch ring (panns.py:65-80, 250) -- against
+    float64 torch, PER STREAM (5e-5 of the stream's own output maximum), with streams 1e3 x / 1e-3 x the others, an all-zero
+    stream and a stream with one outlier in one launch; bitwise equal for every persistent-grid size (a workgroup's walk over
+    its pixel groups, the look-ahead behind its last group), and the reported per-stream maxima equal those of the output."""
+    from st_ito import _hip
+    L = _hip.lib()
+    c1 = 64
+    assert L.stito_conv_block1_f2reg_supported(n, H, W, c1, cout, pool)
+    g = torch.Generator().manual_seed(H * 100 + W + cout)
+    x = torch.randn((n, 1, H, W), generator=g)
+    if n >= 2: x[1] *= 1e3
+    if n >= 3: x[2] *= 1e-3
+    if n >= 4: x[3] = 0.0
+    if n >= 5: x[4, 0, H // 2, W // 3] = 250.0
+    w1 = torch.randn((c1, 1, 3, 3), generator=g) / 3.0
+    w2 = torch.randn((cout, c1, 3, 3), generator=g) / np.sqrt(9 * c1)
+    s1, h1 = 0.5 + torch.rand(c1, generator=g), 0.3 * torch.randn(c1, generator=g)
+    s2, h2 = 0.5 + torch.rand(cout, generator=g), 0.2 * torch.randn(cout, generator=g)
+    F = torch.nn.functional
+    y = torch.relu(F.conv2d(x.double(), w1.double(), padding=1) * s1.double()[None, :, None, None] + h1.double()[None, :, None, None])
+    y = torch.relu(F.conv2d(y, w2.double(), padding=1) * s2.double()[None, :, None, None] + h2.double()[None, :, None, None])
+    if pool:
+        y = F.avg_pool2d(y, 2)
+    n_, C_, H_, W_ = y.shape
+    ref = y.reshape(n_, C_ // 8, 8, H_, W_).permute(0, 1, 3, 4, 2).contiguous()
+    st = _hip.stream_ptr()
+    xd = x.reshape(n, H, W).contiguous().to(dev)
+    w1d, s1d, h1d, w2d, s2d, h2d = (t.contiguous().to(dev) for t in (w1, s1, h1, w2, s2, h2))
+    fw = torch.empty(L.stito_cnn14_packed_conv1_f2reg_floats(), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv1_f2reg(_hip.ptr(w1d), _hip.ptr(s1d), _hip.ptr(h1d), c1, _hip.ptr(fw), st))
+    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, c1, _hip.CONV_WINOGRAD_F2_REG), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w2d), cout, c1, _hip.CONV_WINOGRAD_F2_REG, _hip.ptr(upk), st))
+    wsb = L.stito_conv_block1_f2reg_workspace_bytes(n, H, W, c1, cout, pool)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+
+    def run():
+        out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
+        amax = torch.zeros(n, dtype=torch.int32, device=dev)
+        _hip.check(L.stito_conv_block1_f2reg(_hip.ptr(xd), _hip.ptr(fw), _hip.ptr(upk), _hip.ptr(s2d), _hip.ptr(h2d), _hip.ptr(out),
+                                             n, H, W, c1, cout, pool, _hip.ptr(ws), wsb, st, _hip.ptr(amax)))
+        return out, amax
+
+    out, amax = run()
+    got = out.cpu().double()
+    assert not torch.isnan(got).any(), "unwritten outputs"
+    worst = 0.0
+    for i in range(n):
+        m = ref[i].abs().max().item()
+        e = (got[i] - ref[i]).abs().max().item()
+        if H_ * W_ > 0:
+            worst = max(worst, e / max(m, 1e-30))
+            assert e <= 5e-5 * m + 1e-30, f"stream {i}: max err {e:.3e} of {m:.3e}"
+    print(f"fused block (f2reg) {n}x{H}x{W} 1->{c1}->{cout} pool={pool}: worst per-stream err {worst:.2e} of the stream's maximum")
+    if H_ * W_ > 0:
+        assert torch.equal(amax.cpu().view(torch.float32), out.reshape(n, -1).max(dim=1).values.cpu()), "reported per-stream maxima"
+    # against the two launches (first conv kernel, then the same F(2x2,3x3) kernel on its stored output): the same function
+    pk1 = torch.empty(L.stito_cnn14_packed_conv_floats(c1, 1, 0), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w1d), c1, 1, 0, _hip.ptr(pk1), st))
+    mid = torch.empty((n, c1 // 8, H, W, 8), device=dev)
+    _hip.check(L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(pk1), _hip.ptr(s1d), _hip.ptr(h1d), _hip.ptr(mid), n, H, W, 1, c1, 0, 0, st))
+    out2 = torch.empty_like(out)
+    wsb2 = L.stito_conv3x3_workspace_bytes(n, H, W, c1, cout, pool, _hip.CONV_WINOGRAD_F2_REG)
+    ws2 = torch.empty(max(wsb2, 16), dtype=torch.uint8, device=dev)
+    _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(mid), _hip.ptr(upk), _hip.ptr(s2d), _hip.ptr(h2d), _hip.ptr(out2), n, H, W, c1, cout, pool,
+                                          _hip.CONV_WINOGRAD_F2_REG, _hip.ptr(ws2), wsb2, st))
+    for i in range(n):
+        m = ref[i].abs().max().item()
+        assert (out[i] - out2[i]).abs().max().item() <= 2e-5 * m + 1e-30, f"stream {i}: fused vs two launches"
+    # persistent loop: any number of workgroups per channel block gives the same bits
+    for wg in ("8", "16", "64"):
+        os.environ["STITO_W23_WG"] = wg
+        try:
+            o2, a2 = run()
+        finally:
+            del os.environ["STITO_W23_WG"]
+        assert torch.equal(o2, out) and torch.equal(a2, amax), f"STITO_W23_WG={wg}"
+
+
 @pytest.mark.parametrize("norm", ["minmax", "batchnorm", "none"])
 def test_model_vs_golden_reference(dev, golden_dir, norm):
     """Full Cnn14 forward + get_param_embeds against the reference's conv stack output."""
@@ -716,6 +801,45 @@ def test_trunk_with_direct_split_layers(dev):
         for a, c in zip(outs[("f32", n)], outs[("dsplit", n)]):
             rel = ((c - a).abs().max() / a.abs().max()).item()
             print(f"direct split-precision layers vs float32 trunk, n = {n}: {rel:.2e} of the embedding maximum")
+            assert rel < 5e-6, rel
+
+
+@pytest.mark.parametrize("norm", ["batchnorm", "minmax", "none"])
+def test_trunk_block1_one_launch_is_the_default_and_matches_two_launches(dev, norm):
+    """The default trunk runs conv_block1 as ONE launch (conv1_f2reg_w_dev set -> stito_cnn14_forward calls
+    stito_conv_block1_f2reg; 11 timed conv launches per pass either way: the first conv on its own is VALU work and not
+    timed); STITO_CONV_FUSE1=0 / conv_fuse1 = False restores the two launches.
+    Same function: embeddings inside float32 rounding of each other on a bench-shaped input and a short one, for every
+    input_norm mode (raw dB values up to ~100 included), with a stream 1e-3 x the others in the batch."""
+    from st_ito import _hip
+    from st_ito.models.panns import Cnn14
+    L = _hip.lib()
+    om = O.fill_deterministic(O.Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, norm), 0).eval()
+    outs, launches = {}, {}
+    for kind in ("one", "two"):
+        pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, norm)
+        pm.load_state_dict(om.state_dict())
+        pm.eval().to(dev)
+        if kind == "two":
+            pm.conv_fuse1 = False
+        W, _, _ = pm._ensure()
+        assert bool(W.conv1_f2reg_w_dev) == (kind == "one")
+        assert int(W.conv_wino_algo[1]) == _hip.CONV_WINOGRAD_F2_REG
+        for n in (480000, 40001):
+            x = torch.stack([O.synth_audio(70 + i, 2, n) * (1.0 if i != 1 else 1e-3) for i in range(3)])
+            _hip.check(L.stito_conv_timing_enable(1))
+            try:
+                outs[(kind, n)] = [t.clone() for t in pm(x.to(dev))]
+                tot, cnt = ctypes.c_double(), ctypes.c_int()
+                _hip.check(L.stito_conv_timing_read(ctypes.byref(tot), ctypes.byref(cnt)))
+            finally:
+                _hip.check(L.stito_conv_timing_enable(0))
+            launches[(kind, n)] = cnt.value
+    for n in (480000, 40001):
+        assert launches[("one", n)] == 11 and launches[("two", n)] == 11, launches
+        for a, c in zip(outs[("two", n)], outs[("one", n)]):
+            rel = ((c - a).abs().max() / a.abs().max()).item()
+            print(f"conv_block1 in one launch vs two, input_norm {norm}, n = {n}: {rel:.2e} of the embedding maximum")
             assert rel < 5e-6, rel
 
 

@@ -22,7 +22,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/stito_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
-    assert lib.stito_version() == 7
+    assert lib.stito_version() == 8
     for kind, n in enumerate([18, 4, 2, 3, 4, 1, 25, 5]):
         assert lib.stito_fx_num_params(kind) == n
     assert lib.stito_fx_num_params(99) < 0

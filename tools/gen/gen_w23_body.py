@@ -37,6 +37,7 @@ import sys
 NB = 2
 DMA_STEP = 1   # blocks between two copies (measured at 512 streams, conv_block1.conv2: 1 -> 5.40 ms, 4 -> 5.73 ms: the copies need the time to land, not a lower issue rate)
 NO_T = NO_M = False   # ablation variants (W23_ABL & 1: no transform instructions, & 2: no products)
+FUSE = False          # "fuse1" variant: the patch is not copied, it is COMPUTED -- relu(bn1(conv3x3(log-mel))) on the matrix pipe -- in the copy slots
 VCOMB = {0: (0, 2, "sub"), 1: (1, 2, "add"), 2: (2, 1, "sub"), 3: (1, 3, "sub")}   # V(i, j) = t[a] -+ t[c]
 
 class Asm:
@@ -117,10 +118,12 @@ def phase(ks, out):
         if s == 0: pre.append(f"W23_STAMP({[0, 1, 4, 5][ks]})")
         if s == 10 and ks in (1, 3):
             pre.append(f"W23_STAMP({2 if ks == 1 else 6}) W23_X() W23_STAMP({3 if ks == 1 else 7})")
-            pre.append("if (more1) { W23_DMA_PREP(cB) }" if ks == 1 else "if (more2) { W23_DMA_PREP(cA) }")
+            if FUSE: pre.append("W23_C1_PREP(cB)" if ks == 1 else "W23_C1_PREP(cA)")
+            else: pre.append("if (more1) { W23_DMA_PREP(cB) }" if ks == 1 else "if (more2) { W23_DMA_PREP(cA) }")
         # the eight copies behind a barrier, DMA_STEP blocks apart: 8 KB per wave issued back to back is more than a CU keeps in
         # flight (~20 KB): the issuing waves -- all of them -- stood still for ~1 400 cycles per burst
         for i in range(8):
+            if FUSE: break
             at = 11 + DMA_STEP * i                      # block index counted from block 0 of the phase with the barrier
             if (ks, s) == ((1 + at // 24) % 4, at % 24):   # behind X of phase 1: k-steps 2, 3 of the next group
                 post.append(f"if (more1) {{ W23_DMA_Q({2 + i // 4}, ent + {i // 4}, {i % 4}) }}")
@@ -128,6 +131,20 @@ def phase(ks, out):
                 if at < 24: post.append(f"if (more2) {{ W23_DMA_Q({i // 4}, ent + {2 + i // 4}, {i % 4}) }}")
                 else:       # ... continued in the next trip of the loop: that group is now "the next one", ent has moved on by 4
                     post.append(f"if (e_have && more1) {{ W23_DMA_Q({i // 4}, ent + {4 + i // 4}, {i % 4}) }}")
+        # fuse1: this wave's parity plane (51 pixels = two column blocks of 32) x 32 first-conv channels (phase 1: channels 32..63 =
+        # k-steps 2, 3 of the next group into this group's entries 0, 1; phase 3: channels 0..31 = k-steps 0, 1 of the group after
+        # next into entries 2, 3) as 2 x 3 products [32 channels x 16 window taps] x [16 taps x 32 pixels]; an accumulator is read
+        # (ReLU, 4 ds_write_b128) two blocks behind its products: two products of the main stream have issued in between, each
+        # waits for the matrix pipe, so the first-conv products have left it.  Behind the phase-1 barrier also the log-mel window of
+        # the group after next (LDS-DMA, <= 3 rows per wave).
+        if FUSE and ks in (1, 3):
+            mb, e0, tg = (1, 0, "mel_pB") if ks == 1 else (0, 2, "1 - mel_pB")
+            items = {10: f"W23_C1_A({mb}) W23_C1_MLD(0, {tg})", 11: "W23_C1_B(0)", 12: "W23_C1_MM(0)", 13: f"W23_C1_MM(1) W23_C1_MLD(1, {tg})",
+                     14: "W23_C1_MM(2)", 15: "W23_C1_B(1)", 16: f"W23_C1_ST(0, ent + {e0}) W23_C1_MM(0)", 17: "W23_C1_MM(1)", 18: "W23_C1_MM(2)",
+                     21: f"W23_C1_ST(1, ent + {e0})"}
+            if s in items:   # unconditional like the look-ahead: behind the last groups it runs on stale windows into entries nobody reads
+                if ks == 1 and s == 10: post.append("if (more2) { W23_MEL_DMA(cA, 1 - mel_pB) }")
+                post.append(items[s])
         nxt_pre = []
         if s == 10: nxt_pre.append(f"W23_SETP(ent + {ks + 1})")
         if 10 <= s <= 17:
@@ -174,7 +191,8 @@ def body(proto):
     out.append("    }")
     return out
 
-proto = len(sys.argv) > 1 and sys.argv[1] == "prologue"
+proto = "prologue" in sys.argv[1:]
+FUSE = "fuse1" in sys.argv[1:]
 print("// GENERATED by tools/gen/gen_w23_body.py -- do not edit (NB = 2, 4 k-steps per group; the W23_ABL & 3 variants are timing experiments)")
 for abl in range(4):
     NO_T, NO_M = bool(abl & 1), bool(abl & 2)
