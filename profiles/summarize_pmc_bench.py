@@ -5,9 +5,10 @@ rocprofv3 --pmc runs of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline 
 Units: the counters are KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of a wide streaming read at 64 B, so the
 read side is doubled (guide, section HBM); WRITE_SIZE is taken as is (uncalibrated).  FETCH_SIZE counts the requests of
 the XCDs' L2s to the fabric: Infinity-Cache hits are in it, so "traffic" is L2-miss traffic, an upper bound of HBM's.
-A trunk pass = the dispatches from one k_conv_first to the next; the LAST pass of the process is a timed bench step at
-the full stream count.  A layer = its transform pass (template MODE 2 / 3 / 4 of k_conv_wino43), if it has one, plus the
-convolution kernel that follows it.
+A trunk pass = the conv dispatches in front of one k_head (back to the k_head before it); the LAST pass of the process is a
+timed bench step at the full stream count.  A layer = its transform pass (template MODE 2 / 3 / 4 of k_conv_wino43), if it
+has one, plus the convolution kernel that follows it; conv_block1 in one launch (k_conv_wino23r<.., FUSE1 = true>, with its
+per-stream scale pass k_w23_mel_params) is ONE layer whose algorithmic bytes are the log-mel image in and the pooled map out.
 Usage: python profiles/summarize_pmc_bench.py <fetch.db> <write.db> <n_streams> [out.json]"""
 import json
 import os
@@ -24,16 +25,15 @@ def dispatches(path, counter):
 
 
 def last_pass(rows):
-    firsts = [i for i, r in enumerate(rows) if "k_conv_first" in r[0]]
-    assert firsts, "no trunk pass in the trace"
-    seg = rows[firsts[-1] + 1:]
-    out = []
-    for r in seg:
-        if "k_conv_wino" in r[0] or "k_conv3x3" in r[0]:
-            out.append(r)
-        if "k_head" in r[0]:
-            break
-    return out
+    heads = [i for i, r in enumerate(rows) if "k_head" in r[0]]
+    assert heads, "no trunk pass in the trace"
+    lo = heads[-2] + 1 if len(heads) > 1 else 0
+    return [r for r in rows[lo:heads[-1]] if "k_conv_wino" in r[0] or "k_conv3x3" in r[0] or "k_w23_mel_params" in r[0]]
+
+
+def fused1(kname):
+    m = re.search(r"k_conv_wino23r<([^>]*)>", kname)
+    return bool(m) and m.group(1).split(",")[-1].strip() in ("true", "1")
 
 
 def mode_of(kname):
@@ -46,7 +46,7 @@ def mode_of(kname):
 
 def kind_of(kname):
     if "k_conv_wino23r" in kname:
-        return "F(2x2,3x3), f16 hi + lo operands, weights resident in registers"
+        return "F(2x2,3x3), f16 hi + lo operands, weights resident in registers" + (", first conv computed into the patch ring" if fused1(kname) else "")
     if "k_conv_wino43s2" in kname:
         return "F(4x4,3x3), f16 hi + lo operands, two sweeps (64 x 64 tiles)"
     if "k_conv_wino43s" in kname:
@@ -64,12 +64,17 @@ assert len(f) == len(w) and [a[0] for a in f] == [b[0] for b in w], (len(f), len
 chans = [64, 128, 256, 512, 1024, 2048]
 shapes = []
 H, W = 469, 128
+one_launch = any(fused1(r[0]) for r in f)
 for b in range(6):
     for j in range(2):
         cin = (chans[b - 1] if b else 1) if j == 0 else chans[b]
         cout = chans[b]
         pool = j == 1 and b < 5
-        if cin % 8 == 0:
+        if one_launch and b == 0:
+            if j == 1:
+                alg = 4.0 * (S * H * W * 1 + S * (H // 2) * (W // 2) * cout + 9 * 1 * 64 + 9 * 64 * cout)
+                shapes.append((f"conv_block1 (one launch) {H}x{W} 1->64->{cout} pool", alg))
+        elif cin % 8 == 0:
             Ho, Wo = (H // 2, W // 2) if pool else (H, W)
             alg = 4.0 * (S * H * W * cin + S * Ho * Wo * cout + 9 * cin * cout)
             shapes.append((f"conv_block{b + 1}.conv{j + 1} {H}x{W} {cin}->{cout}{' pool' if pool else ''}", alg))
@@ -78,6 +83,8 @@ for b in range(6):
 layers, cur = [], []
 for i, (name, _, _) in enumerate(f):
     cur.append(i)
+    if "k_w23_mel_params" in name:
+        continue
     if mode_of(name) in (0, 1) or "k_conv_wino43s" in name or "k_conv_wino43h" in name or "wino43" not in name or "k_conv_wino23r" in name:
         layers.append(cur)
         cur = []

@@ -13,12 +13,12 @@ for path in sys.argv[1:]:
     print(f"{'kernel':100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
     for r in rows:
         print(f"{r[0][:100]:100s} {r[1]:6d} {r[2]:10.3f} {r[3]:10.1f} {r[4]:10.1f} {r[5]:10.1f} {100 * r[2] / tot:6.2f}")
-    # The conv launches as bench.py counts them: the 11 MFMA 3x3-conv layers of every full-size trunk pass.  A layer is one
-    # convolution kernel (> 1 ms at full size: k_conv_wino43 MODE 0 / 1, k_conv_wino43s / s2 / h, k_conv_wino8, k_conv3x3) plus
+    # The conv launches as bench.py counts them: the MFMA 3x3-conv launches of every full-size trunk pass (10 with conv_block1 in one launch).  A layer is one
+    # convolution kernel (> 1 ms at full size: k_conv_wino43 MODE 0 / 1, k_conv_wino43s / s2 / h, k_conv_wino23r, k_conv_wino8, k_conv3x3) plus
     # -- where the F(4x4,3x3) input transform is hoisted -- its transform pass (template MODE 2 / 3 / 4 of k_conv_wino43,
     # > 0.08 ms at full size; the 2-stream target-embedding pass is far below both thresholds).
     import re
-    fam = {"f32": [0, 0.0], "f16": [0, 0.0]}
+    fam = {"f32": [0, 0.0], "f16-stream": [0, 0.0], "f16-reg": [0, 0.0]}   # bench.py's roofline families
     n_tr, t_tr = 0, 0.0
     for name, dur in cur.execute("select name, end-start from kernels where name like '%k_conv_wino%' or name like '%k_conv3x3%'"):
         m = re.search(r"k_conv_wino43<([^>]*)>", name)
@@ -26,15 +26,15 @@ for path in sys.argv[1:]:
         if mode in (2, 3, 4):
             if 8e4 < dur:
                 n_tr += 1; t_tr += dur / 1e6
-                fam["f16" if mode in (3, 4) else "f32"][1] += dur / 1e6
+                fam["f16-stream" if mode in (3, 4) else "f32"][1] += dur / 1e6
         elif dur > 1e6:
-            pipe = "f16" if re.search(r"k_conv_wino43(s2|s|h)<", name) else "f32"
+            pipe = "f16-stream" if re.search(r"k_conv_wino43(s2|s|h)<", name) else ("f16-reg" if "k_conv_wino23r" in name else "f32")
             fam[pipe][0] += 1; fam[pipe][1] += dur / 1e6
-    n = fam["f32"][0] + fam["f16"][0]
+    n = sum(v[0] for v in fam.values())
     if n:
-        total = fam["f32"][1] + fam["f16"][1]
+        total = sum(v[1] for v in fam.values())
         print(f"# conv launches: {n} conv layers ({n_tr} of them with a separate transform pass, {t_tr:.2f} ms in those passes), avg {total / n:.4f} ms per layer, "
               f"total {total:.2f} ms")
-        for pipe in ("f32", "f16"):
+        for pipe in fam:
             if fam[pipe][0]:
                 print(f"#   {pipe} matrix pipe: {fam[pipe][0]} layers, avg {fam[pipe][1] / fam[pipe][0]:.4f} ms per layer   <- compare with roofline*.avg_launch_ms of the bench line")
