@@ -367,7 +367,10 @@ class PopulationEvaluator:
             tgt = self.targets[name]
             if tgt.shape[1] != emb.shape[1]:
                 raise ValueError(f"{name}: candidate embeddings have {emb.shape[1]} dims, the target {tgt.shape[1]}")
-            ed = torch.nn.functional.dropout(emb, p=dropout, training=True).contiguous() if dropout > 0.0 else emb
+            # dropout hits the style embeddings only: the reference scores the content embeddings undropped
+            # (style_transfer.py:545-568: F.dropout on input_embeds[embed_name], then the content term on its own)
+            drop = dropout > 0.0 and not name.startswith("__content__:")
+            ed = torch.nn.functional.dropout(emb, p=dropout, training=True).contiguous() if drop else emb
             for b, q0, q1 in spans:
                 _hip.check(L.stito_neg_cosine(_hip.ptr(ed[q0:q1]), q1 - q0, emb.shape[1], _hip.ptr(tgt[b]),
                                               self.entry_weights.get(name, 1.0) / len(embeds),

@@ -76,7 +76,10 @@ def get_param_embeds(
         print("Warning: NaNs found in side_embeddings")
     ref_dev = getattr(model, "reference_device", None) or dev.type
     if x.dtype == torch.float32 and sample_rate == 48000 and x.device.type == ref_dev and not x.requires_grad:
-        x.div_(peaks.to(x.device).clamp(min=1e-8).view(-1, 1, 1))  # utils.py:473-474 on the caller's tensor
+        try:
+            x.div_(peaks.to(x.device).clamp(min=1e-8).view(-1, 1, 1))  # utils.py:473-474 on the caller's tensor
+        except RuntimeError:
+            pass  # expanded / overlapping view: the reference's in-place division raises there too, after its embeddings are lost; here they are kept
     return {"mid": mid.type_as(x_device), "side": side.type_as(x_device)}
 
 
@@ -176,6 +179,7 @@ def make_synthetic_param_model(seed: int = 0, input_norm: str = "minmax", embed_
     model.eval()
     if torch.cuda.is_available():
         model.cuda()
+    model.reference_device = "cuda" if torch.cuda.is_available() else "cpu"  # as load_param_model(use_gpu=...) records it (get_param_embeds)
     return model
 
 

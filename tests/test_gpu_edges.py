@@ -201,6 +201,46 @@ def test_get_param_embeds_normalises_the_callers_tensor_like_the_reference(dev, 
         pm.reference_device = "cuda"
 
 
+def test_get_param_embeds_takes_an_expanded_view(dev, pm):
+    """An expanded (stride-0) batch cannot be divided in place (torch raises): the embeddings still come back and equal
+    those of the materialised batch; make_synthetic_param_model records reference_device like load_param_model does."""
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    assert make_synthetic_param_model(1).reference_device == "cuda"
+    one = (0.4 * O.synth_audio(9, 2, 48000)[None]).to(dev)
+    view = one.expand(3, -1, -1)
+    e_view = get_param_embeds(view, pm, SR)
+    e_full = get_param_embeds(view.clone(), pm, SR)
+    assert torch.equal(e_view["mid"], e_full["mid"]) and torch.equal(e_view["side"], e_full["side"])
+
+
+def test_dropout_leaves_the_content_entries_alone(dev, pm):
+    """style_transfer.py:545-568: F.dropout hits the style embeddings only; the content embeddings are scored undropped with
+    weight 2.  Generic-metric path with a fake embed_func whose style and content entries are the same vectors: with the same
+    RNG state the fitness is (-cos(drop(e), t) + 2 (-cos(e, t))) / 2."""
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    P, dim = 5, 96
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn((P, dim), generator=g).to(dev)
+    tgt = torch.randn((1, dim), generator=g).to(dev)
+
+    def fake(x, m, sr):
+        return {"a": emb[: x.shape[0]], "__content__:a": emb[: x.shape[0]]}
+
+    x = O.synth_audio(4, 2, 30000)[None]
+    x /= x.abs().max()
+    ev = PopulationEvaluator(x, SR, E.make_plugins("eq"), pm, {"a": tgt, "__content__:a": tgt}, embed_func=fake,
+                             entry_weights={"__content__:a": 2.0})
+    W = np.random.default_rng(0).random((P, ev.ndims))
+    torch.manual_seed(11)
+    got = ev.evaluate(W, dropout=0.5)[0].cpu()
+    torch.manual_seed(11)
+    ed = torch.nn.functional.dropout(emb, p=0.5, training=True)
+    cos = torch.nn.functional.cosine_similarity
+    want = (-cos(ed, tgt.expand(P, -1)) - 2.0 * cos(emb, tgt.expand(P, -1))).cpu() / 2.0
+    assert torch.allclose(got, want, atol=2e-6), (got, want)
+
+
 def test_parallel_flag_keeps_the_reference_length_policy(dev):
     """reference style_transfer.py:499-502: with parallel=True the pool renders x as it is -- no zero padding to 262144
     samples, no crop -- so a short input is evaluated on its own length.  Serial branch: padded (517-518)."""
