@@ -233,6 +233,15 @@ class PopulationEvaluator:
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         self._streams = None
+        # EXPERIMENT, OFF (STITO_GRAPH=1 to try): the plain fused call -- one population per pass, no crop, no dropout, no audio
+        # handed back -- captured as one hipGraph (render -> log-mel -> Cnn14 -> loss: ~45 launches).  Measured on MI355X:
+        # 45.6 -> 44.4 ms per evaluate at pop 256, 6.4 -> 6.2 ms at pop 32, bitwise the eager result in most processes -- but
+        # in about one process in three every replay after the first returned a few wrong per-candidate peaks (the buffer the
+        # captured hipMemsetAsync node zeroes in front of the last render kernel held foreign bits), whatever synchronisation
+        # surrounded the calls; not root-caused (a torch-only graph under the same pattern is fine), so it does not ship on.
+        self._graph_on = os.environ.get("STITO_GRAPH", "0") == "1"
+        self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls)
+        self._x_padded = None
 
     def _input(self, random_crop: bool, rng, parallel: bool = False) -> torch.Tensor:
         """Length policy of style_transfer.py:505-518 (one crop position for all inputs of a batch).  The reference's
@@ -246,7 +255,74 @@ class PopulationEvaluator:
                 start = int(rng.randint(16384, n - CROP_LEN)) if (n - CROP_LEN) > 16384 else 0
                 return x[..., start:start + CROP_LEN].contiguous()
             return x
-        return torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
+        if n == CROP_LEN:
+            return x
+        if self._x_padded is None:  # padded once: the same buffer for every call (a captured graph reads it)
+            self._x_padded = torch.nn.functional.pad(x, (0, CROP_LEN - n)).contiguous()
+        return self._x_padded
+
+    def _fused_pass(self, Wc, x, p0, p1, per, n_calls, dropout, want_audio):
+        """One pass of the fused AFx-Rep path over candidates p0 .. p1 - 1 on the current stream:
+        render -> log-mel + Cnn14 -> loss.  -> (loss, mid, side, audio or None, peaks, n_calls)"""
+        L = _hip.lib()
+        B = self.n_inputs
+        b0, b1 = p0 // per, (p1 + per - 1) // per
+        xin = x[0] if B == 1 else x[b0:b1]
+        audio, peaks = render_population(self.plugins, xin, Wc, self.sample_rate, chain=self.chain)
+        mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
+        loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
+        # dropout (style_transfer.py:549-551) hits the embeddings only inside the distance; the cosine is
+        # scale-invariant, so dropping the raw vectors and normalising afterwards is the same quantity.
+        # The returned embeddings stay undropped, like the reference's output_embeds.
+        md, sd = mid, side
+        if dropout > 0.0:
+            md = torch.nn.functional.dropout(mid, p=dropout, training=True).contiguous()
+            sd = torch.nn.functional.dropout(side, p=dropout, training=True).contiguous()
+        spans = [(0, 0, p1 - p0)] if B == 1 else [(b, (b - b0) * per, (b - b0 + 1) * per) for b in range(b0, b1)]
+        for b, q0, q1 in spans:  # candidates of pair b against target b
+            _hip.check(L.stito_embed_loss(_hip.ptr(md[q0:q1]), _hip.ptr(sd[q0:q1]), q1 - q0, mid.shape[1],
+                                          _hip.ptr(self.tmid[b]), _hip.ptr(self.tside[b]), _hip.ptr(loss[q0:q1]),
+                                          _hip.ptr(self.flags[n_calls % 256]), _hip.stream_ptr()))
+            n_calls += 1
+        if dropout > 0.0:  # NaN scrub + L2 norm of the embeddings handed back
+            _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1], None, None, None,
+                                          _hip.ptr(self.flags[255]), _hip.stream_ptr()))
+        return loss, mid, side, (normalize_audio_(audio, peaks) if want_audio else None), (audio, peaks), n_calls
+
+    def _evaluate_graph(self, W, x, per):
+        """The plain fused call as one hipGraph launch.  Captured on first use per (population size, input buffer) after one
+        eager pass (which also builds everything lazy: packed weights, workspaces, LDS attributes); W travels through a
+        static device buffer; the outputs are copied out of the graph's buffers, so they stay valid across calls."""
+        Wn = np.asarray(W, dtype=np.float64)
+        if Wn.ndim != 2 or Wn.shape[1] != self.ndims:
+            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wn.shape)}")
+        P = Wn.shape[0]
+        key = (P, x.data_ptr(), tuple(x.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            Wbuf = torch.empty((P, self.ndims), dtype=torch.float64, device=self.device)
+            Wbuf.copy_(torch.from_numpy(Wn))
+            side_stream = torch.cuda.Stream(self.device)
+            side_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side_stream):
+                self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)   # eager warm-up (not part of the graph)
+            torch.cuda.current_stream(self.device).wait_stream(side_stream)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                loss, mid, side, _, keep, n_calls = self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
+            # the graph holds raw pointers: everything it touches stays referenced here -- the outputs, the render and trunk
+            # workspaces as they were at capture (a later, larger call replaces those objects; the graph keeps its own)
+            keep = (keep, _WS._bufs.get("render"), getattr(self.model, "_ws", None), x)
+            ent = (g, Wbuf, loss, mid, side, n_calls, keep)
+            if len(self._graphs) >= 4:   # a few shapes at most (find_w0 batch, population, last partial shard)
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = ent
+        g, Wbuf, loss, mid, side, n_calls, _ = ent
+        Wbuf.copy_(torch.from_numpy(Wn))
+        g.replay()
+        self._n_flag_rows = min(n_calls, 255)
+        return loss.clone(), {"mid": mid.clone(), "side": side.clone()}, None
 
     def _groups(self, P: int) -> int:
         """Number of candidate groups pipelined over two HIP streams (STITO_PIPELINE_GROUPS, default
@@ -265,13 +341,10 @@ class PopulationEvaluator:
         software-pipelined over two HIP streams: while group g runs log-mel + Cnn14 + loss on the
         embed stream, group g+1 runs its effect chain on the render stream.  A candidate's result
         does not depend on the grouping."""
-        Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
-        if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
-            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
         x = self._input(random_crop, rng, parallel)
-        P = Wt.shape[0]
+        P = len(W)
         B = self.n_inputs
-        if P % B:
+        if P == 0 or P % B:
             raise ValueError(f"{P} candidates cannot be split over {B} inputs")
         per = P // B  # candidates per input
         G = self._groups(P)
@@ -281,6 +354,13 @@ class PopulationEvaluator:
         if B > 1:  # passes hold whole pairs
             step = max(per, step // per * per)
         bounds = [(p0, min(P, p0 + step)) for p0 in range(0, P, step)]
+        cropped = random_crop and not parallel and self.x_full.shape[-1] > CROP_LEN   # a new input buffer per call
+        if (self._graph_on and self.fused and len(bounds) == 1 and dropout == 0.0 and not want_audio and not cropped and
+                not torch.cuda.is_current_stream_capturing()):
+            return self._evaluate_graph(W, x, per)
+        Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
+        if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
+            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
         L = _hip.lib()
         main = torch.cuda.current_stream(self.device)
         pipelined = len(bounds) > 1 and G > 1
