@@ -1331,7 +1331,7 @@ extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int 
     }
     const size_t feat = (size_t)n_streams * w->channels[6];
     return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + cnn14_pre_bytes(w, n_streams, H, W) +
-           2 * align_up((size_t)n_streams * sizeof(unsigned), 256) + 256;  // + two per-stream output-maximum buffers (split-precision layers)
+           STITO_CNN14_NUM_CONVS * align_up((size_t)n_streams * sizeof(unsigned), 256) + 256;  // + per-stream output maxima, one buffer per conv (split-precision layers)
 }
 
 // ---- optional launch timing for bench.py: HIP events on the launch stream around the MFMA convs ----
@@ -1403,10 +1403,12 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     float *feat = (float *)(ws + align_up(a * 4, 256) + align_up(b * 4, 256));
     const size_t vbytes = cnn14_pre_bytes(w, S, H, W);
     void *vbuf = ws + align_up(a * 4, 256) + align_up(b * 4, 256) + align_up((size_t)S * w->channels[6] * 4, 256);
-    // per-stream output maxima, handed from a layer to the split-precision layer behind it (two buffers, alternating)
-    unsigned *amax_buf[2] = {(unsigned *)((char *)vbuf + vbytes), (unsigned *)((char *)vbuf + vbytes + align_up((size_t)S * sizeof(unsigned), 256))};
+    // per-stream output maxima, handed from a layer to the split-precision layer behind it: one buffer per conv, all zeroed by
+    // ONE memset at the top of the pass (a memset per layer was ten more dispatches per pass)
+    const size_t amax_stride = align_up((size_t)S * sizeof(unsigned), 256);
+    unsigned *const amax_all = (unsigned *)((char *)vbuf + vbytes);
+    STITO_HIP_CHECK(hipMemsetAsync(amax_all, 0, amax_stride * STITO_CNN14_NUM_CONVS, st));
     const unsigned *amax_have = nullptr;  // maxima of the current input, if its producer reported them
-    int amax_next = 0;
 
     const float *cur = logmel_dev;
     // conv_block1 as one launch when the fused first-conv weights and an F(4x4,3x3) packing of its second conv are there
@@ -1438,15 +1440,13 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                     (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLITK ||
                      nalgo == STITO_CONV_DIRECT_SPLIT || nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
                     stito_conv3x3_supported(S, H[1], W[1], w->channels[1], w->channels[2], 0, nalgo)) {
-                    amax_out = amax_buf[amax_next];
-                    STITO_HIP_CHECK(hipMemsetAsync(amax_out, 0, (size_t)S * sizeof(unsigned), st));
+                    amax_out = (unsigned *)((char *)amax_all + amax_stride * 1);
                 }
             }
             const int rc = stito_conv_block1_f2reg(cur, w->conv1_f2reg_w_dev, w->conv_wino_dev[1], w->bn_scale_dev[1], w->bn_shift_dev[1], actB,
                                                    S, H[0], W[0], cout, cout, 1, vbuf, vbytes, stream, amax_out);
             if (rc) return rc;
             amax_have = amax_out;
-            if (amax_out != nullptr) amax_next ^= 1;
             if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
             cur = actB;
             continue;
@@ -1503,8 +1503,7 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                     (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLITK ||
                      nalgo == STITO_CONV_DIRECT_SPLIT || nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
                     stito_conv3x3_supported(S, H[nb], W[nb], nci, w->channels[nb + 1], npool, nalgo)) {
-                    amax_out = amax_buf[amax_next];
-                    STITO_HIP_CHECK(hipMemsetAsync(amax_out, 0, (size_t)S * sizeof(unsigned), st));
+                    amax_out = (unsigned *)((char *)amax_all + amax_stride * i);
                 }
             }
             const int rc = conv3x3_ws(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
@@ -1512,7 +1511,6 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                                       algo_i, vbuf, vbytes, stream, amax_have, amax_out);
             if (rc) return rc;
             amax_have = amax_out;
-            if (amax_out != nullptr) amax_next ^= 1;
             if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
         }
         cur = actB;

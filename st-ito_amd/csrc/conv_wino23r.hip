@@ -830,6 +830,12 @@ __global__ __launch_bounds__(256) void k_w23_mel_params(const float *__restrict_
         amax_in[blockIdx.x] = __float_as_uint(bound);
         sm[blockIdx.x] = __float_as_uint(s_m);
         kinv[blockIdx.x] = __float_as_uint(hdr[1] / s_m);    // powers of two: exact
+        if (blockIdx.x == 0) {   // the two entries behind the last stream: read (not used) by the kernel's look-ahead
+            const int S = (int)gridDim.x;
+            amax_in[S] = amax_in[S + 1] = 0u;
+            sm[S] = sm[S + 1] = 0x3f800000u;
+            kinv[S] = kinv[S + 1] = 0x3f800000u;
+        }
     }
 }
 
@@ -849,7 +855,6 @@ int launch_wino23r_fused1(const float *logmel, const float *c1pk, const float *w
                   "fused conv block (winograd F(2x2,3x3), register-resident weights): workspace have %zu need %zu", ws_bytes, wino23r_fused1_workspace_bytes(c, pool));
     const size_t part = align_up((size_t)(c.S + 2) * sizeof(unsigned), 256);
     unsigned *amax_in = (unsigned *)ws, *sm = (unsigned *)((char *)ws + part), *kinv = (unsigned *)((char *)ws + 2 * part);
-    STITO_HIP_CHECK(hipMemsetAsync(ws, 0, 3 * part, st));   // the two entries behind the last stream are read (not used) by the look-ahead
     hipLaunchKernelGGL(k_w23_mel_params, dim3((unsigned)c.S), dim3(256), 0, st, logmel, (int64_t)c.H * c.W, c1pk + 1024, amax_in, sm, kinv);
     STITO_LAUNCH_CHECK();
     const W23Fuse1 f1{(const char *)c1pk, sm, kinv};
