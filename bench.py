@@ -100,7 +100,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "st-ito_amd", "csrc")
-    for name in ("cnn14.hip", "conv_wino43.hip", "conv_wino23r.hip", "conv_wino23r_body.inc", "conv_wino23r_pro.inc", "conv_direct_split.hip", "conv_layout.h", "common.h"):
+    for name in ("cnn14.hip", "conv_wino43.hip", "conv_wino23r.hip", "conv_wino23r_body.inc", "conv_wino23r_body_f1.inc", "conv_wino23r_pro.inc", "conv_layout.h", "common.h"):
         for line in open(os.path.join(d, name), "r", encoding="utf-8", errors="replace"):
             code = line.split("//", 1)[0].rstrip()
             if code:
@@ -126,7 +126,6 @@ def pmc_traffic_per_launch(n_streams):
 ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)", 3: "winograd F(4x4,3x3), input transform hoisted (two kernels)",
               4: "winograd F(4x4,3x3), input transform hoisted, f32 operands as f16 hi + lo on the f16 matrix pipe (3 products, f32 accumulate)",
               5: "the same on 64 x 64 workgroup tiles in two sweeps over the positions",
-              6: "winograd F(4x4,3x3), transform in the kernel, split operands on the f16 pipe", 7: "direct implicit GEMM, split operands on the f16 pipe",
               8: "winograd F(2x2,3x3), weights resident in registers, input transform in registers, split operands on the f16 pipe"}
 
 
@@ -194,7 +193,7 @@ def conv_layer_times(model, n_streams, T, reps=3):
                                mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)))
             cur = out
             continue
-        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3, 4, 5, 6, 7, 8) else 1
+        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3, 4, 5, 8) else 1
         wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], walgo)
         algo = walgo if wino else 0
         wsb = L.stito_conv3x3_workspace_bytes(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
@@ -211,7 +210,7 @@ def conv_layer_times(model, n_streams, T, reps=3):
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         fl = r["flops"] * n_streams
         issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
-        pipe = "f16-reg" if algo == 8 else ("f16-stream" if algo in (4, 5, 6, 7) else "f32")
+        pipe = "f16-reg" if algo == 8 else ("f16-stream" if algo in (4, 5) else "f32")
         # split-precision kernel: every operand element of every product travels L2 -> LDS as 4 bytes (hi + lo); per workgroup
         # 36 positions x (32 tiles + 64 couts) x cin elements, i.e. 4 / (2 * 32 * 64 / 96) bytes per f32-equivalent MAC
         # (two-sweep kernel: 128 elements per 64 x 64 MACs)

@@ -79,11 +79,12 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 8 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+/* ABI version: 9 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
  * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT;
- * 7: STITO_CONV_WINOGRAD_F2_REG; 8: stito_conv_block1_f2reg + stito_cnn14_weights.conv1_f2reg_w_dev (appended)). */
+ * 7: STITO_CONV_WINOGRAD_F2_REG; 8: stito_conv_block1_f2reg + stito_cnn14_weights.conv1_f2reg_w_dev (appended);
+ * 9: algorithms 6 and 7 retired). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -204,17 +205,10 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * the workspace: a third fewer bytes copied into LDS per MAC, which is what bounds _F4_SPLIT.  Own packing; sums in
         * a different order than _F4_SPLIT (same accuracy, not the same bits). */
        STITO_CONV_WINOGRAD_F4_SPLIT2 = 5,
-       /* Split-precision products with the input transform INSIDE the convolution (no workspace round trip of the transformed
-        * input): for the layers below 256 output channels, whose activations are large and whose channel loops are short.
-        * A chunk of 4 input channels fills one f16 MFMA of depth 16 with hi hi' + hi lo' + lo hi'.  cin % 8 == 0,
-        * cout % 64 == 0; own packing; workspace = one word per stream. */
-       STITO_CONV_WINOGRAD_F4_SPLITK = 6,
-       /* DIRECT implicit GEMM on the f16 matrix pipe with the same split operands (f16 hi + lo, three products, f32 accumulate):
-        * 9 MACs per output at 3 / 16 of the f32 pipe's price are 1.7 f32-pipe equivalents against F(4x4,3x3)'s 2.25, with no
-        * transform, no 36-position exchange and 576 MACs per input element copied into LDS -- for the layers whose maps are
-        * large and whose channel loops are short (conv_block1 - conv_block4.conv1).  cin % 16 == 0, cout % 64 == 0, maps at
-        * least 16 wide; own packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 6). */
-       STITO_CONV_DIRECT_SPLIT = 7,
+       /* 6 (STITO_CONV_WINOGRAD_F4_SPLITK: split-precision products with the input transform inside the convolution) and
+        * 7 (STITO_CONV_DIRECT_SPLIT: direct implicit GEMM with split operands) were experiments of rounds 3 - 4 that never beat
+        * the kernels they were meant to replace; RETIRED in ABI version 9 (stito_conv3x3_supported returns 0 for them, packing
+        * and launching fail with STITO_E_UNSUPPORTED).  The numbers stay reserved. */
        /* Winograd F(2x2,3x3) on the f16 matrix pipe with the same split operands, for the 64-input-channel layers (conv_block1.conv2,
         * conv_block2.conv1): the transformed WEIGHTS (16 positions x 64 x 64 as f16 hi + lo = 256 KB) stay in the registers of
         * persistent workgroups for the whole launch, the input transform is done in registers straight into the MFMA operand
@@ -232,7 +226,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2, _F4_SPLITK, STITO_CONV_DIRECT_SPLIT or STITO_CONV_WINOGRAD_F2_REG */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2 or STITO_CONV_WINOGRAD_F2_REG */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -325,7 +319,7 @@ int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const 
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
 /* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT / _F4_SPLIT2: the transformed
- * input; _F4_SPLITK: per-stream maxima of the input, stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
+ * input; STITO_CONV_WINOGRAD_F2_REG: per-stream maxima of the input; stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
 size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                              const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,

@@ -51,8 +51,6 @@ def kind_of(kname):
         return "F(4x4,3x3), f16 hi + lo operands, two sweeps (64 x 64 tiles)"
     if "k_conv_wino43s" in kname:
         return "F(4x4,3x3), f16 hi + lo operands"
-    if "k_conv_wino43h" in kname:
-        return "F(4x4,3x3), f16 hi + lo operands, in-kernel transform"
     if "k_conv_wino43" in kname:
         return "F(4x4,3x3) f32" + (", hoisted transform" if mode_of(kname) == 1 else "")
     return "F(2x2,3x3) f32" if "wino" in kname else "direct f32"
@@ -85,7 +83,7 @@ for i, (name, _, _) in enumerate(f):
     cur.append(i)
     if "k_w23_mel_params" in name:
         continue
-    if mode_of(name) in (0, 1) or "k_conv_wino43s" in name or "k_conv_wino43h" in name or "wino43" not in name or "k_conv_wino23r" in name:
+    if mode_of(name) in (0, 1) or "k_conv_wino43s" in name or "wino43" not in name or "k_conv_wino23r" in name:
         layers.append(cur)
         cur = []
 assert not cur and len(layers) == len(shapes), (len(layers), len(shapes), [x[0][:40] for x in f])

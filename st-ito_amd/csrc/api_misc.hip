@@ -12,4 +12,4 @@ void set_error(const char *fmt, ...) {
 }  // namespace stito
 
 extern "C" const char *stito_last_error(void) { return stito::g_err; }
-extern "C" int stito_version(void) { return 8; }
+extern "C" int stito_version(void) { return 9; }

@@ -90,24 +90,13 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
 bool wino43_split_supported(const ConvShape &c, bool pool);
 size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool);
 size_t wino43_split_packed_floats(int cout, int cin);
-int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st);  // 0: k_conv_wino43s, 1: s2, 2: h
-size_t wino43_splitk_workspace_bytes(const ConvShape &c, bool pool);
-int launch_wino43_splitk(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st);  // 0: k_conv_wino43s, 1: s2
 size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool);
 double wino43_split2_issued_flops(const ConvShape &c, bool pool);
 int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                          bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
-// conv_direct_split.hip: direct implicit GEMM on the f16 matrix pipe, f32 operands as f16 hi + lo (the layers up to conv_block4.conv1)
-bool dsplit_supported(const ConvShape &c, bool pool);
-double dsplit_issued_flops(const ConvShape &c, bool pool);
-size_t dsplit_workspace_bytes(const ConvShape &c, bool pool);  // per-stream maxima of the input when the caller has none
-size_t dsplit_packed_floats(int cout, int cin);
-int pack_dsplit(const float *w_oihw, int cout, int cin, float *packed, hipStream_t st);
-int launch_dsplit(const float *in, const float *wpk, const float *scale, const float *shift, float *out, const ConvShape &c, bool pool,
-                  void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 // conv_wino23r.hip: Winograd F(2x2,3x3) on the f16 matrix pipe, weights resident in registers (the 64-input-channel layers)
 bool wino23r_supported(const ConvShape &c, bool pool);
 double wino23r_issued_flops(const ConvShape &c, bool pool);

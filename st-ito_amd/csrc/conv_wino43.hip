@@ -799,292 +799,6 @@ __global__ void k_pack_wino43(const float *__restrict__ w, int Cout, int Cin, fl
         }
 }
 
-// ---- in-kernel transform, split-precision products (the layers below 256 output channels) --------------------------------
-// k_conv_wino43 (MODE 0) with the matrix products moved to the f16 pipe as in k_conv_wino43s, for the layers where hoisting
-// the transform does not pay (their transformed input would be 2.25 x the activations, through HBM and back).  Same
-// structure: 4-channel chunks, halo patch and weight slab by LDS-DMA, every wave transforms its share of the next chunk.
-// A chunk's 4 channels fill ONE v_mfma_f32_32x32x16_f16 per block: with x = hi + lo (scaled f16 halves, w43s_vscale) the 16
-// k-slots carry  lanes 0..31: [hi c0..c3 | hi c0..c3] x [hi' | lo'],  lanes 32..63: [lo c0..c3 | 0] x [hi' | lo']
-// = hi hi' + hi lo' + lo hi' for the four channels -- 33 cycles of matrix pipe where the exact-f32 form needs 128, and on a
-// pipe that runs beside the VALU instead of in it (tools/ubench: the f32 MFMA is issued through the f32 VALU).
-//   weights  packed [cin/4][36][cout][hi' x 4 | lo' x 4] (16 B per position and channel: the B operand as it is, every lane
-//            of both halves reads its channel's 16 bytes), layer scale as in k_pack_wino43s;
-//   V        [pos][hi | lo][32 tiles][4 halfs]: the A operand is one ds_read_b64 (hi for lanes 0..31, lo for 32..63) and two
-//            v_and_b32 (the upper 8 bytes: a copy of hi resp. zero); the transform item (row i, tile, channel pair) rounds its
-//            six outputs to hi + lo (the stream's scale folded into the row coefficients: a power of two) and stores 12 x 4 bytes;
-//   the period's work (~1 300 cycles) is shorter than the HBM latency of a patch copy, so the patches are fetched two periods
-//   ahead into three buffers by alternating wave sets (see the main loop), and every LDS read is issued a stage ahead of its
-//   consumer (the first version, one period of prefetch and reads next to their consumers, sat at 2 500 cycles per period
-//   whatever was ablated).  Halo patches of tile widths 8 and 4 only (three patch buffers have to fit).
-#ifndef H43_ABL
-#define H43_ABL 0  // timing-experiment bit mask (1 no transform, 2 no products, 4 no copies); 0 in every build that ships
-#endif
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int TTW, bool POOL>
-__global__ __launch_bounds__(W43_THREADS) void k_conv_wino43h(const float *__restrict__ in, const float *__restrict__ upk,
-                                                               const float *__restrict__ scale, const float *__restrict__ shift,
-                                                               float *__restrict__ out, Wino43Geom g,
-                                                               const unsigned *__restrict__ amax, const float *__restrict__ u_inv_p) {
-    constexpr int TTH = 32 / TTW;
-    constexpr int PWC = 4 * TTW + 2;
-    using PL = W43Patch<TTW>;
-    constexpr int PFL = PL::PFL, BUF = W43_BUF;
-    constexpr int NP2 = (PL::SLOTS + 255) / 256;  // patch copies per wave of the issuing set (4 waves cover all slots)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int set = wv >> 2, w4 = wv & 3, t256 = tid & 255;  // waves w and w + 4 share a SIMD: one of each set per SIMD
-    int ct_;
-    const int m_blk = fdiv((int)blockIdx.x, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    const int n0 = ct_ * 64;
-    int cb;
-    const int rb = fdiv(m_blk, g.fNCB, cb);
-    const int vtr0 = rb * TTH, tc0 = cb * TTW;
-    const int n_chunks = g.Cin / W43_K;
-    float *patch0 = smem + 2 * BUF;  // three patch buffers
-    int tr0_;
-    const int s0_ = fdiv(vtr0, g.fTR, tr0_);
-    const int iv_lo = s0_ * g.H + 4 * tr0_ - 1;
-
-    const int half = lane >> 5, l31 = lane & 31;
-    const int nh = wv & 1, pg = wv >> 1;
-    const char *a_rd = (const char *)smem + W43_U * 4 + (9 * pg) * 512 + half * 256 + l31 * 8;
-    const char *b_rd = (const char *)smem + (9 * pg) * 1024 + (nh * 32 + l31) * 16;
-    const unsigned a_mask = half ? 0u : 0xffffffffu;
-
-    int roff[4];
-    f32x2 cab, ccd;
-    int vdst;
-    const float *u_base = upk + (int64_t)n0 * 4;
-    const int64_t u_pos_stride = (int64_t)g.Cout * W43_K, u_chunk_stride = 36 * u_pos_stride;  // floats
-    const unsigned u_voff = (unsigned)lane * 16u;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
-
-    int h_first;
-    const int s_first = fdiv(iv_lo < 0 ? 0 : iv_lo, g.fH, h_first);
-    const int64_t plane8 = (int64_t)g.H * g.W * 8;
-    const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W);
-    unsigned p_off[NP2];
-    uint64_t p_mask[NP2];
-    unsigned p_own = 0;  // bit j: slot t256 + 256 j exists and is never loaded (= padding: zeroed once)
-#pragma unroll
-    for (int j = 0; j < NP2; ++j) {
-        const int q = t256 + 256 * j;
-        const int plane = q / PL::PLANE, pos = q % PL::PLANE;
-        const int pr4 = PL::ROWMAJOR ? pos / PL::CW : pos % PL::RH, pc4 = PL::ROWMAJOR ? pos % PL::CW : pos / PL::RH;
-        const int pr = 4 * pr4 + (plane >> 2), pc = 4 * pc4 + (plane & 3);
-        const int iv = iv_lo + pr;
-        const int w = 4 * tc0 - 1 + pc;
-        const bool ok = q < PL::SLOTS && pr < g.PR && pc < PWC && iv >= 0 && iv < g.S * g.H && w >= 0 && w < g.W;
-        int hq_;
-        const int sq_ = fdiv(ok ? iv : 0, g.fH, hq_);
-        const int s_ = ok ? sq_ : s_first, h_ = ok ? hq_ : 0, w_ = ok ? w : 0;
-        p_off[j] = (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
-        p_mask[j] = __builtin_amdgcn_ballot_w64(ok);
-        if (q < PL::SLOTS && !ok) p_own |= 1u << j;
-    }
-    const unsigned lds_patch = lds0 + (unsigned)(2 * BUF) * 4u;
-
-// U slab of chunk CH -> buffer BOFF, piece II (one position: 64 channels x 16 B = 1 KB)
-#define H43_COPY_U(CH, BOFF, II)                                                                         \
-    glds16_m0(u_base + (int64_t)(CH) * u_chunk_stride + (II) * u_pos_stride, u_voff, lds0 + (unsigned)((BOFF) + (II) * 64 * W43_K) * 4u);
-// patch(CH) -> patch buffer PB (0..2): NP2 masked LDS-DMA instructions per wave of the issuing set (pixels w4 * 64 + 256 j + lane)
-#define H43_COPY_P2(CH, PB)                                                                              \
-    {                                                                                                    \
-        const int cc_ = (CH);                                                                            \
-        const float *pb_ = p_base + (int64_t)(cc_ >> 1) * plane8 + (cc_ & 1) * 4;                        \
-        _Pragma("unroll") for (int j = 0; j < NP2; ++j) {                                                \
-            uint64_t keep_;                                                                              \
-            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"  \
-                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                          \
-                         : "=&s"(keep_)                                                                  \
-                         : "v"(p_off[j]), "s"(pb_), "s"(lds_patch + (unsigned)((PB) * PFL + (w4 * 64 + 256 * j) * W43_K) * 4u), \
-                           "s"(p_mask[j])                                                                \
-                         : "memory");                                                                    \
-        }                                                                                                \
-    }
-// one output pair of the transform -> scaled f16 halves hi + lo at position column J of the item's row
-#define H43_PUT(J, VAL)                                                                                  \
-    {                                                                                                    \
-        const f32x2 v_ = (VAL);                                                                          \
-        const h2 hi_ = __builtin_convertvector(v_, h2);                                                  \
-        const h2 lo_ = __builtin_convertvector(v_ - __builtin_convertvector(hi_, f32x2), h2);            \
-        *(h2 *)(vb_ + (J) * 512) = hi_;                                                                  \
-        *(h2 *)(vb_ + (J) * 512 + 256) = lo_;                                                            \
-    }
-#define H43_COLS(VBOFF)                                                                                  \
-    {                                                                                                    \
-        char *vb_ = (char *)(smem + (VBOFF)) + vdst;                                                     \
-        const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, cm4 = {-4.f, -4.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f}; \
-        H43_PUT(0, pk_fma(c4, tT[0], pk_fma(cm5, tT[2], tT[4])))                                         \
-        const f32x2 p_ = pk_fma(cm4, tT[2], tT[4]), q_ = pk_fma(cm4, tT[1], tT[3]);                      \
-        H43_PUT(1, pk_add(p_, q_))                                                                       \
-        H43_PUT(2, pk_sub(p_, q_))                                                                       \
-        const f32x2 s_ = pk_sub(tT[4], tT[2]), u_ = pk_sub(tT[3], tT[1]);                                \
-        H43_PUT(3, pk_fma(c2, u_, s_))                                                                   \
-        H43_PUT(4, pk_fma(cm2, u_, s_))                                                                  \
-        H43_PUT(5, pk_fma(c4, tT[1], pk_fma(cm5, tT[3], tT[5])))                                         \
-    }
-// operands of block group G (blocks 3 G .. 3 G + 2): A = 8 bytes of V (hi for lanes 0..31, lo for 32..63), B = 16 bytes of U
-#define H43_OPS_RD(CUR, G)                                                                               \
-    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                                   \
-        ax[t_] = *(const u32x2 *)(a_rd + (CUR) * 4 + (3 * (G) + t_) * 512);                              \
-        bx[t_] = *(const u32x4 *)(b_rd + (CUR) * 4 + (3 * (G) + t_) * 1024);                             \
-    }
-#define H43_MFMA(G)                                                                                      \
-    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                                   \
-        const u32x4 a4_ = {ax[t_][0], ax[t_][1], ax[t_][0] & a_mask, ax[t_][1] & a_mask};                \
-        acc[3 * (G) + t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a4_), __builtin_bit_cast(h8, bx[t_]), acc[3 * (G) + t_], 0, 0, 0); \
-    }
-#define H43_FENCE() __builtin_amdgcn_sched_barrier(0);
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
-    f32x2 tT[6], rA[3][4];
-    u32x2 ax[3];
-    u32x4 bx[3];
-
-    // ---- prologue: patch(0), patch(2) (set 0) / patch(1) (set 1) and U(0) by LDS-DMA; zero fill of the padding slots of all
-    // three patch buffers; transform item geometry; V(0)
-    if (set == 0) {
-        H43_COPY_P2(0, 0)
-        if (n_chunks > 2) H43_COPY_P2(2, 2)
-    } else {
-        H43_COPY_P2(1, 1)
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int ii = wv + 8 * j < 36 ? wv + 8 * j : wv + 8 * j - 8;
-        H43_COPY_U(0, 0, ii)
-    }
-#pragma unroll
-    for (int j = 0; j < NP2; ++j)
-        if ((p_own >> j) & 1) {
-            const int q = t256 + 256 * j;
-            *(f32x4 *)(patch0 + q * W43_K) = (f32x4)(0.0f);
-            *(f32x4 *)(patch0 + PFL + q * W43_K) = (f32x4)(0.0f);
-            *(f32x4 *)(patch0 + 2 * PFL + q * W43_K) = (f32x4)(0.0f);
-        }
-    {
-        int ti, tile, cp;
-        if (lane < 32) {
-            ti = wv >> 1; tile = (wv & 1) * 16 + (lane & 15); cp = lane >> 4;
-        } else {
-            const int u = 8 + (wv >> 1), l = lane & 15;
-            ti = u >> 1; tile = (u & 1) * 16 + (wv & 1) * 8 + (l & 7); cp = l >> 3;
-        }
-        int kr[4];
-        float cf[4];
-        switch (ti) {
-            case 0: kr[0] = 0; kr[1] = 2; kr[2] = 4; kr[3] = 4; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
-            case 1: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -4.f; cf[1] = -4.f; cf[2] = 1.f; cf[3] = 1.f; break;
-            case 2: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 4.f; cf[1] = -4.f; cf[2] = -1.f; cf[3] = 1.f; break;
-            case 3: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = -2.f; cf[1] = -1.f; cf[2] = 2.f; cf[3] = 1.f; break;
-            case 4: kr[0] = 1; kr[1] = 2; kr[2] = 3; kr[3] = 4; cf[0] = 2.f; cf[1] = -1.f; cf[2] = -2.f; cf[3] = 1.f; break;
-            default: kr[0] = 1; kr[1] = 3; kr[2] = 5; kr[3] = 5; cf[0] = 4.f; cf[1] = -5.f; cf[2] = 1.f; cf[3] = 0.f; break;
-        }
-        const int vtr = vtr0 + tile / TTW, tcl = tile % TTW;
-        int tr;
-        const int s_ = fdiv(vtr, g.fTR, tr);
-        const int pc0 = s_ * g.H + 4 * tr - 1 - iv_lo;
-        // the stream's power-of-two scale rides on the row coefficients (exact)
-        const float vs = w43s_vscale(amax[vtr < g.VTR ? s_ : g.S - 1]);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int hh = 4 * tr - 1 + kr[x];
-            const bool ok = vtr < g.VTR && hh >= 0 && hh < g.H;
-            cf[x] = ok ? cf[x] * vs : 0.f;
-            const int prow = ok ? pc0 + kr[x] : 0;
-            roff[x] = PL::slot(prow, 4 * tcl) * W43_K + cp * 2;
-        }
-        cab = (f32x2){cf[0], cf[1]};
-        ccd = (f32x2){cf[2], cf[3]};
-        vdst = W43_U * 4 + (ti * 6) * 512 + tile * 8 + cp * 4;  // bytes: V[6 ti + j][hi | lo][tile][2 cp .. 2 cp + 1]
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    W43_BARRIER()
-    W43_T_RD(patch0, 0, rA[0]) W43_T_RD(patch0, 1, rA[1]) W43_T_RD(patch0, 2, rA[2])
-    W43_T_ROW(0, rA[0]) W43_T_ROW(1, rA[1]) W43_T_ROW(2, rA[2])
-    W43_T_RD(patch0, 3, rA[0]) W43_T_RD(patch0, 4, rA[1]) W43_T_RD(patch0, 5, rA[2])
-    W43_T_ROW(3, rA[0]) W43_T_ROW(4, rA[1]) W43_T_ROW(5, rA[2])
-    H43_COLS(0)
-    W43_BARRIER()  // V(0), U(0) complete
-
-    // ---- main loop: period k multiplies chunk k, transforms patch(k + 1) into V(k + 1), copies U(k + 1) and patch(k + 3).
-    // The sets alternate roles: set k % 2 issues the patch copies (HBM latency: they get two periods, nobody waits for them
-    // before barrier(k + 1)); the other set issues the U copies (L2 hits) and waits vmcnt(0) at the end of the period, which
-    // also covers the patch copies it issued in period k - 1.  Inside the period every LDS read is issued one stage ahead of
-    // its consumer: three transform columns and three blocks' operands are in flight at a time.
-    int r1 = 1, r3 = 0;  // (k + 1) % 3, (k + 3) % 3
-    for (int k = 0; k < n_chunks; ++k) {
-        const int cur = (k & 1) * BUF, nxt = BUF - cur;
-        const bool more = k + 1 < n_chunks;
-        const bool p_role = (k & 1) == set;
-        const float *pb_r = patch0 + r1 * PFL;
-        if (!(H43_ABL & 4)) {
-            if (p_role) {
-                if (k + 3 < n_chunks) H43_COPY_P2(k + 3, r3)
-            } else if (more) {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) H43_COPY_U(k + 1, nxt, w4 + 4 * j)
-            }
-        }
-        H43_FENCE()
-        if (more && !(H43_ABL & 1)) { W43_T_RD(pb_r, 0, rA[0]) W43_T_RD(pb_r, 1, rA[1]) W43_T_RD(pb_r, 2, rA[2]) }
-        if (!(H43_ABL & 2)) H43_OPS_RD(cur, 0)
-        H43_FENCE()
-        if (more && !(H43_ABL & 1)) {
-            W43_T_ROW(0, rA[0]) W43_T_ROW(1, rA[1]) W43_T_ROW(2, rA[2])
-            W43_T_RD(pb_r, 3, rA[0]) W43_T_RD(pb_r, 4, rA[1]) W43_T_RD(pb_r, 5, rA[2])
-        }
-        H43_FENCE()
-        if (!(H43_ABL & 2)) { H43_MFMA(0) H43_OPS_RD(cur, 1) }
-        H43_FENCE()
-        if (more && !(H43_ABL & 1)) { W43_T_ROW(3, rA[0]) W43_T_ROW(4, rA[1]) W43_T_ROW(5, rA[2]) }
-        H43_FENCE()
-        if (!(H43_ABL & 2)) { H43_MFMA(1) H43_OPS_RD(cur, 2) }
-        H43_FENCE()
-        if (more && !(H43_ABL & 1)) H43_COLS(nxt)
-        H43_FENCE()
-        if (!(H43_ABL & 2)) H43_MFMA(2)
-        if (!p_role) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W43_BARRIER()
-        r1 = r1 == 2 ? 0 : r1 + 1;
-        r3 = r3 == 2 ? 0 : r3 + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
-}
-
-// weights of k_conv_wino43h: [cin/4][36][cout][hi x 4 | lo x 4], scaled as k_pack_wino43s (hdr behind the data)
-__global__ void k_pack_wino43h(const float *__restrict__ w, int Cout, int Cin, char *__restrict__ o, const unsigned *__restrict__ hdr) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Cout * Cin) return;
-    const int ci = (int)(i % Cin), co = (int)(i / Cin);
-    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-    double gk[3][3], t[6][3];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) gk[a][b] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + b];
-    for (int a = 0; a < 6; ++a)
-        for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * gk[0][b] + G[a][1] * gk[1][b] + G[a][2] * gk[2][b];
-    const float su = __uint_as_float(hdr[2]);
-    const int chunk = ci / W43_K, c4 = ci % W43_K;
-    for (int a = 0; a < 6; ++a)
-        for (int b = 0; b < 6; ++b) {
-            const float us = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]) * su;
-            const _Float16 hi = (_Float16)us, lo = (_Float16)(us - (float)hi);
-            char *d = o + (((int64_t)chunk * 36 + a * 6 + b) * Cout + co) * 16 + c4 * 2;
-            *(_Float16 *)d = hi;
-            *(_Float16 *)(d + 8) = lo;
-        }
-}
-
 #ifndef S43B_ABL
 #define S43B_ABL 0  // timing experiment (k_conv_wino43s / s2): 1 = no main loop (prologue + epilogue(s) only), 2 = no slab copies in the loop, 4 = no operand reads / MFMAs; 0 in every build that ships
 #endif
@@ -1532,7 +1246,7 @@ __global__ void k_pack_wino43s_scale(unsigned *hdr) {
 size_t wino43_split_packed_floats(int cout, int cin) { return (size_t)36 * cout * cin + 64; }
 
 int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st) {
-    STITO_REQUIRE((layout == 2 ? cin % 8 == 0 : cin % 64 == 0) && cout % 64 == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
+    STITO_REQUIRE(cin % 64 == 0 && cout % 64 == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
     const int64_t n = (int64_t)cout * cin;
     unsigned *hdr = (unsigned *)(packed + (size_t)36 * cout * cin);
     STITO_HIP_CHECK(hipMemsetAsync(hdr, 0, 64 * sizeof(float), st));
@@ -1540,8 +1254,7 @@ int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int
     STITO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_wino43s_scale, dim3(1), dim3(1), 0, st, hdr);
     STITO_LAUNCH_CHECK();
-    if (layout == 2) hipLaunchKernelGGL(k_pack_wino43h, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
-    else if (layout == 1) hipLaunchKernelGGL(k_pack_wino43s2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
+    if (layout == 1) hipLaunchKernelGGL(k_pack_wino43s2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
     else hipLaunchKernelGGL(k_pack_wino43s<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
@@ -1878,58 +1591,6 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     STITO_LAUNCH_CHECK();
     W43_CLK_REPORT("k_conv_wino43s (f16 MFMA)", c, st)
     return STITO_OK;
-}
-
-// In-kernel transform on the f16 pipe (k_conv_wino43h).  Workspace: one unsigned per stream, used when the producer of `in` did
-// not report its per-stream maxima.
-size_t wino43_splitk_workspace_bytes(const ConvShape &c, bool pool) {
-    if (!wino43_supported(c, pool) || ((int64_t)c.Cin * c.H * c.W) % 8 != 0) return 0;
-    if (w43_ttw(c, pool) < 4) return 0;  // three patch buffers of the narrow-tile layouts do not fit next to the operand buffers
-    return align_up((size_t)c.S * sizeof(unsigned), 256);
-}
-
-template <int TTW, bool POOL>
-static int launch_w43_splitk(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                             char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
-    Wino43Geom g;
-    size_t lds;
-    int64_t blocks;
-    STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
-                  "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
-    const unsigned *amax = amax_in;
-    if (amax_in == nullptr) {
-        unsigned *amax_ws = (unsigned *)ws;
-        amax = amax_ws;
-        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
-        const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
-        int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
-        const int cap = (4096 + c.S - 1) / c.S;
-        splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
-        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax_ws);
-        STITO_LAUNCH_CHECK();
-    }
-    g.amax_out = amax_out;
-    auto kern = k_conv_wino43h<TTW, POOL>;
-    lds = ((size_t)2 * W43_BUF + 3 * W43Patch<TTW>::PFL) * sizeof(float);  // two operand buffers, three patch buffers
-    STITO_REQUIRE(lds <= 160 * 1024, STITO_E_UNSUPPORTED, "conv (split-precision winograd, in-kernel transform): tile width %d", TTW);
-    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g, amax, u_inv);
-    STITO_LAUNCH_CHECK();
-    return STITO_OK;
-}
-
-int launch_wino43_splitk(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
-                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
-    const size_t need = wino43_splitk_workspace_bytes(c, pool);
-    STITO_REQUIRE(need > 0 && (amax_in != nullptr || (ws != nullptr && ws_bytes >= need)), STITO_E_WORKSPACE,
-                  "conv (split-precision winograd F(4x4,3x3), in-kernel transform): workspace have %zu need %zu", ws_bytes, need);
-    char *w = (char *)ws;
-    switch (w43_ttw(c, pool)) {
-        case 8: return pool ? launch_w43_splitk<8, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_splitk<8, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
-        case 4: return pool ? launch_w43_splitk<4, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_splitk<4, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
-        default: set_error("conv (split-precision winograd, in-kernel transform): maps narrower than 4 tiles are not covered"); return STITO_E_UNSUPPORTED;
-    }
 }
 
 // Two-sweep variant: workspace = V slabs of the pixel-block pairs | stream maxima | per-workgroup partial outputs (256 KB each).

@@ -17,8 +17,8 @@ LIB_PATH = os.environ.get("STITO_LIB_PATH") or os.path.join(_HERE, "_lib", "libs
 FX_PARAMETRIC_EQ, FX_COMPRESSOR, FX_DISTORTION, FX_DELAY, FX_REVERB, FX_GAIN, FX_NOISE_REVERB, FX_CHORUS = range(8)
 NORM_NONE, NORM_MINMAX, NORM_BATCHNORM = range(3)
 FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
-CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE, CONV_WINOGRAD_F4_SPLIT, CONV_WINOGRAD_F4_SPLIT2, CONV_WINOGRAD_F4_SPLITK = 0, 1, 2, 3, 4, 5, 6
-CONV_DIRECT_SPLIT = 7
+CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE, CONV_WINOGRAD_F4_SPLIT, CONV_WINOGRAD_F4_SPLIT2 = 0, 1, 2, 3, 4, 5
+# 6, 7: retired in ABI version 9 (split-precision experiments that never beat the kernels they were meant to replace)
 CONV_WINOGRAD_F2_REG = 8
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4

@@ -133,15 +133,6 @@ class Cnn14(nn.Module):
         # epilogue (two sweeps, the first one's outputs parked in HBM) is repaid by a third fewer bytes per MAC only when the
         # channel loop is long (measured at 512 streams: 512 -> 512 4.45 -> 4.20 ms, 2048 -> 2048 4.05 -> 3.05; 256 -> 512 2.51 -> 2.66)
         self.conv_split2_min_cin = int(os.environ.get("STITO_CONV_SPLIT2_MIN_CIN", "512"))
-        # experimental, off by default (0): the layers BELOW conv_split_min_cout on the f16 pipe with the transform in the
-        # kernel (CONV_WINOGRAD_F4_SPLITK) up to this many output channels.  Correct (parity-tested) but slower than the f32
-        # kernel today: with the matrix pipe out of the way its period (~1 300 cycles of work) is shorter than the HBM latency
-        # of the halo-patch copies, which the one-period prefetch of the f32 schedule no longer hides
-        self.conv_splitk_max_cout = int(os.environ.get("STITO_CONV_SPLITK_MAX_COUT", "0"))
-        # layers with at most this many INPUT channels (and cin % 16 == 0) run the DIRECT form on the f16 pipe with the same split
-        # operands (CONV_DIRECT_SPLIT): 9 MACs per output at 3 / 16 of the f32 pipe's price, no transform, no exchange epilogue,
-        # 576 MACs per input element copied into LDS -- the large maps with short channel loops (0 = never)
-        self.conv_dsplit_max_cin = int(os.environ.get("STITO_CONV_DSPLIT_MAX_CIN", "0"))
         # the 64-input-channel layers (conv_block1.conv2, conv_block2.conv1) by Winograd F(2x2,3x3) on the f16 pipe with the
         # transformed weights resident in registers and the input transform done in registers (CONV_WINOGRAD_F2_REG), unless
         # STITO_CONV_F2REG=0
@@ -198,12 +189,8 @@ class Cnn14(nn.Module):
                     algo = _hip.CONV_WINOGRAD_F4_SPLIT if split else (_hip.CONV_WINOGRAD_F4_PRE if pre else self.conv_algo)
                     if split and 0 < self.conv_split2_min_cin <= cin:
                         algo = _hip.CONV_WINOGRAD_F4_SPLIT2
-                    if not split and not pre and self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cout <= self.conv_splitk_max_cout:
-                        algo = _hip.CONV_WINOGRAD_F4_SPLITK
                     if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and self.conv_f2reg and cin == 64 and cout % 64 == 0:
                         algo = _hip.CONV_WINOGRAD_F2_REG
-                    if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and cin % 16 == 0 and cin <= self.conv_dsplit_max_cin:
-                        algo = _hip.CONV_DIRECT_SPLIT   # opt-in experiment: wins over the defaults
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)
                     _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(upk), st))
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()

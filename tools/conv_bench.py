@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames", type=int, default=469)
-    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 5 = 4 on 64 x 64 tiles in two sweeps, 6 = split operands with the transform in the kernel, 7 = direct implicit GEMM with split operands (maps at least 16 wide; production mix elsewhere), 8 = F(2x2,3x3) with register-resident weights (64 input channels; production mix elsewhere), 9 = production mix (cout >= 256: 5 from cin 512 up, else 4; below: 2)")
+    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 5 = 4 on 64 x 64 tiles in two sweeps, 8 = F(2x2,3x3) with register-resident weights (64 input channels; production mix elsewhere), 9 = production mix (cout >= 256: 5 from cin 512 up, else 4; below: 2)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--max-cin", type=int, default=1 << 30, help="only the layers with at most this many input channels")
     a = ap.parse_args()
@@ -33,10 +33,7 @@ def main():
             m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2
         if m == 8 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 8):
             m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2  # register-resident F(2x2,3x3): 64 input channels only
-        if m == 7 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 7):
-            m = 9  # the direct split-precision kernel does not tile maps narrower than 16: production mix there
-            m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2
-        if m in (4, 5, 6) and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m):
+        if m in (4, 5) and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m):
             m = 3
         if m == 3 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 3):
             return 2  # the hoisted transform needs cout % 256 == 0
