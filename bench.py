@@ -143,13 +143,11 @@ def conv_layer_times(model, n_streams, T, reps=3):
     layers = []
     cur = x
     order = []
-    fused = bool(W.conv1_fused_w_dev) and bool(W.conv_wino_dev[1]) and W.conv_wino_algo[1] == 2 and \
-        L.stito_conv_block1_fused_supported(n_streams, rows[0]["H"], rows[0]["W"], rows[0]["cout"], rows[1]["cout"], 1)
-    fusedr = (not fused) and bool(W.conv1_f2reg_w_dev) and bool(W.conv_wino_dev[1]) and W.conv_wino_algo[1] == 8 and \
+    fusedr = bool(W.conv1_f2reg_w_dev) and bool(W.conv_wino_dev[1]) and W.conv_wino_algo[1] == 8 and \
         L.stito_conv_block1_f2reg_supported(n_streams, rows[0]["H"], rows[0]["W"], rows[0]["cout"], rows[1]["cout"], 1)
     for i, r in enumerate(rows):
         Ho, Wo = (r["H"] // 2, r["W"] // 2) if r["pool"] else (r["H"], r["W"])
-        if (fused or fusedr) and i == 0:
+        if fusedr and i == 0:
             continue  # conv_block1 is one launch: reported with its second conv
         out = torch.empty((n_streams, r["cout"] // 8, Ho, Wo, 8), device=dev)
         if fusedr and i == 1:
@@ -172,25 +170,6 @@ def conv_layer_times(model, n_streams, T, reps=3):
             layers.append(dict(layer="conv_block1 (one launch: conv1 computed on the matrix pipe into conv2's patch ring)", algo=ALGO_NAMES[8],
                                H=r["H"], W=r["W"], cin=1, cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2), pipe="f16-reg",
                                mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / PIPE_PEAK["f16-reg"], 4)))
-            cur = out
-            continue
-        if fused and i == 1:
-            args = (_hip.ptr(x), W.conv1_fused_w_dev, W.bn_shift_dev[0], W.conv_wino_dev[1], W.bn_scale_dev[1], W.bn_shift_dev[1],
-                    _hip.ptr(out), n_streams, r["H"], r["W"], r["cin"], r["cout"], 1, st)
-            _hip.check(L.stito_conv_block1_fused(*args))
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a, b in ev:
-                a.record()
-                _hip.check(L.stito_conv_block1_fused(*args))
-                b.record()
-            torch.cuda.synchronize()
-            ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-            fl = (r["flops"] + rows[0]["flops"]) * n_streams
-            issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 2)
-            order.append(("f32", issued, 0.0))
-            layers.append(dict(layer="conv_block1 (conv1 fused into conv2's patch staging)", algo=ALGO_NAMES[2], H=r["H"], W=r["W"], cin=1,
-                               cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2),
-                               mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)))
             cur = out
             continue
         walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3, 4, 5, 8) else 1

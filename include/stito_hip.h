@@ -84,7 +84,7 @@ const char *stito_last_error(void);
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
  * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT;
  * 7: STITO_CONV_WINOGRAD_F2_REG; 8: stito_conv_block1_f2reg + stito_cnn14_weights.conv1_f2reg_w_dev (appended);
- * 9: algorithms 6 and 7 retired). */
+ * 9: algorithms 6 and 7 and stito_conv_block1_fused / stito_cnn14_pack_conv1_fused retired). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -233,8 +233,7 @@ typedef struct {
     const float *fc_mid_b_dev;   /* (embed_dim) */
     const float *fc_side_wt_dev; /* (2048, embed_dim) */
     const float *fc_side_b_dev;  /* (embed_dim) */
-    const float *conv1_fused_w_dev; /* stito_cnn14_pack_conv1_fused, or NULL.  With it and an F(4x4,3x3) packing of conv index 1
-                                       the forward runs conv_block1 as ONE launch (stito_conv_block1_fused) */
+    const float *reserved_ptr;      /* was conv1_fused_w_dev (ABI 3 - 8: the F(4x4,3x3)-based fused block, retired in ABI 9); ignored */
     const float *conv1_f2reg_w_dev; /* stito_cnn14_pack_conv1_f2reg, or NULL (ABI v8).  With it and a
                                        STITO_CONV_WINOGRAD_F2_REG packing of conv index 1 the forward runs conv_block1 as ONE
                                        launch (stito_conv_block1_f2reg): the 64-channel full-resolution map is never stored */
@@ -267,19 +266,10 @@ int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, i
  * the 1-channel input of the first conv is (n, H, W).
  * in (n, cin/8, H, W, 8) -> out (n, cout/8, H', W', 8), y = relu(conv3x3(x) * scale + shift),
  * pool != 0: 2x2 average pooling (floor). */
-/* conv_block1 fused (panns.py:250, ConvBlock 65-80): y = pool?(relu(bn2(conv3x3(relu(bn1(conv3x3(x))))))) for a 1-channel
- * input x (n, H, W) -- the log-mel image -- in one launch: the first conv (c1 channels) is evaluated per 4-channel chunk
- * while the Winograd F(4x4,3x3) kernel stages its input patch, so the c1-channel full-resolution map never goes to HBM.
- *   fused_w1_dev  stito_cnn14_pack_conv1_fused(w1 (c1,1,3,3), bn1 scale): [c1/4][9][4], scale folded;  shift1_dev (c1)
- *   packed_w2_dev STITO_CONV_WINOGRAD_F4 packing of w2 (cout, c1, 3, 3);  scale2_dev / shift2_dev (cout)
- *   out_dev       (n, cout/8, H', W', 8).   Needs c1 % 8 == 0, cout % 64 == 0, W >= 32 (pooled) / W >= 29 (not pooled). */
-int stito_cnn14_pack_conv1_fused(const float *w_oihw_dev, const float *scale_dev, int c1, float *packed_dev, void *stream);
-int stito_conv_block1_fused_supported(int n, int H, int W, int c1, int cout, int pool);
-int stito_conv_block1_fused(const float *x_dev, const float *fused_w1_dev, const float *shift1_dev, const float *packed_w2_dev,
-                            const float *scale2_dev, const float *shift2_dev, float *out_dev, int n, int H, int W, int c1,
-                            int cout, int pool, void *stream);
-/* conv_block1 in one launch on the register-resident F(2x2,3x3) kernel (STITO_CONV_WINOGRAD_F2_REG; ABI v8): same function
- * as stito_conv_block1_fused.  The first conv (c1 = 64 channels, bn1, ReLU) is evaluated on the f16 matrix pipe (4 x 4 window
+/* conv_block1 in one launch (panns.py:250, ConvBlock 65-80): y = pool?(relu(bn2(conv3x3(relu(bn1(conv3x3(x))))))) for a
+ * 1-channel input x (n, H, W) -- the log-mel image -- on the register-resident F(2x2,3x3) kernel (STITO_CONV_WINOGRAD_F2_REG;
+ * ABI v8; the F(4x4,3x3)-based stito_conv_block1_fused of ABI 3 - 8, 11.4 ms against this one's 5.4, was retired in ABI 9).
+ * out_dev (n, cout/8, H', W', 8).  The first conv (c1 = 64 channels, bn1, ReLU) is evaluated on the f16 matrix pipe (4 x 4 window
  * x 32 channels x 32 pixels per product; operands split into f16 hi + lo like the second conv's, three products, f32
  * accumulate) straight into the LDS patch ring of the second conv, in the instruction slots where the unfused kernel issues
  * its patch copies.

@@ -41,7 +41,7 @@ def mode_of(kname):
     if not m:
         return 0
     args = [a.strip() for a in m.group(1).split(",")]
-    return int(args[4]) if len(args) > 4 else 0
+    return int(args[-1]) if len(args) >= 4 else 0   # <TTW, POOL, TRACE, MODE> (five arguments before round 4's clean-up: MODE last too)
 
 
 def kind_of(kname):

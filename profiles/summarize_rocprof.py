@@ -22,7 +22,7 @@ for path in sys.argv[1:]:
     n_tr, t_tr = 0, 0.0
     for name, dur in cur.execute("select name, end-start from kernels where name like '%k_conv_wino%' or name like '%k_conv3x3%'"):
         m = re.search(r"k_conv_wino43<([^>]*)>", name)
-        mode = int(m.group(1).split(",")[4]) if m and len(m.group(1).split(",")) > 4 else 0
+        mode = int(m.group(1).split(",")[-1]) if m and len(m.group(1).split(",")) >= 4 else 0
         if mode in (2, 3, 4):
             if 8e4 < dur:
                 n_tr += 1; t_tr += dur / 1e6

@@ -1080,25 +1080,6 @@ extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin,
     return STITO_OK;
 }
 
-extern "C" int stito_cnn14_pack_conv1_fused(const float *w_oihw_dev, const float *scale_dev, int c1, float *packed_dev, void *stream) {
-    STITO_REQUIRE(c1 > 0 && c1 % 8 == 0, STITO_E_UNSUPPORTED, "fused first conv: %d channels", c1);
-    return pack_fuse1(w_oihw_dev, scale_dev, c1, packed_dev, (hipStream_t)stream);
-}
-
-extern "C" int stito_conv_block1_fused_supported(int n, int H, int W, int c1, int cout, int pool) {
-    if (n <= 0 || H <= 0 || W <= 0) return 0;
-    return wino43_fused_supported(ConvShape{n, H, W, c1, cout}, pool != 0) ? 1 : 0;
-}
-
-extern "C" int stito_conv_block1_fused(const float *x_dev, const float *fused_w1_dev, const float *shift1_dev,
-                                       const float *packed_w2_dev, const float *scale2_dev, const float *shift2_dev, float *out_dev,
-                                       int n, int H, int W, int c1, int cout, int pool, void *stream) {
-    STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
-    STITO_REQUIRE(c1 % 8 == 0 && cout % 64 == 0, STITO_E_UNSUPPORTED, "fused conv block: %d -> %d channels", c1, cout);
-    return launch_wino43_fused(x_dev, fused_w1_dev, shift1_dev, packed_w2_dev, scale2_dev, shift2_dev, out_dev,
-                               ConvShape{n, H, W, c1, cout}, pool != 0, (hipStream_t)stream);
-}
-
 extern "C" size_t stito_cnn14_packed_conv1_f2reg_floats(void) { return conv1_f2reg_packed_floats(); }
 
 extern "C" int stito_cnn14_pack_conv1_f2reg(const float *w_oihw_dev, const float *scale_dev, const float *shift_dev, int c1,
@@ -1390,12 +1371,8 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     const unsigned *amax_have = nullptr;  // maxima of the current input, if its producer reported them
 
     const float *cur = logmel_dev;
-    // conv_block1 as one launch when the fused first-conv weights and an F(4x4,3x3) packing of its second conv are there
-    const bool fuse1 = w->conv1_fused_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
-                       w->conv_wino_algo[1] == STITO_CONV_WINOGRAD_F4 && w->channels[0] == 1 &&
-                       stito_conv_block1_fused_supported(S, H[0], W[0], w->channels[1], w->channels[1], 1);
-    // ... or on the register-resident F(2x2,3x3) kernel, which computes the first conv into its patch ring
-    const bool fuse1r = !fuse1 && w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
+    // conv_block1 as one launch on the register-resident F(2x2,3x3) kernel, which computes the first conv into its patch ring
+    const bool fuse1r = w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
                         w->conv_wino_algo[1] == STITO_CONV_WINOGRAD_F2_REG && w->channels[0] == 1 &&
                         stito_conv_block1_f2reg_supported(S, H[0], W[0], w->channels[1], w->channels[1], 1) &&
                         vbytes >= stito_conv_block1_f2reg_workspace_bytes(S, H[0], W[0], w->channels[1], w->channels[1], 1);
@@ -1426,24 +1403,6 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                                                    S, H[0], W[0], cout, cout, 1, vbuf, vbytes, stream, amax_out);
             if (rc) return rc;
             amax_have = amax_out;
-            if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
-            cur = actB;
-            continue;
-        }
-        if (blk == 0 && fuse1) {
-            const bool timed = g_conv_timing.on;
-            if (timed) {
-                if (g_conv_timing.used == g_conv_timing.pool.size()) {
-                    hipEvent_t e0, e1;
-                    STITO_HIP_CHECK(hipEventCreate(&e0));
-                    STITO_HIP_CHECK(hipEventCreate(&e1));
-                    g_conv_timing.pool.emplace_back(e0, e1);
-                }
-                STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
-            }
-            const int rc = stito_conv_block1_fused(cur, w->conv1_fused_w_dev, w->bn_shift_dev[0], w->conv_wino_dev[1], w->bn_scale_dev[1],
-                                                   w->bn_shift_dev[1], actB, S, H[0], W[0], cout, cout, 1, stream);
-            if (rc) return rc;
             if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
             cur = actB;
             continue;

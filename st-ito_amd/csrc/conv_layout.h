@@ -113,9 +113,5 @@ size_t conv1_f2reg_packed_floats();
 int pack_conv1_f2reg(const float *w_dev, const float *scale_dev, const float *shift_dev, int c1, float *packed, hipStream_t st);
 int launch_wino23r_fused1(const float *logmel, const float *c1pk, const float *wpk, const float *scale, const float *shift, float *out,
                           const ConvShape &c, bool pool, void *ws, size_t ws_bytes, hipStream_t st, unsigned *amax_out);
-bool wino43_fused_supported(const ConvShape &c, bool pool);   // c.Cin = channels of the (fused) first conv
-int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st);
-int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,
-                        const float *shift, float *out, const ConvShape &c, bool pool, hipStream_t st);
 
 }  // namespace stito

@@ -100,11 +100,7 @@ struct Wino43Geom {
     long long *clk;    // W43_CLK builds only
     unsigned *amax_out;  // or NULL: per stream, the largest output of this layer as a bit pattern (atomicMax; zeroed by the caller):
                          // what the split-precision kernels scale the NEXT layer's transformed input by (w43s_vscale)
-    // FUSE1 instantiation (conv_block1: the Cin = 1 first conv computed on the fly while staging the patch):
-    const float *fw;   // first-conv weights, BN scale folded, packed [16 chunks][9 taps][4 channels]
-    const float *fsh;  // first-conv BN shifts (64)
 };
-static constexpr int W43_WIN_ROWS = 34, W43_WIN_COLS = 36;  // FUSE1: raw log-mel window (patch + 1 halo, + 2 pad rows per stream boundary)
 
 // LDS layout of a halo patch buffer (16-byte pixels = the 4 channels of the chunk).  A transform read fetches, for 16 tiles
 // at a time, the pixel (4 tr + k, 4 tc + l) of each tile: with the pixels stored row by row those addresses are 64 bytes
@@ -147,17 +143,6 @@ __device__ __forceinline__ f32x2 pk_fma_lo(f32x2 x, f32x2 c, f32x2 y) {
 __device__ __forceinline__ f32x2 pk_fma_hi(f32x2 x, f32x2 c, f32x2 y) {
     f32x2 d;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(c), "v"(y));
-    return d;
-}
-// d = w * c.lo + y / w * c.hi + y with the packed operand w in an SGPR pair (wave-uniform weights)
-__device__ __forceinline__ f32x2 pk_sfma_lo(f32x2 w, f32x2 c, f32x2 y) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "s"(w), "v"(c), "v"(y));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_sfma_hi(f32x2 w, f32x2 c, f32x2 y) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(w), "v"(c), "v"(y));
     return d;
 }
 __device__ __forceinline__ f32x2 pk_mul_lo(f32x2 x, f32x2 c) {
@@ -319,7 +304,7 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
 // ALUs the f32 MFMAs run on; for those layers the transform is hoisted: MODE 2 runs the production pipeline alone (one
 // workgroup per pixel block, no weights, no MFMAs) and writes every chunk's V slab -- in exactly the LDS layout -- to HBM,
 // MODE 1 is the convolution with `in` = those slabs: V(k) arrives by LDS-DMA like U(k), nothing is transformed.
-template <int TTW, bool POOL, bool TRACE, bool FUSE1 = false, int MODE = 0>
+template <int TTW, bool POOL, bool TRACE, int MODE = 0>
 __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(const float *__restrict__ in, const float *__restrict__ upk,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, float *__restrict__ out,
@@ -334,7 +319,6 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     // the transform passes (MODE >= 2) have no weights: their two buffers hold V only (36 KB + patches = 64 KB of LDS, and with
     // <= 128 VGPRs two workgroups share a CU: twice the HBM requests in flight of a pass that does nothing but move data)
     constexpr int BUF = VOUT ? W43_V : W43_BUF, UO = VOUT ? 0 : W43_U;
-    static_assert(!(FUSE1 && MODE != 0), "the fused first conv only exists for MODE 0");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -413,7 +397,6 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     const float *p_base = in + act_off(s_first, 0, 0, 0, g.Cin, g.H, g.W) + (int64_t)(c_base >> 1) * plane8;
     unsigned p_off[NPL];                             // per-lane byte offset from the chunk's base
     uint64_t p_mask[NPL];                            // lanes of this wave that have a pixel (wave-uniform)
-    int f_win[NPL], f_dst[NPL];                      // FUSE1: window offset of the pixel's 3x3 neighbourhood, patch-buffer destination
     if constexpr (!PREV) {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
@@ -427,38 +410,11 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
             int hq_;
             const int sq_ = fdiv(ok ? iv : 0, g.fH, hq_);
             const int s_ = ok ? sq_ : s_first, h_ = ok ? hq_ : 0, w_ = ok ? w : 0;
-            p_off[j] = FUSE1 ? 0u : (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
+            p_off[j] = (unsigned)(((int64_t)(s_ - s_first) * (g.Cin >> 3) * plane8 + ((int64_t)h_ * g.W + w_) * 8) * 4);
             p_mask[j] = __builtin_amdgcn_ballot_w64(ok);
-            if (FUSE1) {
-                // window coordinates: rows in PADDED virtual-row space pv = s (H + 2) + h + 1 (a zero row above and below every
-                // stream, so the first conv's own padding needs no test), columns w - (4 tc0 - 2)
-                const int pv = s_ * (g.H + 2) + h_ + 1, pv0 = s_first * (g.H + 2) + h_first;  // pv0 = pv(first row) - 1
-                f_win[j] = ok ? (pv - pv0 - 1) * W43_WIN_COLS + pc : 0;          // top-left neighbour (row pv - 1, column w - 1)
-                f_dst[j] = ok ? q * W43_K : -1;                                  // lanes without a pixel write a trash row
-            }
         }
     }
     const unsigned lds_patch = lds0 + (unsigned)(2 * BUF) * 4u;  // byte address of patch buffer 0
-    float *f_window = patch0 + 2 * PFL + 256;                    // FUSE1: trash row, then the raw log-mel window
-// FUSE1: patch(CH) -> patch buffer PB computed from the window: 4 channels of relu(bn(conv3x3)) per pixel, packed math on the
-// channel pairs (weights in SGPR pairs, the nine neighbours broadcast from register pairs through op_sel)
-#define W43_MAKE_P1(CH, PB, J)                                                                          \
-    if (p_mask[J]) {                                                                                    \
-        const int cc_ = (CH) < n_chunks ? (CH) : n_chunks - 1;                                           \
-        const f32x2 *fw_ = (const f32x2 *)(g.fw + cc_ * 36);   /* [tap][pair] */                         \
-        const f32x2 *fs_ = (const f32x2 *)(g.fsh + cc_ * 4);                                             \
-        const float *wp_ = f_window + f_win[J];                                                          \
-        f32x2 nb_[5];                                                                                    \
-        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) nb_[t_ >> 1][t_ & 1] = wp_[(t_ / 3) * W43_WIN_COLS + t_ % 3]; \
-        f32x2 a01 = fs_[0], a23 = fs_[1];                                                                \
-        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) {                                               \
-            if (t_ & 1) { a01 = pk_sfma_hi(fw_[2 * t_], nb_[t_ >> 1], a01); a23 = pk_sfma_hi(fw_[2 * t_ + 1], nb_[t_ >> 1], a23); } \
-            else        { a01 = pk_sfma_lo(fw_[2 * t_], nb_[t_ >> 1], a01); a23 = pk_sfma_lo(fw_[2 * t_ + 1], nb_[t_ >> 1], a23); } \
-        }                                                                                                \
-        const f32x2 z2_ = {0.f, 0.f};                                                                    \
-        a01 = __builtin_elementwise_max(a01, z2_); a23 = __builtin_elementwise_max(a23, z2_);            \
-        *(f32x4 *)(patch0 + (f_dst[J] >= 0 ? (PB) * PFL + f_dst[J] : 2 * PFL + lane * 4)) = __builtin_shufflevector(a01, a23, 0, 1, 2, 3); \
-    }
 
 #define W43_COPY_U1(CH, BOFF, J_) /* callers guarantee CH < n_chunks */                                  \
     {                                                                                                    \
@@ -612,20 +568,9 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-    if (!FUSE1) W43_COPY_P(0, 0)
+    W43_COPY_P(0, 0)
     if (!VOUT) { W43_COPY_U1(0, 0, 0) W43_COPY_U1(0, 0, 1) W43_COPY_U1(0, 0, 2) W43_COPY_U1(0, 0, 3) W43_COPY_U1(0, 0, 4) }
-    if (!FUSE1) W43_COPY_P(1, 1)
-    if (FUSE1) {
-        // raw log-mel window (1 channel) of the block: rows in padded virtual-row space from pv0, columns from 4 tc0 - 2
-        const int pv0 = s_first * (g.H + 2) + h_first;
-        for (int e = tid; e < W43_WIN_ROWS * W43_WIN_COLS; e += W43_THREADS) {
-            const int rw = e / W43_WIN_COLS, cw = e % W43_WIN_COLS;
-            const int pv = pv0 + rw, s_ = pv / (g.H + 2), h_ = pv % (g.H + 2) - 1;
-            const int w_ = 4 * tc0 - 2 + cw;
-            const bool ok = s_ < g.S && h_ >= 0 && h_ < g.H && w_ >= 0 && w_ < g.W;
-            f_window[e] = ok ? in[((int64_t)s_ * g.H + h_) * g.W + w_] : 0.0f;
-        }
-    }
+    W43_COPY_P(1, 1)
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const int q = tid + W43_THREADS * j;
@@ -674,11 +619,6 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         ccd = (f32x2){cf[2], cf[3]};
         vdst = UO + (ti * 6) * 32 * W43_K + cp * 64 + ((tile + 16 * cp) & 31) * 2;  // V[6 ti + j][cp][(tile + 16 cp) % 32]
     }
-    if (FUSE1) {
-        W43_BARRIER()  // window complete
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) { W43_MAKE_P1(0, 0, j) W43_MAKE_P1(1, 1, j) }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
     W43_T_RD(patch0, 0, rX) W43_T_RD(patch0, 1, rY)
@@ -708,7 +648,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
         if (V16) W43_STORE_V16(k, cur) else if (V16B) W43_STORE_V16B(k, cur) else if (VOUT) W43_STORE_V(k, cur) \
         if (!(FIRST)) {                                                                                  \
-            W43_GAP(P2, 2, 0, 0, if (MORE_ && !(W43_ABL & 4)) { if (PREV) { W43_COPY_V1(k + 1, nxt, 0) } else if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) } else W43_COPY_P(k + 2, k & 1) }) \
+            W43_GAP(P2, 2, 0, 0, if (MORE_ && !(W43_ABL & 4)) { if (PREV) { W43_COPY_V1(k + 1, nxt, 0) } else W43_COPY_P(k + 2, k & 1) }) \
             W43_GAP(P2, 2, 1, 0, W43_OPS(W43_LOAD_OPS(G0, sb, 0)) W43_UCP(W43_COPY_U1(k + 1, nxt, 0)))   \
             W43_GAP(P2, 2, 2, 0, W43_UCP(W43_COPY_U1(k + 1, nxt, 1)))                                    \
             W43_GAP(P2, 2, 0, 1, W43_UCP(W43_COPY_U1(k + 1, nxt, 2)))                                    \
@@ -716,7 +656,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
             W43_GAP(P2, 2, 2, 1, W43_UCP(W43_COPY_U1(k + 1, nxt, 4)))                                    \
         } else {                                                                                         \
             if (PREV) { W43_COPY_V1(k + 1, nxt, 0) W43_COPY_V1(k + 1, nxt, 1) W43_COPY_V1(k + 1, nxt, 2) } \
-            else if (FUSE1) { W43_MAKE_P1(k + 2, k & 1, 0) W43_MAKE_P1(k + 2, k & 1, 1) } else W43_COPY_P(k + 2, k & 1) \
+            else W43_COPY_P(k + 2, k & 1)                                                                \
             W43_OPS(W43_LOAD_OPS(G0, sb, 0))                                                             \
             W43_UCP(W43_COPY_U1(k + 1, nxt, 0) W43_COPY_U1(k + 1, nxt, 1) W43_COPY_U1(k + 1, nxt, 2)     \
                     W43_COPY_U1(k + 1, nxt, 3) W43_COPY_U1(k + 1, nxt, 4))                               \
@@ -724,7 +664,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         }                                                                                                \
         W43_GAP(G0, 0, 0, 0, W43_OPS(W43_LOAD_OPS(G1, sb, 1)))                                           \
         W43_GAP(G0, 0, 1, 0, W43_TRF(W43_T_RD(pb_r, 0, rX) W43_T_RD(pb_r, 1, rY)) if (PREV && MORE_ && !(FIRST)) W43_COPY_V1(k + 1, nxt, 1)) \
-        W43_GAP(G0, 0, 2, 0, if (FUSE1 && MORE_ && !(FIRST)) W43_MAKE_P1(k + 2, k & 1, 1) if (PREV && MORE_ && !(FIRST)) W43_COPY_V1(k + 1, nxt, 2)) \
+        W43_GAP(G0, 0, 2, 0, if (PREV && MORE_ && !(FIRST)) W43_COPY_V1(k + 1, nxt, 2)) \
         W43_GAP(G0, 0, 0, 1, W43_TRF(W43_T_ROW(0, rX) W43_T_RD(pb_r, 2, rX)))                            \
         W43_GAP(G0, 0, 1, 1, W43_TRF(W43_T_ROW(1, rY) W43_T_RD(pb_r, 3, rY)))                            \
         W43_GAP(G0, 0, 2, 1, W43_TRF(W43_T_ROW(2, rX) W43_T_RD(pb_r, 4, rX)))                            \
@@ -1324,54 +1264,6 @@ double wino43_issued_flops(const ConvShape &c, bool pool) {
     return ok ? 2.0 * (double)blocks * 32.0 * 64.0 * 36.0 * c.Cin : 0.0;
 }
 
-// first-conv weights for the fused block: w (c1, 1, 3, 3), BN scale folded -> [c1/4][9][4]
-__global__ void k_pack_fuse1(const float *__restrict__ w, const float *__restrict__ scale, int c1, float *__restrict__ o) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c1 * 9) return;
-    const int c = i / 9, t = i % 9;
-    o[((c >> 2) * 9 + t) * 4 + (c & 3)] = w[i] * scale[c];
-}
-
-int pack_fuse1(const float *w_dev, const float *scale_dev, int c1, float *packed, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_fuse1, dim3((c1 * 9 + 255) / 256), dim3(256), 0, st, w_dev, scale_dev, c1, packed);
-    STITO_LAUNCH_CHECK();
-    return STITO_OK;
-}
-
-// conv_block1 in one launch: relu(bn1(conv3x3(log-mel))) is computed per 4-channel chunk while the patch is staged (FUSE1),
-// so the 64-channel full-resolution map (7.9 GB at 512 streams) is never written or read.  Maps of TTW = 8 only.
-static bool w43_fused_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &lds, int64_t &blocks) {
-    if (w43_ttw(c, pool) != 8 || !w43_geometry<8>(c, pool, g, lds, blocks)) return false;
-    const int nb = (4 - 1) / g.TR + 1;  // stream boundaries a block of 4 tile rows can straddle
-    if (g.PR + 2 + 2 * nb > W43_WIN_ROWS || 4 * 8 + 2 + 2 > W43_WIN_COLS) return false;
-    lds += (size_t)(256 + W43_WIN_ROWS * W43_WIN_COLS) * sizeof(float);
-    return lds <= 160 * 1024;
-}
-
-bool wino43_fused_supported(const ConvShape &c, bool pool) {
-    if (c.Cin % 8 != 0 || c.Cout % 64 != 0 || (pool && (c.H < 2 || c.W < 2))) return false;
-    Wino43Geom g;
-    size_t lds;
-    int64_t blocks;
-    return w43_fused_geometry(c, pool, g, lds, blocks);
-}
-
-int launch_wino43_fused(const float *logmel, const float *fw, const float *fsh, const float *upk, const float *scale,
-                        const float *shift, float *out, const ConvShape &c, bool pool, hipStream_t st) {
-    Wino43Geom g;
-    size_t lds;
-    int64_t blocks;
-    STITO_REQUIRE(w43_fused_geometry(c, pool, g, lds, blocks), STITO_E_UNSUPPORTED,
-                  "fused conv block (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
-    g.fw = fw;
-    g.fsh = fsh;
-    auto kern = pool ? k_conv_wino43<8, true, false, true> : k_conv_wino43<8, false, false, true>;
-    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, logmel, upk, scale, shift, out, g);
-    STITO_LAUNCH_CHECK();
-    return STITO_OK;
-}
-
 #if W43_CLK
 // a ring of 256 launches, no synchronisation (the launches stay back to back); dumped when the process exits: the LAST launch of
 // every (kernel, shape), i.e. the clock after that kernel has run for as long as the caller kept launching it
@@ -1482,14 +1374,14 @@ static int launch_w43_pre(const float *in, const float *upk, const float *scale,
         int ncg = 1;
         while (m_blocks * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;  // even share, >= 4 chunks
         gv.n_cgroups = ncg;
-        auto kern = k_conv_wino43<TTW, POOL, false, false, 2>;
+        auto kern = k_conv_wino43<TTW, POOL, false, 2>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
         hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, vbuf, gv);
         STITO_LAUNCH_CHECK();
     }
-    auto kern = k_conv_wino43<TTW, POOL, false, false, 1>;
+    auto kern = k_conv_wino43<TTW, POOL, false, 1>;
     const size_t lds1 = (size_t)2 * W43_BUF * sizeof(float);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     // grid in whole XCD rounds: 8 XCDs x (groups of 8 pixel blocks) x (groups of 4 channel tiles) x 32 workgroups
@@ -1562,7 +1454,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
         int ncg = 1;
         while (m_blocks * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
         gv.n_cgroups = ncg;
-        auto kern = k_conv_wino43<TTW, POOL, false, false, 3>;
+        auto kern = k_conv_wino43<TTW, POOL, false, 3>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
         hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
@@ -1672,7 +1564,7 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
         int ncg = 1;
         while (m_blocks2 * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
         gv.n_cgroups = ncg;
-        auto kern = k_conv_wino43<TTW, POOL, false, false, 4>;
+        auto kern = k_conv_wino43<TTW, POOL, false, 4>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
         hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks2 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,

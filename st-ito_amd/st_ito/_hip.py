@@ -49,7 +49,7 @@ class Cnn14Weights(Structure):
         ("bn_scale_dev", c_void_p * 12), ("bn_shift_dev", c_void_p * 12),
         ("fc_mid_wt_dev", c_void_p), ("fc_mid_b_dev", c_void_p),
         ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
-        ("conv1_fused_w_dev", c_void_p),
+        ("reserved_ptr", c_void_p),
         ("conv1_f2reg_w_dev", c_void_p),
     ]
 
@@ -90,10 +90,6 @@ SIGNATURES = {
     "stito_conv_timing_enable": (c_int, [c_int]),
     "stito_conv_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "stito_conv_timing_read_each": (c_int, [POINTER(ctypes.c_double), c_int, POINTER(c_int)]),
-    "stito_cnn14_pack_conv1_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "stito_conv_block1_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "stito_conv_block1_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                        c_int, c_int, c_int, c_void_p]),
     "stito_cnn14_packed_conv1_f2reg_floats": (c_size_t, []),
     "stito_cnn14_pack_conv1_f2reg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "stito_conv_block1_f2reg_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),

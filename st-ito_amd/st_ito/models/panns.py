@@ -207,15 +207,6 @@ class Cnn14(nn.Module):
                 idx = 2 * b + j
                 W.conv_w_dev[idx], W.bn_scale_dev[idx], W.bn_shift_dev[idx] = packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
                 keep += [w, packed, scale, shift]
-                if idx == 0 and self.conv_algo == _hip.CONV_WINOGRAD_F4 and os.environ.get("STITO_FUSE_BLOCK1", "0") == "1":
-                    # conv_block1 in one launch (stito_conv_block1_fused): the first conv is evaluated while the second one stages
-                    # its input, so the 64-channel full-resolution map (7.9 GB at 512 streams) never goes to HBM.  Opt-in: measured
-                    # 11.4 ms against 2.8 + 7.6 ms for the two launches at 512 streams -- the first conv's VALU work (56 packed
-                    # instructions per wave per chunk) comes out of the MFMA stream's time -- so it only pays when memory is short.
-                    fw = torch.empty(cout * 9, dtype=torch.float32, device=dev)
-                    _hip.check(L.stito_cnn14_pack_conv1_fused(_hip.ptr(w), _hip.ptr(scale), cout, _hip.ptr(fw), st))
-                    W.conv1_fused_w_dev = fw.data_ptr()
-                    keep.append(fw)
         if (self.conv_fuse1 and int(W.conv_wino_algo[1]) == _hip.CONV_WINOGRAD_F2_REG and W.conv_wino_dev[1] and
                 self.conv_block1.conv1.weight.shape[:2] == (64, 1)):
             # conv_block1 in one launch (stito_conv_block1_f2reg): the first conv is computed on the matrix pipe into the second

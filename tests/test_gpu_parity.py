@@ -561,55 +561,6 @@ def test_conv_repeat_launch_race_guard(dev, H, W, cin, cout, pool, algos):
         del outs
 
 
-@pytest.mark.parametrize("n,H,W,c1,cout,pool", [(2, 33, 128, 64, 64, 1), (3, 9, 64, 64, 64, 1), (5, 6, 32, 64, 128, 1),
-                                                 (2, 21, 40, 64, 128, 0), (1, 469, 128, 64, 64, 1), (4, 13, 128, 8, 64, 1)])
-def test_conv_block1_fused_vs_torch(dev, n, H, W, c1, cout, pool):
-    """stito_conv_block1_fused: relu(bn1(conv3x3(x))) -> relu(bn2(conv3x3(.))) (+ 2x2 average pool) of a 1-channel map in ONE
-    launch (the first conv evaluated while the Winograd F(4x4,3x3) kernel stages its patch; panns.py:65-80, 250; opt-in in the
-    model through STITO_FUSE_BLOCK1=1) against float64 torch.  Shapes include several streams per workgroup (stream boundaries inside the first conv's window), maps
-    whose last tile row is partial, the bench map, and a first conv of 8 channels."""
-    from st_ito import _hip
-    L = _hip.lib()
-    if not L.stito_conv_block1_fused_supported(n, H, W, c1, cout, pool):
-        pytest.skip("shape not covered by the fused kernel")
-    g = torch.Generator().manual_seed(H * 100 + W + c1)
-    x = torch.randn((n, 1, H, W), generator=g)
-    w1 = torch.randn((c1, 1, 3, 3), generator=g) / 3.0
-    w2 = torch.randn((cout, c1, 3, 3), generator=g) / np.sqrt(9 * c1)
-    s1, h1 = 0.5 + torch.rand(c1, generator=g), 0.3 * torch.randn(c1, generator=g)
-    s2, h2 = 0.5 + torch.rand(cout, generator=g), 0.2 * torch.randn(cout, generator=g)
-    F = torch.nn.functional
-    y = torch.relu(F.conv2d(x.double(), w1.double(), padding=1) * s1.double()[None, :, None, None] + h1.double()[None, :, None, None])
-    y = torch.relu(F.conv2d(y, w2.double(), padding=1) * s2.double()[None, :, None, None] + h2.double()[None, :, None, None])
-    if pool:
-        y = F.avg_pool2d(y, 2)
-    n_, C_, H_, W_ = y.shape
-    ref = y.reshape(n_, C_ // 8, 8, H_, W_).permute(0, 1, 3, 4, 2).contiguous()
-    st = _hip.stream_ptr()
-    xd = x.reshape(n, H, W).contiguous().to(dev)
-    w1d, s1d, h1d, w2d, s2d, h2d = (t.contiguous().to(dev) for t in (w1, s1, h1, w2, s2, h2))
-    fw = torch.empty(c1 * 9, device=dev)
-    _hip.check(L.stito_cnn14_pack_conv1_fused(_hip.ptr(w1d), _hip.ptr(s1d), c1, _hip.ptr(fw), st))
-    upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, c1, 2), device=dev)
-    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w2d), cout, c1, 2, _hip.ptr(upk), st))
-    out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
-    _hip.check(L.stito_conv_block1_fused(_hip.ptr(xd), _hip.ptr(fw), _hip.ptr(h1d), _hip.ptr(upk), _hip.ptr(s2d), _hip.ptr(h2d),
-                                         _hip.ptr(out), n, H, W, c1, cout, pool, st))
-    got = out.cpu().double()
-    assert not torch.isnan(got).any(), "unwritten outputs"
-    err = (got - ref).abs().max().item()
-    print(f"fused block {n}x{H}x{W} 1->{c1}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
-    assert err < 5e-5 * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
-    # and against the two-launch path (first conv kernel, then the same Winograd kernel), which must agree to rounding
-    pk1 = torch.empty(L.stito_cnn14_packed_conv_floats(c1, 1, 0), device=dev)
-    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w1d), c1, 1, 0, _hip.ptr(pk1), st))
-    mid = torch.empty((n, c1 // 8, H, W, 8), device=dev)
-    _hip.check(L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(pk1), _hip.ptr(s1d), _hip.ptr(h1d), _hip.ptr(mid), n, H, W, 1, c1, 0, 0, st))
-    out2 = torch.empty_like(out)
-    _hip.check(L.stito_conv3x3_bn_relu(_hip.ptr(mid), _hip.ptr(upk), _hip.ptr(s2d), _hip.ptr(h2d), _hip.ptr(out2), n, H, W, c1, cout, pool, 2, st))
-    assert (out - out2).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
-
-
 @pytest.mark.parametrize("n,H,W,cout,pool", [(2, 33, 128, 64, 1), (3, 9, 64, 64, 1), (5, 6, 32, 128, 1), (2, 21, 40, 128, 0),
                                               (1, 469, 128, 64, 1), (4, 13, 128, 64, 1), (3, 7, 130, 64, 0), (6, 4, 16, 64, 1),
                                               (2, 2, 2, 64, 1), (1, 1, 1, 64, 0), (40, 10, 34, 64, 1)])
