@@ -126,6 +126,7 @@ def pmc_traffic_per_launch(n_streams):
 ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)", 3: "winograd F(4x4,3x3), input transform hoisted (two kernels)",
               4: "winograd F(4x4,3x3), input transform hoisted, f32 operands as f16 hi + lo on the f16 matrix pipe (3 products, f32 accumulate)",
               5: "the same on 64 x 64 workgroup tiles in two sweeps over the positions",
+              9: "the same on 128 x 128 workgroup tiles in six sweeps (one position row each)",
               8: "winograd F(2x2,3x3), weights resident in registers, input transform in registers, split operands on the f16 pipe"}
 
 
@@ -172,7 +173,7 @@ def conv_layer_times(model, n_streams, T, reps=3):
                                mfma_issued_tflops=round(issued / ms / 1e9, 2), mfma_frac=round(issued / ms / 1e9 / PIPE_PEAK["f16-reg"], 4)))
             cur = out
             continue
-        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3, 4, 5, 8) else 1
+        walgo = int(W.conv_wino_algo[i]) if W.conv_wino_algo[i] in (1, 2, 3, 4, 5, 8, 9) else 1
         wino = bool(W.conv_wino_dev[i]) and L.stito_conv3x3_supported(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], walgo)
         algo = walgo if wino else 0
         wsb = L.stito_conv3x3_workspace_bytes(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
@@ -189,11 +190,13 @@ def conv_layer_times(model, n_streams, T, reps=3):
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         fl = r["flops"] * n_streams
         issued = L.stito_conv3x3_issued_flops(n_streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], algo)
-        pipe = "f16-reg" if algo == 8 else ("f16-stream" if algo in (4, 5) else "f32")
+        pipe = "f16-reg" if algo == 8 else ("f16-stream" if algo in (4, 5, 9) else "f32")
         # split-precision kernel: every operand element of every product travels L2 -> LDS as 4 bytes (hi + lo); per workgroup
         # 36 positions x (32 tiles + 64 couts) x cin elements, i.e. 4 / (2 * 32 * 64 / 96) bytes per f32-equivalent MAC
         # (two-sweep kernel: 128 elements per 64 x 64 MACs)
-        fill = issued / 3.0 / 2.0 * ((96.0 / (32.0 * 64.0)) if algo == 4 else (128.0 / (64.0 * 64.0))) * 4.0 if algo in (4, 5) else 0.0
+        # (six-sweep kernel: 256 elements per 128 x 128 MACs)
+        per_mac = {4: 96.0 / (32.0 * 64.0), 5: 128.0 / (64.0 * 64.0), 9: 256.0 / (128.0 * 128.0)}
+        fill = issued / 3.0 / 2.0 * per_mac[algo] * 4.0 if algo in per_mac else 0.0
         row = dict(layer=f"conv_block{i // 2 + 1}.conv{i % 2 + 1}", algo=ALGO_NAMES[algo] if r["cin"] % 8 == 0 else "direct (VALU, cin = 1)",
                    H=r["H"], W=r["W"], cin=r["cin"], cout=r["cout"], ms=round(ms, 4), algorithmic_tflops=round(fl / ms / 1e9, 2))
         if issued:

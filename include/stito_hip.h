@@ -84,7 +84,8 @@ const char *stito_last_error(void);
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
  * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT;
  * 7: STITO_CONV_WINOGRAD_F2_REG; 8: stito_conv_block1_f2reg + stito_cnn14_weights.conv1_f2reg_w_dev (appended);
- * 9: algorithms 6 and 7 and stito_conv_block1_fused / stito_cnn14_pack_conv1_fused retired). */
+ * 9: algorithms 6 and 7 and stito_conv_block1_fused / stito_cnn14_pack_conv1_fused retired;
+ * STITO_CONV_WINOGRAD_F4_SPLIT3). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -214,7 +215,14 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * persistent workgroups for the whole launch, the input transform is done in registers straight into the MFMA operand
         * layout (no transformed input in LDS or HBM), the raw halo patches arrive by LDS-DMA.  cin == 64, cout % 64 == 0; own
         * packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 7). */
-       STITO_CONV_WINOGRAD_F2_REG = 8 };
+       STITO_CONV_WINOGRAD_F2_REG = 8,
+       /* The split-precision streaming convolution on 128-tile x 128-channel workgroup tiles, in SIX sweeps over the input
+        * channels (one Winograd position row per sweep; the rows' contributions to the 4 x 4 outputs accumulate in a workgroup-
+        * private scratch area of the workspace): half the bytes copied into LDS per MAC of _F4_SPLIT2, which is what bounds these
+        * kernels.  For the deep layers (long channel loops: the five extra passes over the outputs are + 13 % of the operand
+        * stream at 2 048 input channels, + 27 % at 1 024).  cin % 64 == 0, cout % 512 == 0; own packing; same accuracy as
+        * _F4_SPLIT / _SPLIT2, sums in another order (ABI version 9). */
+       STITO_CONV_WINOGRAD_F4_SPLIT3 = 9 };
 
 typedef struct {
     int32_t embed_dim;
@@ -226,7 +234,7 @@ typedef struct {
     const float *conv_w_dev[STITO_CNN14_NUM_CONVS];    /* STITO_CONV_DIRECT packing (required) */
     const float *conv_wino_dev[STITO_CNN14_NUM_CONVS]; /* Winograd packing of conv_wino_algo[i], or NULL: used per
                                                           layer whenever the feature map fits that kernel */
-    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2 or STITO_CONV_WINOGRAD_F2_REG */
+    int32_t conv_wino_algo[STITO_CNN14_NUM_CONVS];     /* STITO_CONV_WINOGRAD, _F4, _F4_PRE (these two share a packing), _F4_SPLIT, _F4_SPLIT2, _F4_SPLIT3 or STITO_CONV_WINOGRAD_F2_REG */
     const float *bn_scale_dev[STITO_CNN14_NUM_CONVS];
     const float *bn_shift_dev[STITO_CNN14_NUM_CONVS];
     const float *fc_mid_wt_dev;  /* (2048, embed_dim): fc_mid.weight transposed */
@@ -308,7 +316,7 @@ int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, int pool, in
 int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_dev, const float *scale_dev,
                           const float *shift_dev, float *out_dev, int n, int H, int W, int cin, int cout,
                           int pool, int algo, void *stream);
-/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT / _F4_SPLIT2: the transformed
+/* The same with a workspace, for the algorithms that need one (STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT / _F4_SPLIT2 / _F4_SPLIT3: the transformed
  * input; STITO_CONV_WINOGRAD_F2_REG: per-stream maxima of the input; stito_conv3x3_workspace_bytes; 0 bytes / NULL for the others). */
 size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo);
 int stito_conv3x3_bn_relu_ws(const float *in_dev, const float *packed_w_dev, const float *scale_dev,

@@ -47,6 +47,8 @@ def mode_of(kname):
 def kind_of(kname):
     if "k_conv_wino23r" in kname:
         return "F(2x2,3x3), f16 hi + lo operands, weights resident in registers" + (", first conv computed into the patch ring" if fused1(kname) else "")
+    if "k_conv_wino43s3" in kname:
+        return "F(4x4,3x3), f16 hi + lo operands, six sweeps (128 x 128 tiles)"
     if "k_conv_wino43s2" in kname:
         return "F(4x4,3x3), f16 hi + lo operands, two sweeps (64 x 64 tiles)"
     if "k_conv_wino43s" in kname:

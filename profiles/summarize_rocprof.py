@@ -23,12 +23,12 @@ for path in sys.argv[1:]:
     for name, dur in cur.execute("select name, end-start from kernels where name like '%k_conv_wino%' or name like '%k_conv3x3%'"):
         m = re.search(r"k_conv_wino43<([^>]*)>", name)
         mode = int(m.group(1).split(",")[-1]) if m and len(m.group(1).split(",")) >= 4 else 0
-        if mode in (2, 3, 4):
+        if mode in (2, 3, 4, 5):
             if 8e4 < dur:
                 n_tr += 1; t_tr += dur / 1e6
-                fam["f16-stream" if mode in (3, 4) else "f32"][1] += dur / 1e6
+                fam["f16-stream" if mode in (3, 4, 5) else "f32"][1] += dur / 1e6
         elif dur > 1e6:
-            pipe = "f16-stream" if re.search(r"k_conv_wino43(s2|s|h)<", name) else ("f16-reg" if "k_conv_wino23r" in name else "f32")
+            pipe = "f16-stream" if re.search(r"k_conv_wino43(s3|s2|s|h)<", name) else ("f16-reg" if "k_conv_wino23r" in name else "f32")
             fam[pipe][0] += 1; fam[pipe][1] += dur / 1e6
     n = sum(v[0] for v in fam.values())
     if n:

@@ -1054,15 +1054,15 @@ static bool wino_ok(int cout, int cin) { return cin % WK == 0 && cout % 64 == 0;
 extern "C" size_t stito_cnn14_packed_conv_floats(int cout, int cin, int algo) {
     if (algo == 6 || algo == 7) return 0;  // retired (see stito_hip.h)
     if (algo == STITO_CONV_WINOGRAD_F2_REG) return wino23r_packed_floats(cout, cin);
-    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2) return wino43_split_packed_floats(cout, cin);
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2 || algo == STITO_CONV_WINOGRAD_F4_SPLIT3) return wino43_split_packed_floats(cout, cin);
     return (size_t)cout * cin * ((algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) ? 36 : algo == STITO_CONV_WINOGRAD ? 16 : 9);
 }
 
 extern "C" int stito_cnn14_pack_conv(const float *w_oihw_dev, int cout, int cin, int algo, float *packed_dev, void *stream) {
     STITO_REQUIRE(algo != 6 && algo != 7, STITO_E_UNSUPPORTED, "conv: algorithm %d was retired in ABI version 9", algo);
     if (algo == STITO_CONV_WINOGRAD_F2_REG) return pack_wino23r(w_oihw_dev, cout, cin, packed_dev, (hipStream_t)stream);
-    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2)
-        return pack_wino43_split(w_oihw_dev, cout, cin, packed_dev, algo == STITO_CONV_WINOGRAD_F4_SPLIT2 ? 1 : 0,
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2 || algo == STITO_CONV_WINOGRAD_F4_SPLIT3)
+        return pack_wino43_split(w_oihw_dev, cout, cin, packed_dev, algo == STITO_CONV_WINOGRAD_F4_SPLIT3 ? 2 : algo == STITO_CONV_WINOGRAD_F4_SPLIT2 ? 1 : 0,
                                  (hipStream_t)stream);
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) {  // one packing for both
         STITO_REQUIRE(wino_ok(cout, cin), STITO_E_UNSUPPORTED, "conv (winograd): cin %d / cout %d", cin, cout);
@@ -1130,6 +1130,7 @@ extern "C" int stito_conv3x3_supported(int n, int H, int W, int cin, int cout, i
     if (algo == STITO_CONV_WINOGRAD_F4_PRE && (cout % 256 != 0 || (cout >= 1024 && cout % 512 != 0))) return 0;  // its workgroup order deals channel tiles in fours / eights
     if (algo == 6 || algo == 7) return 0;  // retired
     if (algo == STITO_CONV_WINOGRAD_F2_REG) return wino23r_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT3) return wino43_split3_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2)
         return (cout < 1024 || cout % 512 == 0) && wino43_split_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_supported(ConvShape{n, H, W, cin, cout}, pool != 0) ? 1 : 0;
@@ -1147,6 +1148,7 @@ extern "C" double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int c
     if (algo == STITO_CONV_WINOGRAD_F4 || algo == STITO_CONV_WINOGRAD_F4_PRE) return wino43_issued_flops(c, pool != 0);
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT) return 3.0 * wino43_issued_flops(c, pool != 0);  // hi hi' + hi lo' + lo hi' on the f16 pipe
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT2) return wino43_split2_issued_flops(c, pool != 0);
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT3) return wino43_split3_issued_flops(c, pool != 0);
     if (algo == STITO_CONV_WINOGRAD) {
         WinoGeom g;
         size_t lds;
@@ -1169,7 +1171,7 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
                                      int pool, int algo, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
-    STITO_REQUIRE(algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+    STITO_REQUIRE(algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 && algo != STITO_CONV_WINOGRAD_F4_SPLIT3 &&
                   algo != STITO_CONV_WINOGRAD_F2_REG, STITO_E_WORKSPACE,
                   "conv: STITO_CONV_WINOGRAD_F4_PRE / _F4_SPLIT* / STITO_CONV_WINOGRAD_F2_REG need stito_conv3x3_bn_relu_ws");
     if (cin % 8 != 0) {
@@ -1197,11 +1199,12 @@ extern "C" int stito_conv3x3_bn_relu(const float *in_dev, const float *packed_w_
 }
 
 extern "C" size_t stito_conv3x3_workspace_bytes(int n, int H, int W, int cin, int cout, int pool, int algo) {
-    if ((algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+    if ((algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 && algo != STITO_CONV_WINOGRAD_F4_SPLIT3 &&
          algo != STITO_CONV_WINOGRAD_F2_REG) || !stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)) return 0;
     if (algo == STITO_CONV_WINOGRAD_F2_REG) return wino23r_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT) return wino43_split_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
     if (algo == STITO_CONV_WINOGRAD_F4_SPLIT2) return wino43_split2_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT3) return wino43_split3_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
     return wino43_pre_workspace_bytes(ConvShape{n, H, W, cin, cout}, pool != 0);
 }
 
@@ -1220,7 +1223,7 @@ static int conv3x3_ws(const float *in_dev, const float *packed_w_dev, const floa
     }
     if (algo == STITO_CONV_DIRECT && cin == 1 && amax_out != nullptr && !pool && n > 0 && H > 0 && W > 0)
         return conv_first(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cout, (hipStream_t)stream, amax_out);
-    if (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2) {
+    if (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 && algo != STITO_CONV_WINOGRAD_F4_SPLIT3) {
         if (algo == STITO_CONV_WINOGRAD_F4 && amax_out != nullptr && n > 0 && H > 0 && W > 0 && cin % 8 == 0 && cout % 64 == 0 &&
             wino_ok(cout, cin) && (!pool || (H >= 2 && W >= 2)))
             return launch_wino43(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0, g_wino_trace,
@@ -1229,10 +1232,13 @@ static int conv3x3_ws(const float *in_dev, const float *packed_w_dev, const floa
         return stito_conv3x3_bn_relu(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, n, H, W, cin, cout, pool, algo, stream);
     }
     STITO_REQUIRE(n > 0 && H > 0 && W > 0, STITO_E_INVALID, "conv: empty input");
-    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2) {
+    if (algo == STITO_CONV_WINOGRAD_F4_SPLIT || algo == STITO_CONV_WINOGRAD_F4_SPLIT2 || algo == STITO_CONV_WINOGRAD_F4_SPLIT3) {
         STITO_REQUIRE(stito_conv3x3_supported(n, H, W, cin, cout, pool, algo), STITO_E_UNSUPPORTED,
                       "conv (split-precision winograd F(4x4,3x3)): %dx%d map, %d -> %d channels not covered (cin %% 64, cout %% 256)", H, W, cin, cout);
         STITO_REQUIRE(!pool || (H >= 2 && W >= 2), STITO_E_INVALID, "Given input size: (%dx%dx%d). Output size is too small", cout, H, W);
+        if (algo == STITO_CONV_WINOGRAD_F4_SPLIT3)
+            return launch_wino43_split3(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
+                                        workspace_dev, workspace_bytes, (hipStream_t)stream, amax_in, amax_out);
         if (algo == STITO_CONV_WINOGRAD_F4_SPLIT2)
             return launch_wino43_split2(in_dev, packed_w_dev, scale_dev, shift_dev, out_dev, ConvShape{n, H, W, cin, cout}, pool != 0,
                                         workspace_dev, workspace_bytes, (hipStream_t)stream, amax_in, amax_out);
@@ -1265,7 +1271,7 @@ static size_t cnn14_pre_bytes(const stito_cnn14_weights *w, int n_streams, const
     size_t v = 0;
     for (int i = 0; i < STITO_CNN14_NUM_CONVS; ++i) {
         const int algo = w->conv_wino_algo[i];
-        if (w->conv_wino_dev[i] == nullptr || (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+        if (w->conv_wino_dev[i] == nullptr || (algo != STITO_CONV_WINOGRAD_F4_PRE && algo != STITO_CONV_WINOGRAD_F4_SPLIT && algo != STITO_CONV_WINOGRAD_F4_SPLIT2 && algo != STITO_CONV_WINOGRAD_F4_SPLIT3 &&
                                                algo != STITO_CONV_WINOGRAD_F2_REG)) continue;
         const int blk = i / 2, j = i % 2;
         const int ci = j == 0 ? w->channels[blk] : w->channels[blk + 1], pool = (j == 1 && blk < 5) ? 1 : 0;
@@ -1393,7 +1399,7 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             {
                 const int nalgo = w->conv_wino_algo[2];
                 if (w->conv_wino_dev[2] != nullptr &&
-                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 ||
+                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
                      nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
                     stito_conv3x3_supported(S, H[1], W[1], w->channels[1], w->channels[2], 0, nalgo)) {
                     amax_out = (unsigned *)((char *)amax_all + amax_stride * 1);
@@ -1412,7 +1418,7 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
             const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
             // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
             int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE ||
-                         w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 ||
+                         w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
                                                   w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F2_REG)
                             ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;  // (a split packing has no float32 fallback: the direct kernel takes over)
             if (walgo == STITO_CONV_WINOGRAD_F4_PRE && !stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo))
@@ -1437,7 +1443,7 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                 const int nci = nj == 0 ? w->channels[nb] : w->channels[nb + 1], npool = (nj == 1 && nb < 5) ? 1 : 0;
                 const int nalgo = w->conv_wino_algo[i + 1];
                 if (w->conv_wino_dev[i + 1] != nullptr &&
-                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 ||
+                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
                      nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
                     stito_conv3x3_supported(S, H[nb], W[nb], nci, w->channels[nb + 1], npool, nalgo)) {
                     amax_out = (unsigned *)((char *)amax_all + amax_stride * i);

@@ -90,10 +90,15 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
 bool wino43_split_supported(const ConvShape &c, bool pool);
 size_t wino43_split_workspace_bytes(const ConvShape &c, bool pool);
 size_t wino43_split_packed_floats(int cout, int cin);
-int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st);  // 0: k_conv_wino43s, 1: s2
+int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st);  // 0: k_conv_wino43s, 1: s2, 2: s3
 size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool);
 double wino43_split2_issued_flops(const ConvShape &c, bool pool);
 int launch_wino43_split2(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+bool wino43_split3_supported(const ConvShape &c, bool pool);   // six sweeps, 128 x 128 workgroup tiles (cout % 512 == 0)
+size_t wino43_split3_workspace_bytes(const ConvShape &c, bool pool);
+double wino43_split3_issued_flops(const ConvShape &c, bool pool);
+int launch_wino43_split3(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                          bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);

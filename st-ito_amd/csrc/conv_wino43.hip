@@ -315,7 +315,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     using PL = W43Patch<TTW>;
     constexpr int NPL = PL::NPL;      // LDS-DMA instructions of patch per wave per chunk
     constexpr int PFL = PL::PFL;      // floats per patch buffer
-    constexpr bool PREV = MODE == 1, VOUT = MODE >= 2, V16 = MODE == 3, V16B = MODE == 4;  // 3 / 4: f16 slabs of k_conv_wino43s / s2
+    constexpr bool PREV = MODE == 1, VOUT = MODE >= 2, V16 = MODE == 3, V16B = MODE == 4, V16C = MODE == 5;  // 3 / 4 / 5: f16 slabs of k_conv_wino43s / s2 / s3
     // the transform passes (MODE >= 2) have no weights: their two buffers hold V only (36 KB + patches = 64 KB of LDS, and with
     // <= 128 VGPRs two workgroups share a CU: twice the HBM requests in flight of a pass that does nothing but move data)
     constexpr int BUF = VOUT ? W43_V : W43_BUF, UO = VOUT ? 0 : W43_U;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     // all of its (position, tile) items; the scale belongs to the tile's stream (`scale` carries the streams' maxima).
     const int v16_tile = tid & 31;
     float v16_s = 1.0f;
-    if constexpr (V16 || V16B) {
+    if constexpr (V16 || V16B || V16C) {
         int vt_ = vtr0 + v16_tile / TTW, tr_;
         vt_ = vt_ < (int)g.VTR ? vt_ : (int)g.VTR - 1;
         v16_s = w43s_vscale(((const unsigned *)scale)[fdiv(vt_, g.fTR, tr_)]);
@@ -449,11 +449,16 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
 //         i >= 3 and is that sweep's local row [1, 2, 0][i] resp. i - 3 (rows {1, 2} and {3, 4} -- the pairs whose
 //         contributions share sums and differences -- are local rows 0, 1); slab 3 (c / 16) + local row, position column
 //         j = p % 6 at 4 KB each: [hi | lo][(c % 16) / 8][64 tiles][c % 8].
+//   V16C (B_ == 2): 128-tile workgroups = pixel-block QUADS, six sweeps of one position row each (k_conv_wino43s3): quad
+//         m_blk / 4, row i = p / 6, period 2 (c / 16) + (j >= 3) with j = p % 6: 24 KB, position j % 3 at 8 KB each:
+//         [hi | lo][(c % 16) / 8][128 tiles = 32 (m_blk % 4) + tile][c % 8].
 #define W43_STORE_V16X(K_, CUR, B_)                                                                      \
     {                                                                                                    \
         const int kc_ = c_base + (K_);                                                                   \
         const float *vs_ = smem + (CUR) + UO;                                                            \
-        char *vo_ = (B_) ? (char *)out + ((int64_t)(m_blk >> 1) * 2 * n_slabs16 + 3 * (kc_ >> 2)) * S43B_PART + \
+        char *vo_ = (B_) == 2 ? (char *)out + ((int64_t)(m_blk >> 2) * 6 * (g.Cin >> 3) + 2 * (kc_ >> 2)) * S43B_PART + \
+                               (((kc_ >> 1) & 1) * 128 + (m_blk & 3) * 32 + v16_tile) * 16                \
+                  : (B_) ? (char *)out + ((int64_t)(m_blk >> 1) * 2 * n_slabs16 + 3 * (kc_ >> 2)) * S43B_PART + \
                                (((kc_ >> 1) & 1) * 64 + (m_blk & 1) * 32 + v16_tile) * 16                 \
                          : (char *)out + ((int64_t)m_blk * n_slabs16 + 9 * (kc_ >> 3)) * S43_VPART +     \
                                (((kc_ >> 1) & 1) * 32 + v16_tile) * 16;                                  \
@@ -470,7 +475,11 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
                     _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) { hi_[e_] = (_Float16)x_[e_]; lo_[e_] = (_Float16)(x_[e_] - (float)hi_[e_]); } \
                     char *d_;                                                                            \
                     int lo_off_;                                                                         \
-                    if (B_) {                                                                            \
+                    if ((B_) == 2) {                                                                     \
+                        const int i_ = p_ / 6, j_ = p_ - 6 * i_;                                         \
+                        d_ = vo_ + ((int64_t)i_ * (g.Cin >> 3) + (j_ >= 3)) * S43B_PART + (j_ % 3) * 8192; \
+                        lo_off_ = 4096;                                                                  \
+                    } else if (B_) {                                                                     \
                         const int i_ = p_ / 6, j_ = p_ - 6 * i_;                                         \
                         const int sw_ = i_ >= 3, lr_ = sw_ ? i_ - 3 : (i_ == 0 ? 2 : i_ - 1);            \
                         d_ = vo_ + ((int64_t)sw_ * n_slabs16 + lr_) * S43B_PART + j_ * 4096;             \
@@ -486,8 +495,9 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
             }                                                                                            \
         }                                                                                                \
     }
-#define W43_STORE_V16(K_, CUR) W43_STORE_V16X(K_, CUR, false)
-#define W43_STORE_V16B(K_, CUR) W43_STORE_V16X(K_, CUR, true)
+#define W43_STORE_V16(K_, CUR) W43_STORE_V16X(K_, CUR, 0)
+#define W43_STORE_V16B(K_, CUR) W43_STORE_V16X(K_, CUR, 1)
+#define W43_STORE_V16C(K_, CUR) W43_STORE_V16X(K_, CUR, 2)
 // patch(CH) -> patch buffer PB (0, 1): two masked LDS-DMA instructions per wave (pixels wv*64 + 512 j + lane)
 #define W43_COPY_P(CH, PB)                                                                              \
     {                                                                                                   \
@@ -646,7 +656,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         const int cur = (k & 1) * BUF, nxt = BUF - cur;                                                  \
         const float *sb = smem + cur;                                                                    \
         const float *pb_r = patch0 + ((k + 1) & 1) * PFL;     /* patch(k+1); patch(k+2) goes where patch(k) was */ \
-        if (V16) W43_STORE_V16(k, cur) else if (V16B) W43_STORE_V16B(k, cur) else if (VOUT) W43_STORE_V(k, cur) \
+        if (V16) W43_STORE_V16(k, cur) else if (V16B) W43_STORE_V16B(k, cur) else if (V16C) W43_STORE_V16C(k, cur) else if (VOUT) W43_STORE_V(k, cur) \
         if (!(FIRST)) {                                                                                  \
             W43_GAP(P2, 2, 0, 0, if (MORE_ && !(W43_ABL & 4)) { if (PREV) { W43_COPY_V1(k + 1, nxt, 0) } else W43_COPY_P(k + 2, k & 1) }) \
             W43_GAP(P2, 2, 1, 0, W43_OPS(W43_LOAD_OPS(G0, sb, 0)) W43_UCP(W43_COPY_U1(k + 1, nxt, 0)))   \
@@ -1092,6 +1102,235 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 #undef F4
 }
 
+// ---- the same on 128 x 128 workgroup tiles, in six sweeps of one position row each ----------------------------------------
+// Both streaming kernels above are bound by what they copy from L2 into LDS (profiles/README.md: slab copies alone 1 625 cycles
+// of a 1 970-cycle period; operand reads and products add little), i.e. by bytes per MAC = (tiles + couts) / (tiles x couts) of
+// the workgroup tile: 96 / 2 048 (k_conv_wino43s), 128 / 4 096 (k_conv_wino43s2).  Here 256 / 16 384: half of the two-sweep
+// kernel's -- measured on the loop alone before anything else was written (tools/ubench/s3_loop.hip, profiles/
+// round4_s3_loop_ubench.txt): 1 850 cycles per 48 KB slab of 786 K MACs against 1 970 per 393 K, 0.56 of the f16 peak issued.
+// What pays for it: only ONE position row's accumulators fit the registers (6 positions x 128 x 128 floats = 384 KB; wave
+// (tile half, cout quarter) owns 64 tiles x 32 couts = 12 blocks = 192 VGPRs), so the input channels are swept six times, once
+// per position row i, and Y = A^T M A -- linear in M, row i contributing A[i][r] (sum_j M[i][j] A[j][c]) to output (r, c) --
+// is assembled through a workgroup-private f32 scratch area (1.25 MB, written and read back by the same lanes): a wave owns
+// all six positions of the row for its sub-tile, so the column combination Z_i[c] = sum_j M[i][j] A[j][c] happens in registers
+// -- NO exchange through LDS, no barrier in the epilogue -- and rows 0..4 just store their four Z values per output (stores
+// only: nothing waits; accumulating the 16 outputs instead was 3.4 x the traffic and a load-add-store chain per sweep: measured,
+// the first version); the sweep of row 5 reads the twenty values back, one output column at a time, combines the rows, and
+// finishes (operand scales, BN, ReLU, pool, stores).
+// Slab = 3 positions (half a row) x 16 channels x (128 tiles | 128 couts) x (hi, lo) = 48 KB: [input part 24 KB | weight part
+// 24 KB], position jj at 8 KB: [hi 4 KB | lo 4 KB], each [channel octet][128][8 f16]; ring of three, two wave sets issuing on
+// alternate periods as above; two periods per 16 channels.  MFMA A operand = weights (rows = couts), B = input (columns =
+// tiles): a lane's accumulator quad = 4 consecutive couts of ITS tile, 16-byte partial-sum accesses and stores fall out.
+#ifndef S43C_ABL
+#define S43C_ABL 0  // timing experiment (k_conv_wino43s3): 1 = no epilogues, 2 = no main loops; 0 in every build that ships
+#endif
+__device__ __forceinline__ const char *w43_uniform(const char *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const char *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+template <int TTW, bool POOL>
+__global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__restrict__ vsl, const char *__restrict__ usl,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                float *__restrict__ out, Wino43Geom g,
+                                                                const unsigned *__restrict__ amax, const float *__restrict__ u_inv_p,
+                                                                f32x4 *__restrict__ partial) {
+    constexpr int TTH = 32 / TTW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, oct = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup order: as the other streaming kernels, over pixel-block QUADS (g.n_mblocks = number of quads) and 128-cout tiles
+    const int n_tiles = g.Cout / 128;
+    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    const int a = g.ct_group, n_ctg = n_tiles / a;
+    const int ct = (gi % n_ctg) * a + (r % a);
+    const int m_quad = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+    if (m_quad >= g.n_mblocks) return;
+    W43_CLK_BEGIN()
+    const int nP = g.Cin >> 3;   // periods per sweep: two per 16 input channels
+    const int set = wv >> 2, w4 = wv & 3, th = wv & 1, cq = wv >> 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
+    const char *v_rd = (const char *)smem + (oct * 128 + th * 64 + l31) * 16;               // + jj * 8192 (+ 4096: lo) + blk * 512
+    const char *u_rd = (const char *)smem + S43B_PART + (oct * 128 + cq * 32 + l31) * 16;   // + jj * 8192 (+ 4096: lo)
+    f32x4 *my_partial = partial + (int64_t)blockIdx.x * (8 * 2 * 4 * 20 * 64) + wv * (2 * 4 * 20 * 64) + lane;  // [wave][blk][quad][row 0..4][c][lane]
+    const float u_inv = u_inv_p[0];
+
+    f32x16 acc[12];   // [position j of the row][tile panel]
+// piece = 4 c + w4 (c < 6: input part) as in the kernels above
+#define S43C_ISSUE(SL, BUF)                                                                              \
+    _Pragma("unroll") for (int c_ = 0; c_ < 12; ++c_) {                                                   \
+        const char *src_ = c_ < 6 ? vw + (int64_t)(SL) * S43B_PART + c_ * 4096                            \
+                                  : uw + (int64_t)(SL) * S43B_PART + (c_ - 6) * 4096;                     \
+        glds16_m0((const float *)src_, (unsigned)lane * 16u, ldsw + (unsigned)((BUF) * S43B_SLAB + c_ * 4096)); \
+    }
+#define S43C_PERIOD(KK, SL, BUF_)                                                                        \
+    {                                                                                                    \
+        const bool mine_ = set == (KK);                                                                   \
+        if (mine_ && (SL) + 2 < nP) { const int nb_ = (BUF_) + 2 >= 3 ? (BUF_) - 1 : (BUF_) + 2; S43C_ISSUE((SL) + 2, nb_) } \
+        const char *pv_ = v_rd + (BUF_) * S43B_SLAB, *pu_ = u_rd + (BUF_) * S43B_SLAB;                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                \
+            const h8 uh_ = *(const h8 *)(pu_ + q_ * 8192), ul_ = *(const h8 *)(pu_ + q_ * 8192 + 4096);    \
+            const h8 vh0_ = *(const h8 *)(pv_ + q_ * 8192), vl0_ = *(const h8 *)(pv_ + q_ * 8192 + 4096);  \
+            const h8 vh1_ = *(const h8 *)(pv_ + q_ * 8192 + 512), vl1_ = *(const h8 *)(pv_ + q_ * 8192 + 4096 + 512); \
+            constexpr int a0_ = ((KK) * 3) * 2;                                                           \
+            S43_MFMA(a0_ + 2 * q_, ul_, vh0_) S43_MFMA(a0_ + 2 * q_ + 1, ul_, vh1_)                       \
+            S43_MFMA(a0_ + 2 * q_, uh_, vl0_) S43_MFMA(a0_ + 2 * q_ + 1, uh_, vl1_)                       \
+            S43_MFMA(a0_ + 2 * q_, uh_, vh0_) S43_MFMA(a0_ + 2 * q_ + 1, uh_, vh1_)                       \
+        }                                                                                                 \
+        if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        W43_BARRIER()                                                                                     \
+    }
+
+    // this lane's two tiles (one per tile panel): map position, validity, stream, BN scale with the operand scales folded in
+    int t_s[2], t_tr[2], t_tc[2];
+    bool t_ok[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int m_blk = 4 * m_quad + 2 * th + blk;
+        int cb;
+        const int rb = fdiv(m_blk, g.fNCB, cb);
+        const int vtr = rb * TTH + l31 / TTW;
+        t_tc[blk] = cb * TTW + l31 % TTW;
+        t_ok[blk] = vtr < g.VTR && t_tc[blk] < g.TC;
+        int tr = 0;
+        t_s[blk] = t_ok[blk] ? fdiv(vtr, g.fTR, tr) : 0;
+        t_tr[blk] = tr;
+    }
+
+#pragma unroll 1
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        const int row = sweep;
+        // (the 64-bit products are VALU work: back into scalar registers by hand -- hipcc hands an "s" asm operand a VGPR pair otherwise)
+        const char *vw = w43_uniform(vsl + ((int64_t)m_quad * 6 + row) * nP * S43B_PART + w4 * 1024);
+        const char *uw = w43_uniform(usl + ((int64_t)ct * 6 + row) * nP * S43B_PART + w4 * 1024);
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+        W43_BARRIER()
+        if (set == 0) { S43C_ISSUE(0, 0) } else { S43C_ISSUE(1, 1) }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W43_BARRIER()
+        int buf = 0;
+        for (int sl = 0; sl < ((S43C_ABL & 2) ? 0 : nP); sl += 2) {   // nP % 2 == 0; the ring position is a run-time value (three loop bodies for it cost registers)
+            S43C_PERIOD(0, sl, buf)
+            buf = buf == 2 ? 0 : buf + 1;
+            S43C_PERIOD(1, sl + 1, buf)
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        // ---- this row's column combination Z[c] = sum_j M[row][j] A[j][c] (c = 0..3) goes to the scratch area (rows 0..4: stores
+        // only, nothing waits for them); the sweep of row 5 reads the five others back, one output column at a time, and finishes:
+        // Y[r][c] = sum_i A[i][r] Z_i[c],  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] ------------------------------
+        if (S43C_ABL & 1) {   // (timing builds: keep the accumulators alive)
+            float s_ = 0.f;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) s_ += acc[q][0] + acc[q][7] + acc[q][15];
+            if (s_ == 12345.f) out[tid] = s_;
+            continue;
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                W43_FENCE()   // one (tile panel, cout quad) at a time: hipcc otherwise hoists every load of the sweep (scratch)
+                f32x4 m[6], Z[4];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = (f32x4){acc[2 * j + blk][4 * gq], acc[2 * j + blk][4 * gq + 1], acc[2 * j + blk][4 * gq + 2], acc[2 * j + blk][4 * gq + 3]};
+                const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                Z[0] = (m[0] + s12) + s34;
+                Z[1] = 2.f * d34 + d12;
+                Z[2] = 4.f * s34 + s12;
+                Z[3] = (8.f * d34 + d12) + m[5];
+                f32x4 *pt = my_partial + (blk * 4 + gq) * (5 * 4 * 64);   // [row 0..4][c][lane]
+                if (sweep < 5) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pt[(sweep * 4 + c) * 64] = Z[c];
+                } else {
+                    const int co = ct * 128 + cq * 32 + 8 * gq + 4 * oct;
+                    f32x4 sc = *(const f32x4 *)(scale + co);
+                    const f32x4 sh = *(const f32x4 *)(shift + co);
+                    unsigned smax = 0;
+                    const int s_ = t_s[blk], tr = t_tr[blk], tc = t_tc[blk];
+                    if (t_ok[blk]) sc = sc * (u_inv / w43s_vscale(amax[s_]));
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        f32x4 y[2][4];   // [column 2 pc + cc][output row]
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            W43_FENCE()
+                            const int c = 2 * pc + cc;
+                            const f32x4 z0 = pt[(0 * 4 + c) * 64], z1 = pt[(1 * 4 + c) * 64], z2 = pt[(2 * 4 + c) * 64], z3 = pt[(3 * 4 + c) * 64],
+                                        z4 = pt[(4 * 4 + c) * 64];
+                            const f32x4 p12 = z1 + z2, q12 = z1 - z2, p34 = z3 + z4, q34 = z3 - z4;
+                            y[cc][0] = (z0 + p12) + p34;
+                            y[cc][1] = 2.f * q34 + q12;
+                            y[cc][2] = 4.f * p34 + p12;
+                            y[cc][3] = (8.f * q34 + q12) + Z[c];
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) y[cc][rr] = __builtin_elementwise_max(y[cc][rr] * sc + sh, (f32x4)(0.0f));
+                        }
+                        if (t_ok[blk]) {
+                            if (POOL) {
+#pragma unroll
+                                for (int pr = 0; pr < 2; ++pr) {
+                                    const int oh = 2 * tr + pr, ow = 2 * tc + pc;
+                                    if (oh < g.Ho && ow < g.Wo) {
+                                        const f32x4 v = (((y[0][2 * pr] + y[1][2 * pr]) + y[0][2 * pr + 1]) + y[1][2 * pr + 1]) * 0.25f;
+                                        *(f32x4 *)(out + act_off(s_, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
+                                        smax = max(smax, w43_max4(v));
+                                    }
+                                }
+                            } else {
+#pragma unroll
+                                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr) {
+                                        const int hh = 4 * tr + rr, ww = 4 * tc + 2 * pc + cc;
+                                        if (hh < g.H && ww < g.W) {
+                                            *(f32x4 *)(out + act_off(s_, co, hh, ww, g.Cout, g.H, g.W)) = y[cc][rr];
+                                            smax = max(smax, w43_max4(y[cc][rr]));
+                                        }
+                                    }
+                            }
+                        }
+                    }
+                    // amax_out[s] only grows: a (possibly stale) agent-scope load that already covers smax makes the atomic unnecessary
+                    if (g.amax_out != nullptr && t_ok[blk] && smax > __hip_atomic_load(g.amax_out + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        atomicMax(g.amax_out + s_, smax);
+                }
+            }
+        }
+    }
+    W43_CLK_END()
+}
+
+// weights of k_conv_wino43s3: [cout / 128][position row i][period 2 (c / 16) + (j >= 3)] x 24 KB, position j % 3 at 8 KB:
+// [hi 4 KB | lo 4 KB], each [(c % 16) / 8][cout % 128][c % 8]
+__global__ void k_pack_wino43s3(const float *__restrict__ w, int Cout, int Cin, char *__restrict__ o, const unsigned *__restrict__ hdr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double gk[3][3], t[6][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) gk[a][b] = (double)w[((int64_t)co * Cin + ci) * 9 + a * 3 + b];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * gk[0][b] + G[a][1] * gk[1][b] + G[a][2] * gk[2][b];
+    const int nP = Cin >> 3;
+    const int kg = ci >> 4, h = (ci >> 3) & 1, i8 = ci & 7;
+    const float su = __uint_as_float(hdr[2]);
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            const float us = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]) * su;
+            const _Float16 hi = (_Float16)us, lo = (_Float16)(us - (float)hi);
+            char *d = o + (((int64_t)(co >> 7) * 6 + a) * nP + 2 * kg + (b >= 3)) * S43B_PART + (b % 3) * 8192 + (h * 128 + (co & 127)) * 16 + i8 * 2;
+            *(_Float16 *)d = hi;
+            *(_Float16 *)(d + 4096) = lo;
+        }
+}
+
 // weights of k_conv_wino43s2: as k_pack_wino43s<1> in the slab order [cout / 64][sweep][slab = 3 (c / 16) + local row][column j]
 __global__ void k_pack_wino43s2(const float *__restrict__ w, int Cout, int Cin, char *__restrict__ o, const unsigned *__restrict__ hdr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1186,7 +1425,7 @@ __global__ void k_pack_wino43s_scale(unsigned *hdr) {
 size_t wino43_split_packed_floats(int cout, int cin) { return (size_t)36 * cout * cin + 64; }
 
 int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int layout, hipStream_t st) {
-    STITO_REQUIRE(cin % 64 == 0 && cout % 64 == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
+    STITO_REQUIRE(cin % 64 == 0 && cout % (layout == 2 ? 128 : 64) == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
     const int64_t n = (int64_t)cout * cin;
     unsigned *hdr = (unsigned *)(packed + (size_t)36 * cout * cin);
     STITO_HIP_CHECK(hipMemsetAsync(hdr, 0, 64 * sizeof(float), st));
@@ -1194,7 +1433,8 @@ int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int
     STITO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_wino43s_scale, dim3(1), dim3(1), 0, st, hdr);
     STITO_LAUNCH_CHECK();
-    if (layout == 1) hipLaunchKernelGGL(k_pack_wino43s2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
+    if (layout == 2) hipLaunchKernelGGL(k_pack_wino43s3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
+    else if (layout == 1) hipLaunchKernelGGL(k_pack_wino43s2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, (const unsigned *)hdr);
     else hipLaunchKernelGGL(k_pack_wino43s<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
     STITO_LAUNCH_CHECK();
     return STITO_OK;
@@ -1598,6 +1838,126 @@ int launch_wino43_split2(const float *in, const float *upk, const float *scale, 
         case 4: return pool ? launch_w43_split2<4, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<4, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
         case 2: return pool ? launch_w43_split2<2, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<2, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
         default: return pool ? launch_w43_split2<1, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split2<1, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+    }
+}
+
+// Six-sweep variant (k_conv_wino43s3): workspace = V slabs of the pixel-block quads | stream maxima | per-workgroup partial outputs (1 MB each).
+bool wino43_split3_supported(const ConvShape &c, bool pool) {
+    return c.Cin % 64 == 0 && c.Cout % 512 == 0 && wino43_supported(c, pool) && ((int64_t)c.Cin * c.H * c.W) % 8 == 0;
+}
+
+template <int TTW>
+static int64_t w43_split3_grid(const ConvShape &c, bool pool, int64_t &m_quads, int &ct_group) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    if (!w43_geometry<TTW>(c, pool, g, lds, blocks)) return 0;
+    const int64_t m_blocks = blocks / (c.Cout / 64);
+    m_quads = (m_blocks + 3) / 4;
+    const int n_tiles = c.Cout / 128;   // a multiple of 4 (wino43_split3_supported)
+    int a = 4;
+    if (const char *e = getenv("STITO_W43S3_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }
+    if (n_tiles % a != 0) return 0;
+    ct_group = a;
+    const int bm = 32 / a;
+    const int64_t m_groups = ((m_quads + 7) / 8 + bm - 1) / bm;
+    return 8 * m_groups * (n_tiles / a) * 32;
+}
+
+static int64_t w43_split3_grid_any(const ConvShape &c, bool pool, int64_t &m_quads, int &ct_group) {
+    switch (w43_ttw(c, pool)) {
+        case 8: return w43_split3_grid<8>(c, pool, m_quads, ct_group);
+        case 4: return w43_split3_grid<4>(c, pool, m_quads, ct_group);
+        case 2: return w43_split3_grid<2>(c, pool, m_quads, ct_group);
+        default: return w43_split3_grid<1>(c, pool, m_quads, ct_group);
+    }
+}
+
+// f16-pipe FLOPs the six-sweep kernel issues: pixel-block quads (padded blocks included) x 128-cout tiles x 128 x 128 x 36 x cin x 3 products
+double wino43_split3_issued_flops(const ConvShape &c, bool pool) {
+    if (!wino43_split3_supported(c, pool)) return 0.0;
+    int64_t m_quads = 0;
+    int a;
+    if (w43_split3_grid_any(c, pool, m_quads, a) <= 0) return 0.0;
+    return 3.0 * 2.0 * (double)m_quads * (c.Cout / 128) * 128.0 * 128.0 * 36.0 * c.Cin;
+}
+
+static size_t w43_split3_vbytes(const ConvShape &c, int64_t m_quads) { return align_up((size_t)m_quads * 6 * (size_t)(c.Cin >> 3) * S43B_PART, 256); }
+
+size_t wino43_split3_workspace_bytes(const ConvShape &c, bool pool) {
+    if (!wino43_split3_supported(c, pool)) return 0;
+    int64_t m_quads = 0;
+    int a;
+    const int64_t grid = w43_split3_grid_any(c, pool, m_quads, a);
+    if (grid <= 0 || grid >= (1ll << 31)) return 0;
+    return w43_split3_vbytes(c, m_quads) + align_up((size_t)c.S * sizeof(unsigned), 256) + (size_t)grid * (8 * 2 * 4 * 20 * 64) * sizeof(f32x4);
+}
+
+template <int TTW, bool POOL>
+static int launch_w43_split3(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                             char *ws, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
+    Wino43Geom g;
+    size_t lds;
+    int64_t blocks;
+    STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
+                  "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
+    int64_t m_quads = 0;
+    int a = 4;
+    const int64_t grid = w43_split3_grid<TTW>(c, POOL, m_quads, a);
+    STITO_REQUIRE(grid > 0 && grid < (1ll << 31), STITO_E_UNSUPPORTED, "conv (six-sweep split-precision winograd): grid / cout %d", c.Cout);
+    const size_t vbytes = w43_split3_vbytes(c, m_quads);
+    unsigned *amax_ws = (unsigned *)(ws + vbytes);
+    const unsigned *amax = amax_in != nullptr ? amax_in : amax_ws;
+    f32x4 *partial = (f32x4 *)(ws + vbytes + align_up((size_t)c.S * sizeof(unsigned), 256));
+    if (amax_in == nullptr) {   // stream maxima (not supplied by the layer that produced `in`)
+        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
+        const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
+        int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
+        const int cap = (4096 + c.S - 1) / c.S;
+        splits = splits > cap ? cap : (splits < 1 ? 1 : splits);
+        hipLaunchKernelGGL(k_stream_absmax, dim3((unsigned)splits, (unsigned)c.S), dim3(256), 0, st, in, per_stream, amax_ws);
+        STITO_LAUNCH_CHECK();
+    }
+    {   // V slabs (MODE 5) of 4 * m_quads pixel blocks (a block past the map transforms to zeros)
+        Wino43Geom gv = g;
+        const int n_chunks = c.Cin / W43_K;
+        const int64_t m_blocks4 = 4 * m_quads;
+        int ncg = 1;
+        while (m_blocks4 * ncg < 1024 && n_chunks % (4 * ncg) == 0 && n_chunks / (2 * ncg) >= 4) ncg *= 2;
+        gv.n_cgroups = ncg;
+        auto kern = k_conv_wino43<TTW, POOL, false, 5>;
+        const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks4 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+                           (const float *)amax, (const float *)nullptr, (float *)ws, gv);
+        STITO_LAUNCH_CHECK();
+    }
+    auto kern = k_conv_wino43s3<TTW, POOL>;
+    const size_t lds1 = (size_t)3 * S43B_SLAB;
+    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    g.n_mblocks = (int)m_quads;
+    g.ct_group = a;
+    g.amax_out = amax_out;
+    const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    W43_CLK_ARM(g)
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                       (const unsigned *)amax, u_inv, partial);
+    STITO_LAUNCH_CHECK();
+    W43_CLK_REPORT("k_conv_wino43s3 (f16 MFMA)", c, st)
+    return STITO_OK;
+}
+
+int launch_wino43_split3(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
+                         bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in, unsigned *amax_out) {
+    const size_t need = wino43_split3_workspace_bytes(c, pool);
+    STITO_REQUIRE(need > 0 && ws != nullptr && ws_bytes >= need, STITO_E_WORKSPACE,
+                  "conv (six-sweep split-precision winograd F(4x4,3x3)): workspace have %zu need %zu", ws_bytes, need);
+    char *w = (char *)ws;
+    switch (w43_ttw(c, pool)) {
+        case 8: return pool ? launch_w43_split3<8, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split3<8, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        case 4: return pool ? launch_w43_split3<4, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split3<4, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        case 2: return pool ? launch_w43_split3<2, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split3<2, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
+        default: return pool ? launch_w43_split3<1, true>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out) : launch_w43_split3<1, false>(in, upk, scale, shift, out, c, w, st, amax_in, amax_out);
     }
 }
 

@@ -20,6 +20,7 @@ FX_FLAG_NORMALIZE_AFTER = 1  # stito_fx_desc.flags bit 0
 CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4_PRE, CONV_WINOGRAD_F4_SPLIT, CONV_WINOGRAD_F4_SPLIT2 = 0, 1, 2, 3, 4, 5
 # 6, 7: retired in ABI version 9 (split-precision experiments that never beat the kernels they were meant to replace)
 CONV_WINOGRAD_F2_REG = 8
+CONV_WINOGRAD_F4_SPLIT3 = 9
 MAX_FX_PARAMS = 32
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 

@@ -133,6 +133,11 @@ class Cnn14(nn.Module):
         # epilogue (two sweeps, the first one's outputs parked in HBM) is repaid by a third fewer bytes per MAC only when the
         # channel loop is long (measured at 512 streams: 512 -> 512 4.45 -> 4.20 ms, 2048 -> 2048 4.05 -> 3.05; 256 -> 512 2.51 -> 2.66)
         self.conv_split2_min_cin = int(os.environ.get("STITO_CONV_SPLIT2_MIN_CIN", "512"))
+        # ... and on 128 x 128 tiles in SIX sweeps (CONV_WINOGRAD_F4_SPLIT3: half the bytes per MAC again; the rows' contributions
+        # meet in a scratch area) from this many input channels up where cout % 512 == 0: measured at 512 streams 512 -> 512
+        # 3.73 -> 3.42 ms, 512 -> 1024 2.04 -> 1.92, 1024 -> 1024 3.02 -> 2.57, 1024 -> 2048 1.73 -> 1.42, 2048 -> 2048 3.02 -> 2.40
+        # (256 -> 512: 2.35 -> 2.85, the channel loop is too short for six epilogues); 0 = never
+        self.conv_split3_min_cin = int(os.environ.get("STITO_CONV_SPLIT3_MIN_CIN", "512"))
         # the 64-input-channel layers (conv_block1.conv2, conv_block2.conv1) by Winograd F(2x2,3x3) on the f16 pipe with the
         # transformed weights resident in registers and the input transform done in registers (CONV_WINOGRAD_F2_REG), unless
         # STITO_CONV_F2REG=0
@@ -189,6 +194,8 @@ class Cnn14(nn.Module):
                     algo = _hip.CONV_WINOGRAD_F4_SPLIT if split else (_hip.CONV_WINOGRAD_F4_PRE if pre else self.conv_algo)
                     if split and 0 < self.conv_split2_min_cin <= cin:
                         algo = _hip.CONV_WINOGRAD_F4_SPLIT2
+                    if split and 0 < self.conv_split3_min_cin <= cin and cout % 512 == 0:
+                        algo = _hip.CONV_WINOGRAD_F4_SPLIT3
                     if self.conv_algo == _hip.CONV_WINOGRAD_F4 and self.conv_split and self.conv_f2reg and cin == 64 and cout % 64 == 0:
                         algo = _hip.CONV_WINOGRAD_F2_REG
                     upk = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), dtype=torch.float32, device=dev)

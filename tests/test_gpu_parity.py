@@ -347,10 +347,13 @@ CONV_CASES = [  # (n, H, W, cin, cout, pool)
     # the register-resident F(2x2,3x3) kernel (algo 8): the bench maps of conv_block1.conv2 / conv_block2.conv1, widths that are not
     # multiples of its 32-pixel groups, odd sizes with and without pooling, one-pixel-wide and one-row maps
     (1, 469, 128, 64, 64, 1), (2, 234, 64, 64, 128, 0), (2, 37, 50, 64, 64, 0), (3, 11, 33, 64, 192, 1), (2, 1, 70, 64, 64, 0), (2, 9, 1, 64, 64, 0),
+    # the six-sweep kernel (algo 9, cout % 512 == 0): pixel-block quads that end inside the batch, 64 .. 192 input channels (2 .. 6 channel
+    # groups per sweep), pooled odd maps, more quads than one XCD round
+    (5, 14, 4, 512, 512, 0), (3, 29, 8, 192, 512, 1), (9, 9, 16, 64, 1024, 0), (40, 13, 7, 128, 512, 1), (2, 58, 16, 512, 512, 1),
 ]
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 8, 9])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", CONV_CASES)
 def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     from st_ito import _hip
@@ -382,7 +385,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     out = torch.full(ref.shape, float("nan"), device=dev, dtype=torch.float32)
     sd, hd = scale.to(dev), shift.to(dev)
     wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, algo)
-    assert (wsb > 0) == (algo in (3, 4, 5, 8))
+    assert (wsb > 0) == (algo in (3, 4, 5, 8, 9))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
                                           n, H, W, cin, cout, pool, algo, _hip.ptr(ws), wsb, st))
@@ -397,7 +400,7 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
                                        n, H, W, cin, cout, pool, 3, st) == _hip.E_WORKSPACE  # no workspace, no launch
     err = (got - ref).abs().max().item()
     print(f"conv algo {algo} {n}x{H}x{W} {cin}->{cout} pool={pool}: max err {err:.3e} (ref max {ref.abs().max().item():.2f})")
-    if algo in (4, 5, 8):
+    if algo in (4, 5, 8, 9):
         assert L.stito_conv3x3_bn_relu(_hip.ptr(xd), _hip.ptr(packed), _hip.ptr(sd), _hip.ptr(hd), _hip.ptr(out),
                                        n, H, W, cin, cout, pool, algo, st) == _hip.E_WORKSPACE  # no workspace, no launch
     # F(4x4,3x3): random SIGNED inputs are the worst case for the cancellation in its output transform (3.3e-5 of the
@@ -406,9 +409,9 @@ def test_conv_layer_vs_torch(dev, n, H, W, cin, cout, pool, algo):
     assert err < tol * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
 
 
-@pytest.mark.parametrize("algo", [4, 5, 8])
+@pytest.mark.parametrize("algo", [4, 5, 8, 9])
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", [(6, 14, 4, 512, 512, 0), (5, 29, 8, 256, 512, 1), (9, 58, 16, 64, 256, 0),
-                                                 (7, 21, 32, 64, 64, 1), (12, 6, 16, 128, 64, 0)])
+                                                 (7, 21, 32, 64, 64, 1), (12, 6, 16, 128, 64, 0), (13, 14, 4, 1024, 1024, 0)])
 def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
     """STITO_CONV_WINOGRAD_F4_SPLIT carries every operand as f16 hi + lo of a power-of-two multiple of itself; the
     multiple is chosen per stream from the stream's own largest activation.  Streams 1e4 and 1e-4 times the others, an
@@ -417,9 +420,8 @@ def test_conv_split_stream_scales(dev, n, H, W, cin, cout, pool, algo):
     overflow, no loss on the quiet streams), and bitwise independent of what else is in the batch."""
     from st_ito import _hip
     L = _hip.lib()
-    if (algo == 8 or cout < 256) and not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
-        pytest.skip("the in-kernel-transform split kernel only stages maps at least 4 tiles wide, the direct one maps at least 16 "
-                    "pixels wide, the streaming ones 256-channel outputs")
+    if (algo == 8 or cout < 256 or (algo == 9 and cout % 512)) and not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo):
+        pytest.skip("the register-resident kernel takes 64 input channels, the streaming ones outputs in multiples of 256 channels (six sweeps: 512)")
     assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)
     g = torch.Generator().manual_seed(H * 7 + cin)
     x = torch.relu(torch.randn((n, cin, H, W), generator=g))
@@ -514,7 +516,7 @@ def test_conv_f2reg_persistent_loop(dev, n, H, W, cout, pool, wgs, monkeypatch):
 
 # (H, W, cin, cout, pool, algorithms): the deep layers where the streaming kernels keep three slabs of LDS-DMA copies in flight
 # (the copies complete out of issue order: csrc/conv_wino43.hip header), and the persistent register-resident kernel
-RACE_CASES = [(14, 4, 2048, 2048, 0, (2, 3, 5)), (29, 8, 512, 1024, 1, (2, 3, 5)), (58, 16, 512, 512, 1, (2, 3, 4, 5)),
+RACE_CASES = [(14, 4, 2048, 2048, 0, (2, 3, 5, 9)), (29, 8, 512, 1024, 1, (2, 3, 5, 9)), (58, 16, 512, 512, 1, (2, 3, 4, 5, 9)),
               (117, 32, 256, 256, 1, (2, 4)), (117, 32, 128, 256, 0, (2, 4)), (234, 64, 64, 128, 0, (2, 8)), (469, 128, 64, 64, 1, (8,))]
 
 
@@ -710,7 +712,7 @@ def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
         algos = [int(W.conv_wino_algo[i]) for i in range(12)]
         if pre == "split":
             assert algos[1:3] == [_hip.CONV_WINOGRAD_F2_REG] * 2 and algos[3] == _hip.CONV_WINOGRAD_F4   # the 64-input-channel layers: register-resident F(2x2,3x3)
-            assert algos[4:7] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 3 and algos[7:] == [_hip.CONV_WINOGRAD_F4_SPLIT2] * 5
+            assert algos[4:7] == [_hip.CONV_WINOGRAD_F4_SPLIT] * 3 and algos[7:] == [_hip.CONV_WINOGRAD_F4_SPLIT3] * 5   # from 512 input channels: 128 x 128 tiles in six sweeps
         else:
             assert algos[1:6] == [_hip.CONV_WINOGRAD_F4] * 5
             assert algos[6:] == [_hip.CONV_WINOGRAD_F4_PRE if pre else _hip.CONV_WINOGRAD_F4] * 6

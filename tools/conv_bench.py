@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames", type=int, default=469)
-    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 5 = 4 on 64 x 64 tiles in two sweeps, 8 = F(2x2,3x3) with register-resident weights (64 input channels; production mix elsewhere), 9 = production mix (cout >= 256: 5 from cin 512 up, else 4; below: 2)")
+    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 5 = 4 on 64 x 64 tiles in two sweeps, 8 = F(2x2,3x3) with register-resident weights (64 input channels; production mix elsewhere), 9 = the same on 128 x 128 tiles in six sweeps (cout % 512 == 0; production mix elsewhere), 99 = production mix (cout >= 256: 5 from cin 512 up, else 4; below: 2)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--max-cin", type=int, default=1 << 30, help="only the layers with at most this many input channels")
     a = ap.parse_args()
@@ -26,11 +26,13 @@ def main():
     dev = torch.device("cuda", 0)
     st = _hip.stream_ptr()
     rows = [r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 0 and r["cin"] <= a.max_cin]
-    # mode 9 = the production mix of st_ito/models/panns.py: algo 4 for cout >= 512 (3 where 4 does not cover the shape), algo 2 below
+    # mode 99 = the production mix of st_ito/models/panns.py: algo 4 for cout >= 512 (3 where 4 does not cover the shape), algo 2 below
     modes = [int(m) for m in a.modes.split(",")]
     def algo_of(m, r):
-        if m == 9:
+        if m == 99:
             m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2
+        if m == 9 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 9):
+            m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2  # six sweeps: cout % 512 == 0 only
         if m == 8 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 8):
             m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2  # register-resident F(2x2,3x3): 64 input channels only
         if m in (4, 5) and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m):

@@ -27,7 +27,7 @@ for case in range(a.cases):
     sc = (0.5 + torch.rand(cout, generator=g)).to(dev); sh = (0.1 * torch.randn(cout, generator=g)).to(dev)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     ref = None
-    for m in (0, 1, 2, 3, 4, 5, 8):
+    for m in (0, 1, 2, 3, 4, 5, 8, 9):
         if not L.stito_conv3x3_supported(n, H, W, cin, cout, pool, m):
             continue
         packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, m), device=dev)

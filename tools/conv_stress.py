@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--streams", type=int, default=512)
 ap.add_argument("--frames", type=int, default=469)
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--modes", default="2,3,4,5,8")
+ap.add_argument("--modes", default="2,3,4,5,8,9")
 ap.add_argument("--layers", default="")
 a = ap.parse_args()
 L = _hip.lib(); dev = torch.device("cuda", 0); st = _hip.stream_ptr()

@@ -26,7 +26,7 @@ cd $R
 timeout 1200 python tools/run_configs.py --steps 3 2>&1 | grep -v "^[A-Za-z0-9]*: [a-z_]* = \|^$" > gpurun_out/r4p/run_configs.txt
 timeout 400 python tools/trunk_accuracy.py > gpurun_out/r4p/trunk_accuracy.txt 2>&1
 # 6. race hunt on the shipped conv kernels (every layer shape at 512 streams, 10 launches per algorithm) and random shapes
-(echo "# python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8"; timeout 900 python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8 2>&1 | grep -v amdgpu.ids) > gpurun_out/r4p/conv_stress.txt
+(echo "# python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8,9"; timeout 900 python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8,9 2>&1 | grep -v amdgpu.ids) > gpurun_out/r4p/conv_stress.txt
 (echo "# python tools/conv_fuzz.py --cases 150 --seed 4"; timeout 600 python tools/conv_fuzz.py --cases 150 --seed 4 2>&1 | grep -v amdgpu.ids) > gpurun_out/r4p/conv_fuzz.txt
 # 7. LDS / issue counters of the conv kernels (three separate PMC passes, kernel trace only), production mix (conv_bench mode 8)
 cd /tmp
