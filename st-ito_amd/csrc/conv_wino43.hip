@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 // alternate periods as above; two periods per 16 channels.  MFMA A operand = weights (rows = couts), B = input (columns =
 // tiles): a lane's accumulator quad = 4 consecutive couts of ITS tile, 16-byte partial-sum accesses and stores fall out.
 #ifndef S43C_ABL
-#define S43C_ABL 0  // timing experiment (k_conv_wino43s3): 1 = no epilogues, 2 = no main loops; 0 in every build that ships
+#define S43C_ABL 0  // timing experiment (k_conv_wino43s3): 1 = no epilogues, 2 = no main loops, 4 = no partial stores, 8 = no partial loads; 0 in every build that ships
 #endif
 __device__ __forceinline__ const char *w43_uniform(const char *p) {
     const uint64_t v = (uint64_t)(uintptr_t)p;
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
 #define S43C_PERIOD(KK, SL, BUF_)                                                                        \
     {                                                                                                    \
         const bool mine_ = set == (KK);                                                                   \
-        if (mine_ && (SL) + 2 < nP) { const int nb_ = (BUF_) + 2 >= 3 ? (BUF_) - 1 : (BUF_) + 2; S43C_ISSUE((SL) + 2, nb_) } \
+        if (mine_ && (SL) + 2 < 6 * nP) { const int nb_ = (BUF_) + 2 >= 3 ? (BUF_) - 1 : (BUF_) + 2; S43C_ISSUE((SL) + 2, nb_) } \
         const char *pv_ = v_rd + (BUF_) * S43B_SLAB, *pu_ = u_rd + (BUF_) * S43B_SLAB;                    \
         _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                \
             const h8 uh_ = *(const h8 *)(pu_ + q_ * 8192), ul_ = *(const h8 *)(pu_ + q_ * 8192 + 4096);    \
@@ -1198,22 +1198,23 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
         t_tr[blk] = tr;
     }
 
+    // (the 64-bit products are VALU work: back into scalar registers by hand -- hipcc hands an "s" asm operand a VGPR pair otherwise)
+    const char *vw = w43_uniform(vsl + (int64_t)m_quad * 6 * nP * S43B_PART + w4 * 1024);
+    const char *uw = w43_uniform(usl + (int64_t)ct * 6 * nP * S43B_PART + w4 * 1024);
+    if (set == 0) { S43C_ISSUE(0, 0) } else { S43C_ISSUE(1, 1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W43_BARRIER()
+    int buf = 0;
 #pragma unroll 1
     for (int sweep = 0; sweep < 6; ++sweep) {
-        const int row = sweep;
-        // (the 64-bit products are VALU work: back into scalar registers by hand -- hipcc hands an "s" asm operand a VGPR pair otherwise)
-        const char *vw = w43_uniform(vsl + ((int64_t)m_quad * 6 + row) * nP * S43B_PART + w4 * 1024);
-        const char *uw = w43_uniform(usl + ((int64_t)ct * 6 + row) * nP * S43B_PART + w4 * 1024);
 #pragma unroll
         for (int q = 0; q < 12; ++q)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
-        W43_BARRIER()
-        if (set == 0) { S43C_ISSUE(0, 0) } else { S43C_ISSUE(1, 1) }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W43_BARRIER()
-        int buf = 0;
-        for (int sl = 0; sl < ((S43C_ABL & 2) ? 0 : nP); sl += 2) {   // nP % 2 == 0; the ring position is a run-time value (three loop bodies for it cost registers)
+        // the six rows' slabs follow one another in both streams: ONE stream of 6 nP periods, the ring keeps filling through the
+        // epilogues (which touch neither LDS nor barriers); nP % 2 == 0; the ring position is a run-time value (three loop bodies
+        // for it cost registers)
+        for (int sl = sweep * nP; sl < ((S43C_ABL & 2) ? 0 : (sweep + 1) * nP); sl += 2) {
             S43C_PERIOD(0, sl, buf)
             buf = buf == 2 ? 0 : buf + 1;
             S43C_PERIOD(1, sl + 1, buf)
@@ -1229,76 +1230,93 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
             if (s_ == 12345.f) out[tid] = s_;
             continue;
         }
+#define S43C_Z(BLK, GQ, Z_)   /* element by element straight from the accumulator registers (vector temporaries of them are copies) */ \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+            const float m0 = acc[0 + (BLK)][4 * (GQ) + e], m1 = acc[2 + (BLK)][4 * (GQ) + e], m2 = acc[4 + (BLK)][4 * (GQ) + e], \
+                        m3 = acc[6 + (BLK)][4 * (GQ) + e], m4 = acc[8 + (BLK)][4 * (GQ) + e], m5 = acc[10 + (BLK)][4 * (GQ) + e]; \
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;                       \
+            Z_[0][e] = (m0 + s12) + s34;                                                                  \
+            Z_[1][e] = 2.f * d34 + d12;                                                                   \
+            Z_[2][e] = 4.f * s34 + s12;                                                                   \
+            Z_[3][e] = (8.f * d34 + d12) + m5;                                                            \
+        }
+        if (sweep < 5) {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+            for (int bg = 0; bg < 8; ++bg) {
+                W43_FENCE()
+                f32x4 Z[4];
+                S43C_Z(bg >> 2, bg & 3, Z)
+                f32x4 *pt = my_partial + bg * (5 * 4 * 64);   // [row 0..4][c][lane]
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                W43_FENCE()   // one (tile panel, cout quad) at a time: hipcc otherwise hoists every load of the sweep (scratch)
-                f32x4 m[6], Z[4];
+                for (int c = 0; c < 4; ++c) {
+                    if (S43C_ABL & 4) { if (Z[c][0] == 12345.f) pt[(sweep * 4 + c) * 64] = Z[c]; }   // timing builds: no partial stores
+                    else pt[(sweep * 4 + c) * 64] = Z[c];
+                }
+            }
+        } else {
+            // the last row: all eight Z sets first (the accumulators are dead behind them: 128 registers for the loads that follow --
+            // a (panel, quad)'s twenty stored values in flight at once; five at a time was 32 dependent round trips to HBM per workgroup)
+            f32x4 Zl[8][4];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = (f32x4){acc[2 * j + blk][4 * gq], acc[2 * j + blk][4 * gq + 1], acc[2 * j + blk][4 * gq + 2], acc[2 * j + blk][4 * gq + 3]};
-                const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-                Z[0] = (m[0] + s12) + s34;
-                Z[1] = 2.f * d34 + d12;
-                Z[2] = 4.f * s34 + s12;
-                Z[3] = (8.f * d34 + d12) + m[5];
-                f32x4 *pt = my_partial + (blk * 4 + gq) * (5 * 4 * 64);   // [row 0..4][c][lane]
-                if (sweep < 5) {
+            for (int bg = 0; bg < 8; ++bg) { S43C_Z(bg >> 2, bg & 3, Zl[bg]) }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) pt[(sweep * 4 + c) * 64] = Z[c];
-                } else {
-                    const int co = ct * 128 + cq * 32 + 8 * gq + 4 * oct;
-                    f32x4 sc = *(const f32x4 *)(scale + co);
-                    const f32x4 sh = *(const f32x4 *)(shift + co);
-                    unsigned smax = 0;
-                    const int s_ = t_s[blk], tr = t_tr[blk], tc = t_tc[blk];
-                    if (t_ok[blk]) sc = sc * (u_inv / w43s_vscale(amax[s_]));
+            for (int bg = 0; bg < 8; ++bg) {
+                W43_FENCE()
+                const int blk = bg >> 2, gq = bg & 3;
+                const f32x4 *pt = my_partial + bg * (5 * 4 * 64);
+                f32x4 zr[5][4];
 #pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) {
-                        f32x4 y[2][4];   // [column 2 pc + cc][output row]
+                for (int i = 0; i < 5; ++i)
 #pragma unroll
-                        for (int cc = 0; cc < 2; ++cc) {
-                            W43_FENCE()
-                            const int c = 2 * pc + cc;
-                            const f32x4 z0 = pt[(0 * 4 + c) * 64], z1 = pt[(1 * 4 + c) * 64], z2 = pt[(2 * 4 + c) * 64], z3 = pt[(3 * 4 + c) * 64],
-                                        z4 = pt[(4 * 4 + c) * 64];
-                            const f32x4 p12 = z1 + z2, q12 = z1 - z2, p34 = z3 + z4, q34 = z3 - z4;
-                            y[cc][0] = (z0 + p12) + p34;
-                            y[cc][1] = 2.f * q34 + q12;
-                            y[cc][2] = 4.f * p34 + p12;
-                            y[cc][3] = (8.f * q34 + q12) + Z[c];
+                    for (int c = 0; c < 4; ++c) zr[i][c] = (S43C_ABL & 8) ? Zl[bg][c] : pt[(i * 4 + c) * 64];   // (timing builds: no partial loads)
+                const int co = ct * 128 + cq * 32 + 8 * gq + 4 * oct;
+                f32x4 sc = *(const f32x4 *)(scale + co);
+                const f32x4 sh = *(const f32x4 *)(shift + co);
+                unsigned smax = 0;
+                const int s_ = t_s[blk], tr = t_tr[blk], tc = t_tc[blk];
+                if (t_ok[blk]) sc = sc * (u_inv / w43s_vscale(amax[s_]));
 #pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) y[cc][rr] = __builtin_elementwise_max(y[cc][rr] * sc + sh, (f32x4)(0.0f));
-                        }
-                        if (t_ok[blk]) {
-                            if (POOL) {
+                for (int pc = 0; pc < 2; ++pc) {
+                    f32x4 y[2][4];   // [column 2 pc + cc][output row]
 #pragma unroll
-                                for (int pr = 0; pr < 2; ++pr) {
-                                    const int oh = 2 * tr + pr, ow = 2 * tc + pc;
-                                    if (oh < g.Ho && ow < g.Wo) {
-                                        const f32x4 v = (((y[0][2 * pr] + y[1][2 * pr]) + y[0][2 * pr + 1]) + y[1][2 * pr + 1]) * 0.25f;
-                                        *(f32x4 *)(out + act_off(s_, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
-                                        smax = max(smax, w43_max4(v));
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int c = 2 * pc + cc;
+                        const f32x4 p12 = zr[1][c] + zr[2][c], q12 = zr[1][c] - zr[2][c], p34 = zr[3][c] + zr[4][c], q34 = zr[3][c] - zr[4][c];
+                        y[cc][0] = (zr[0][c] + p12) + p34;
+                        y[cc][1] = 2.f * q34 + q12;
+                        y[cc][2] = 4.f * p34 + p12;
+                        y[cc][3] = (8.f * q34 + q12) + Zl[bg][c];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) y[cc][rr] = __builtin_elementwise_max(y[cc][rr] * sc + sh, (f32x4)(0.0f));
+                    }
+                    if (t_ok[blk]) {
+                        if (POOL) {
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {
+                                const int oh = 2 * tr + pr, ow = 2 * tc + pc;
+                                if (oh < g.Ho && ow < g.Wo) {
+                                    const f32x4 v = (((y[0][2 * pr] + y[1][2 * pr]) + y[0][2 * pr + 1]) + y[1][2 * pr + 1]) * 0.25f;
+                                    *(f32x4 *)(out + act_off(s_, co, oh, ow, g.Cout, g.Ho, g.Wo)) = v;
+                                    smax = max(smax, w43_max4(v));
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr) {
+                                    const int hh = 4 * tr + rr, ww = 4 * tc + 2 * pc + cc;
+                                    if (hh < g.H && ww < g.W) {
+                                        *(f32x4 *)(out + act_off(s_, co, hh, ww, g.Cout, g.H, g.W)) = y[cc][rr];
+                                        smax = max(smax, w43_max4(y[cc][rr]));
                                     }
                                 }
-                            } else {
-#pragma unroll
-                                for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                                    for (int rr = 0; rr < 4; ++rr) {
-                                        const int hh = 4 * tr + rr, ww = 4 * tc + 2 * pc + cc;
-                                        if (hh < g.H && ww < g.W) {
-                                            *(f32x4 *)(out + act_off(s_, co, hh, ww, g.Cout, g.H, g.W)) = y[cc][rr];
-                                            smax = max(smax, w43_max4(y[cc][rr]));
-                                        }
-                                    }
-                            }
                         }
                     }
-                    // amax_out[s] only grows: a (possibly stale) agent-scope load that already covers smax makes the atomic unnecessary
-                    if (g.amax_out != nullptr && t_ok[blk] && smax > __hip_atomic_load(g.amax_out + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        atomicMax(g.amax_out + s_, smax);
                 }
+                // amax_out[s] only grows: a (possibly stale) agent-scope load that already covers smax makes the atomic unnecessary
+                if (g.amax_out != nullptr && t_ok[blk] && smax > __hip_atomic_load(g.amax_out + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    atomicMax(g.amax_out + s_, smax);
             }
         }
     }
