@@ -22,6 +22,7 @@ python $R/profiles/summarize_rocprof.py $R/gpurun_out/r4p/prof/*/*_results.db > 
 cd $R
 # 4. micro-benchmarks (numerics of the operand split, f16 MFMA rate, LDS fill under the sharing patterns)
 (cd tools/ubench && [ -x split_mfma ] || hipcc --offload-arch=gfx950 -O3 split_mfma.hip -o split_mfma -w; timeout 200 ./split_mfma 7 > ../../gpurun_out/r4p/split_mfma_ubench.txt 2>&1)
+(cd tools/ubench && [ -x s3_loop ] || hipcc --offload-arch=gfx950 -O3 s3_loop.hip -o s3_loop -w; (echo "# tools/ubench/s3_loop 2048; s3_loop 1024   (main-loop prototype of the 128 x 128 six-sweep tile; all-zero operands: the part holds ~2.15 GHz here, ~1.6 under real data)"; timeout 200 ./s3_loop 2048; timeout 200 ./s3_loop 1024) > ../../gpurun_out/r4p/s3_loop_ubench.txt 2>&1)
 # 5. all configs (the five of BASELINE.json + the reference's own operating points) + trunk accuracy
 timeout 1200 python tools/run_configs.py --steps 3 2>&1 | grep -v "^[A-Za-z0-9]*: [a-z_]* = \|^$" > gpurun_out/r4p/run_configs.txt
 timeout 400 python tools/trunk_accuracy.py > gpurun_out/r4p/trunk_accuracy.txt 2>&1
