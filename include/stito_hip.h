@@ -245,6 +245,13 @@ typedef struct {
     const float *conv1_f2reg_w_dev; /* stito_cnn14_pack_conv1_f2reg, or NULL (ABI v8).  With it and a
                                        STITO_CONV_WINOGRAD_F2_REG packing of conv index 1 the forward runs conv_block1 as ONE
                                        launch (stito_conv_block1_f2reg): the 64-channel full-resolution map is never stored */
+    /* ABI v9: a second packing per conv (or NULL) for the calls in which the first one's kernel would not fill the device.
+     * Today: conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT3 with conv_alt_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 -- the
+     * six-sweep kernel's workgroups are four times larger, so a small batch (fewer than 3/4 workgroup per CU) runs the
+     * two-sweep kernel instead; results differ at float32 rounding level between the two (both inside the parity bar), a
+     * given batch size always takes the same one. */
+    const float *conv_alt_dev[STITO_CNN14_NUM_CONVS];
+    int32_t conv_alt_algo[STITO_CNN14_NUM_CONVS];
 } stito_cnn14_weights;
 
 /* Number of floats of a packed conv weight for (cout, cin) and algorithm. */

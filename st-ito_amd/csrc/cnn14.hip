@@ -1275,7 +1275,11 @@ static size_t cnn14_pre_bytes(const stito_cnn14_weights *w, int n_streams, const
                                                algo != STITO_CONV_WINOGRAD_F2_REG)) continue;
         const int blk = i / 2, j = i % 2;
         const int ci = j == 0 ? w->channels[blk] : w->channels[blk + 1], pool = (j == 1 && blk < 5) ? 1 : 0;
-        const size_t need = stito_conv3x3_workspace_bytes(n_streams, H[blk], W[blk], ci, w->channels[blk + 1], pool, algo);
+        size_t need = stito_conv3x3_workspace_bytes(n_streams, H[blk], W[blk], ci, w->channels[blk + 1], pool, algo);
+        if (w->conv_alt_dev[i] != nullptr) {
+            const size_t alt = stito_conv3x3_workspace_bytes(n_streams, H[blk], W[blk], ci, w->channels[blk + 1], pool, w->conv_alt_algo[i]);
+            need = alt > need ? alt : need;
+        }
         v = need > v ? need : v;
     }
     if (w->conv1_f2reg_w_dev != nullptr && w->channels[0] == 1) {   // conv_block1 in one launch: per-stream scales of the log-mel operand
@@ -1376,6 +1380,12 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     STITO_HIP_CHECK(hipMemsetAsync(amax_all, 0, amax_stride * STITO_CNN14_NUM_CONVS, st));
     const unsigned *amax_have = nullptr;  // maxima of the current input, if its producer reported them
 
+    int n_cus = 256;
+    {
+        int dev_ = 0;
+        STITO_HIP_CHECK(hipGetDevice(&dev_));
+        STITO_HIP_CHECK(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_));
+    }
     const float *cur = logmel_dev;
     // conv_block1 as one launch on the register-resident F(2x2,3x3) kernel, which computes the first conv into its patch ring
     const bool fuse1r = w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
@@ -1423,7 +1433,14 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                             ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;  // (a split packing has no float32 fallback: the direct kernel takes over)
             if (walgo == STITO_CONV_WINOGRAD_F4_PRE && !stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo))
                 walgo = STITO_CONV_WINOGRAD_F4;  // same packing
-            const bool wino = w->conv_wino_dev[i] != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
+            const float *wino_w = w->conv_wino_dev[i];
+            if (walgo == STITO_CONV_WINOGRAD_F4_SPLIT3 && w->conv_alt_dev[i] != nullptr && w->conv_alt_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+                4 * wino43_split3_workgroups(ConvShape{S, H[blk], W[blk], ci, cout}, pool != 0) < 3 * n_cus &&
+                stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, STITO_CONV_WINOGRAD_F4_SPLIT2)) {
+                walgo = STITO_CONV_WINOGRAD_F4_SPLIT2;   // too few of the large workgroups for this batch: the alternative packing
+                wino_w = w->conv_alt_dev[i];
+            }
+            const bool wino = wino_w != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
             const bool timed = g_conv_timing.on && ci % 8 == 0;
             if (timed) {
                 if (g_conv_timing.used == g_conv_timing.pool.size()) {
@@ -1449,7 +1466,7 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
                     amax_out = (unsigned *)((char *)amax_all + amax_stride * i);
                 }
             }
-            const int rc = conv3x3_ws(j == 0 ? cur : actA, wino ? w->conv_wino_dev[i] : w->conv_w_dev[i], w->bn_scale_dev[i],
+            const int rc = conv3x3_ws(j == 0 ? cur : actA, wino ? wino_w : w->conv_w_dev[i], w->bn_scale_dev[i],
                                       w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
                                       algo_i, vbuf, vbytes, stream, amax_have, amax_out);
             if (rc) return rc;

@@ -98,6 +98,7 @@ int launch_wino43_split2(const float *in, const float *upk, const float *scale, 
 bool wino43_split3_supported(const ConvShape &c, bool pool);   // six sweeps, 128 x 128 workgroup tiles (cout % 512 == 0)
 size_t wino43_split3_workspace_bytes(const ConvShape &c, bool pool);
 double wino43_split3_issued_flops(const ConvShape &c, bool pool);
+int64_t wino43_split3_workgroups(const ConvShape &c, bool pool);
 int launch_wino43_split3(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                          bool pool, void *ws, size_t ws_bytes, hipStream_t st, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int launch_wino43_split(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,

@@ -1900,6 +1900,16 @@ double wino43_split3_issued_flops(const ConvShape &c, bool pool) {
     return 3.0 * 2.0 * (double)m_quads * (c.Cout / 128) * 128.0 * 128.0 * 36.0 * c.Cin;
 }
 
+// workgroups of the six-sweep kernel that have work (pixel-block quads x 128-cout tiles): below about one per CU the two-sweep
+// kernel's four times as many, four times shorter workgroups finish sooner (stito_cnn14_forward's choice per call)
+int64_t wino43_split3_workgroups(const ConvShape &c, bool pool) {
+    if (!wino43_split3_supported(c, pool)) return 0;
+    int64_t m_quads = 0;
+    int a;
+    if (w43_split3_grid_any(c, pool, m_quads, a) <= 0) return 0;
+    return m_quads * (c.Cout / 128);
+}
+
 static size_t w43_split3_vbytes(const ConvShape &c, int64_t m_quads) { return align_up((size_t)m_quads * 6 * (size_t)(c.Cin >> 3) * S43B_PART, 256); }
 
 size_t wino43_split3_workspace_bytes(const ConvShape &c, bool pool) {

@@ -52,6 +52,7 @@ class Cnn14Weights(Structure):
         ("fc_side_wt_dev", c_void_p), ("fc_side_b_dev", c_void_p),
         ("reserved_ptr", c_void_p),
         ("conv1_f2reg_w_dev", c_void_p),
+        ("conv_alt_dev", c_void_p * 12), ("conv_alt_algo", c_int32 * 12),
     ]
 
 

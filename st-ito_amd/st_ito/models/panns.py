@@ -203,6 +203,14 @@ class Cnn14(nn.Module):
                     W.conv_wino_dev[2 * b + j] = upk.data_ptr()
                     W.conv_wino_algo[2 * b + j] = algo
                     keep.append(upk)
+                    if algo == _hip.CONV_WINOGRAD_F4_SPLIT3:
+                        # small batches (fewer than 3 / 4 of the six-sweep kernel's workgroups per CU: a population of 32 has 32 of
+                        # them for conv_block6) run the two-sweep kernel: its packing rides along (stito_cnn14_forward chooses per call)
+                        alt = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, _hip.CONV_WINOGRAD_F4_SPLIT2), dtype=torch.float32, device=dev)
+                        _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, _hip.CONV_WINOGRAD_F4_SPLIT2, _hip.ptr(alt), st))
+                        W.conv_alt_dev[2 * b + j] = alt.data_ptr()
+                        W.conv_alt_algo[2 * b + j] = _hip.CONV_WINOGRAD_F4_SPLIT2
+                        keep.append(alt)
                 scale = torch.empty(cout, dtype=torch.float32, device=dev)
                 shift = torch.empty(cout, dtype=torch.float32, device=dev)
                 if isinstance(bn, nn.BatchNorm2d):

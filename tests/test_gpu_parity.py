@@ -727,6 +727,32 @@ def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
             assert rel < 5e-6, rel
 
 
+def test_trunk_small_batches_take_the_two_sweep_packing(dev):
+    """The six-sweep kernel's workgroups are four times the two-sweep kernel's: a batch that gives it fewer than 3 / 4 workgroup per
+    CU (anything below ~380 streams for conv_block6) runs the two-sweep kernel from the alternative packing the model carries
+    (stito_cnn14_weights.conv_alt_dev, ABI v9) -- bitwise what a model without the six-sweep packing computes."""
+    from st_ito import _hip
+    from st_ito.models.panns import Cnn14
+    om = O.fill_deterministic(O.Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "batchnorm"), 0).eval()
+    outs = {}
+    for kind in ("default", "two-sweep only"):
+        pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "batchnorm")
+        pm.load_state_dict(om.state_dict())
+        pm.eval().to(dev)
+        if kind != "default":
+            pm.conv_split3_min_cin = 0
+        W, _, _ = pm._ensure()
+        for i in range(7, 12):
+            if kind == "default":
+                assert int(W.conv_wino_algo[i]) == _hip.CONV_WINOGRAD_F4_SPLIT3 and W.conv_alt_dev[i] and int(W.conv_alt_algo[i]) == _hip.CONV_WINOGRAD_F4_SPLIT2
+            else:
+                assert int(W.conv_wino_algo[i]) == _hip.CONV_WINOGRAD_F4_SPLIT2 and not W.conv_alt_dev[i]
+        x = torch.stack([O.synth_audio(70 + i, 2, 240000) for i in range(4)])
+        outs[kind] = [t.clone() for t in pm(x.to(dev))]
+    for a, b in zip(outs["default"], outs["two-sweep only"]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("norm", ["batchnorm", "minmax", "none"])
 def test_trunk_block1_one_launch_is_the_default_and_matches_two_launches(dev, norm):
     """The default trunk runs conv_block1 as ONE launch (conv1_f2reg_w_dev set -> stito_cnn14_forward calls
