@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--frames", type=int, default=469)
-    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 5 = 4 on 64 x 64 tiles in two sweeps, 8 = F(2x2,3x3) with register-resident weights (64 input channels; production mix elsewhere), 9 = the same on 128 x 128 tiles in six sweeps (cout % 512 == 0; production mix elsewhere), 99 = production mix (cout >= 256: 5 from cin 512 up, else 4; below: 2)")
+    ap.add_argument("--modes", default="0,1", help="conv algorithms: 0 direct, 1 winograd F(2x2,3x3), 2 winograd F(4x4,3x3), 3 = 2 with the input transform hoisted, 4 = 3 on the f16 pipe with split operands, 5 = 4 on 64 x 64 tiles in two sweeps, 8 = F(2x2,3x3) with register-resident weights (64 input channels; production mix elsewhere), 9 = the same on 128 x 128 tiles in six sweeps (cout % 512 == 0; production mix elsewhere), 99 = round 3's mix (cout >= 256: 5 from cin 512 up, else 4; below: 2), 100 = the production mix (8 on 64 input channels, 9 from 512 input channels, else as 99)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--max-cin", type=int, default=1 << 30, help="only the layers with at most this many input channels")
     a = ap.parse_args()
@@ -26,15 +26,17 @@ def main():
     dev = torch.device("cuda", 0)
     st = _hip.stream_ptr()
     rows = [r for r in conv_layer_table(a.frames) if r["cin"] % 8 == 0 and r["cin"] <= a.max_cin]
-    # mode 99 = the production mix of st_ito/models/panns.py: algo 4 for cout >= 512 (3 where 4 does not cover the shape), algo 2 below
+    # mode 100 = the production mix of st_ito/models/panns.py: 8 on the 64-input-channel layers, 9 from 512 input channels where cout % 512 == 0,
+    # else 5 from 512 input channels, 4 from 256 output channels, 2 below; mode 99 = the streaming kernels of round 3 (5 / 4 / 2) -- what the
+    # modes 8 and 9 fall back to where they do not cover a shape, so that either is measured against the kernels it replaced
     modes = [int(m) for m in a.modes.split(",")]
+    def sup(r, m): return L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m)
     def algo_of(m, r):
-        if m == 99:
-            m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2
-        if m == 9 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 9):
-            m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2  # six sweeps: cout % 512 == 0 only
-        if m == 8 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 8):
-            m = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2  # register-resident F(2x2,3x3): 64 input channels only
+        old_mix = (5 if r["cin"] >= 512 else 4) if r["cout"] >= 256 else 2
+        if m == 100:
+            m = 8 if sup(r, 8) else (9 if r["cin"] >= 512 and sup(r, 9) else old_mix)
+        if m == 99 or (m in (8, 9) and not sup(r, m)):
+            m = old_mix
         if m in (4, 5) and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], m):
             m = 3
         if m == 3 and not L.stito_conv3x3_supported(a.streams, r["H"], r["W"], r["cin"], r["cout"], r["pool"], 3):

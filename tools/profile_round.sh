@@ -29,11 +29,11 @@ timeout 400 python tools/trunk_accuracy.py > gpurun_out/r4p/trunk_accuracy.txt 2
 # 6. race hunt on the shipped conv kernels (every layer shape at 512 streams, 10 launches per algorithm) and random shapes
 (echo "# python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8,9"; timeout 900 python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8,9 2>&1 | grep -v amdgpu.ids) > gpurun_out/r4p/conv_stress.txt
 (echo "# python tools/conv_fuzz.py --cases 150 --seed 4"; timeout 600 python tools/conv_fuzz.py --cases 150 --seed 4 2>&1 | grep -v amdgpu.ids) > gpurun_out/r4p/conv_fuzz.txt
-# 7. LDS / issue counters of the conv kernels (three separate PMC passes, kernel trace only), production mix (conv_bench mode 8)
+# 7. LDS / issue counters of the conv kernels (three separate PMC passes, kernel trace only), production mix (conv_bench mode 100)
 cd /tmp
 for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   d=$R/gpurun_out/r4p/ldspmc_$(echo $set | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python $R/tools/conv_bench.py --streams 512 --modes 8 --reps 1 > $d.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python $R/tools/conv_bench.py --streams 512 --modes 100 --reps 1 > $d.log 2>&1
   python $R/tools/pmc_sum.py $d k_conv >> $R/gpurun_out/r4p/stream_lds_pmc.txt
   rm -rf $d
 done
