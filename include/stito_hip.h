@@ -220,8 +220,8 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * channels (one Winograd position row per sweep; the rows' contributions to the 4 x 4 outputs accumulate in a workgroup-
         * private scratch area of the workspace): half the bytes copied into LDS per MAC of _F4_SPLIT2, which is what bounds these
         * kernels.  For the deep layers (long channel loops: the five extra passes over the outputs are + 13 % of the operand
-        * stream at 2 048 input channels, + 27 % at 1 024).  cin % 64 == 0, cout % 512 == 0; own packing; same accuracy as
-        * _F4_SPLIT / _SPLIT2, sums in another order (ABI version 9). */
+        * stream at 2 048 input channels, + 27 % at 1 024).  cin % 64 == 0, cout % 512 == 0; own packing; the same arithmetic in the
+        * same order as _F4_SPLIT2: identical results (ABI version 9). */
        STITO_CONV_WINOGRAD_F4_SPLIT3 = 9 };
 
 typedef struct {
@@ -248,8 +248,8 @@ typedef struct {
     /* ABI v9: a second packing per conv (or NULL) for the calls in which the first one's kernel would not fill the device.
      * Today: conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT3 with conv_alt_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 -- the
      * six-sweep kernel's workgroups are four times larger, so a small batch (fewer than 3/4 workgroup per CU) runs the
-     * two-sweep kernel instead; results differ at float32 rounding level between the two (both inside the parity bar), a
-     * given batch size always takes the same one. */
+     * two-sweep kernel instead.  The two kernels do the same arithmetic in the same order: identical bits (tested), so the
+     * choice cannot be seen in the results. */
     const float *conv_alt_dev[STITO_CNN14_NUM_CONVS];
     int32_t conv_alt_algo[STITO_CNN14_NUM_CONVS];
 } stito_cnn14_weights;

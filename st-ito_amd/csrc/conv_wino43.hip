@@ -1121,6 +1121,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 // 24 KB], position jj at 8 KB: [hi 4 KB | lo 4 KB], each [channel octet][128][8 f16]; ring of three, two wave sets issuing on
 // alternate periods as above; two periods per 16 channels.  MFMA A operand = weights (rows = couts), B = input (columns =
 // tiles): a lane's accumulator quad = 4 consecutive couts of ITS tile, 16-byte partial-sum accesses and stores fall out.
+// The arithmetic and its order are k_conv_wino43s2's -- per position the same sequence of products, Y = A^T M A with the same
+// association -- so the two kernels return identical bits (tested): stito_cnn14_forward may pick either by batch size.
 #ifndef S43C_ABL
 #define S43C_ABL 0  // timing experiment (k_conv_wino43s3): 1 = no epilogues, 2 = no main loops, 4 = no partial stores, 8 = no partial loads; 0 in every build that ships
 #endif
@@ -1174,8 +1176,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
             const h8 vh0_ = *(const h8 *)(pv_ + q_ * 8192), vl0_ = *(const h8 *)(pv_ + q_ * 8192 + 4096);  \
             const h8 vh1_ = *(const h8 *)(pv_ + q_ * 8192 + 512), vl1_ = *(const h8 *)(pv_ + q_ * 8192 + 4096 + 512); \
             constexpr int a0_ = ((KK) * 3) * 2;                                                           \
-            S43_MFMA(a0_ + 2 * q_, ul_, vh0_) S43_MFMA(a0_ + 2 * q_ + 1, ul_, vh1_)                       \
-            S43_MFMA(a0_ + 2 * q_, uh_, vl0_) S43_MFMA(a0_ + 2 * q_ + 1, uh_, vl1_)                       \
+            S43_MFMA(a0_ + 2 * q_, uh_, vl0_) S43_MFMA(a0_ + 2 * q_ + 1, uh_, vl1_)   /* input lo x weight hi first, as */ \
+            S43_MFMA(a0_ + 2 * q_, ul_, vh0_) S43_MFMA(a0_ + 2 * q_ + 1, ul_, vh1_)   /* k_conv_wino43s2: the same bits */ \
             S43_MFMA(a0_ + 2 * q_, uh_, vh0_) S43_MFMA(a0_ + 2 * q_ + 1, uh_, vh1_)                       \
         }                                                                                                 \
         if (!mine_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \

@@ -727,6 +727,38 @@ def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
             assert rel < 5e-6, rel
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout,pool", [(5, 14, 4, 512, 512, 0), (3, 29, 8, 192, 512, 1), (9, 9, 16, 64, 1024, 0), (40, 13, 7, 128, 512, 1),
+                                                 (2, 58, 16, 512, 512, 1), (64, 14, 4, 1024, 1024, 0), (7, 14, 4, 2048, 2048, 0)])
+def test_conv_six_sweeps_is_bitwise_the_two_sweep_kernel(dev, n, H, W, cin, cout, pool):
+    """k_conv_wino43s3 (128 x 128 tiles, six sweeps) and k_conv_wino43s2 (64 x 64, two sweeps) do the same arithmetic in the same
+    order -- per position the same sequence of products over the input channels (input lo x weight hi, hi x lo, hi x hi per 16
+    channels; an MFMA's sum over k does not depend on which operand carries which), then Y = A^T M A with the same association --
+    so which of the two a batch size selects (stito_cnn14_forward takes the two-sweep packing for small batches) cannot be seen
+    in the results: a candidate's fitness stays bitwise independent of the batch it is evaluated in."""
+    from st_ito import _hip
+    L = _hip.lib()
+    st = _hip.stream_ptr()
+    g = torch.Generator().manual_seed(H * 10 + cin)
+    x = torch.relu(torch.randn((n, cin // 8, H, W, 8), generator=g)).to(dev)
+    x[1 % n] *= 300.0
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)).to(dev)
+    sc = (0.5 + torch.rand(cout, generator=g)).to(dev); sh = (0.1 * torch.randn(cout, generator=g)).to(dev)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    outs = {}
+    for m in (_hip.CONV_WINOGRAD_F4_SPLIT2, _hip.CONV_WINOGRAD_F4_SPLIT3):
+        assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, m)
+        packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, m), device=dev)
+        _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, m, _hip.ptr(packed), st))
+        out = torch.full((n, cout // 8, Ho, Wo, 8), float("nan"), device=dev)
+        wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, m)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), n, H, W, cin, cout, pool, m,
+                                              _hip.ptr(ws), wsb, st))
+        outs[m] = out
+    assert not torch.isnan(outs[_hip.CONV_WINOGRAD_F4_SPLIT3]).any()
+    assert torch.equal(outs[_hip.CONV_WINOGRAD_F4_SPLIT2], outs[_hip.CONV_WINOGRAD_F4_SPLIT3])
+
+
 def test_trunk_small_batches_take_the_two_sweep_packing(dev):
     """The six-sweep kernel's workgroups are four times the two-sweep kernel's: a batch that gives it fewer than 3 / 4 workgroup per
     CU (anything below ~380 streams for conv_block6) runs the two-sweep kernel from the alternative packing the model carries
@@ -749,7 +781,12 @@ def test_trunk_small_batches_take_the_two_sweep_packing(dev):
                 assert int(W.conv_wino_algo[i]) == _hip.CONV_WINOGRAD_F4_SPLIT2 and not W.conv_alt_dev[i]
         x = torch.stack([O.synth_audio(70 + i, 2, 240000) for i in range(4)])
         outs[kind] = [t.clone() for t in pm(x.to(dev))]
+        base = [O.synth_audio(90 + k, 2, 480000) for k in range(5)]
+        xl = torch.stack([base[i % 5] * (1.0 + 0.01 * i) for i in range(200)])   # 400 streams: the six-sweep kernel runs
+        outs[kind + " large"] = [t.clone() for t in pm(xl.to(dev))]
     for a, b in zip(outs["default"], outs["two-sweep only"]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs["default large"], outs["two-sweep only large"]):   # ... and computes the same bits (test_conv_six_sweeps_is_bitwise_the_two_sweep_kernel)
         assert torch.equal(a, b)
 
 
