@@ -21,8 +21,10 @@ The JSON line also carries
                  per SIMD: tools/ubench/w23_shadow.hip).  `roofline` is the family with the largest share of the step, the others sit
                  in `roofline_other`.  achieved = FLOPs of the MFMA instructions those launches actually ISSUE (tile padding and
                  all three split products included; stito_conv3x3_issued_flops) / their summed duration, measured with HIP events
-                 the library records on its launch stream around every such launch of the TIMED steps
-                 (stito_conv_timing_enable / _read_each); frac = achieved / peak <= 1.
+                 the library records on its launch stream around every such launch (stito_conv_timing_enable / _read_each).  The
+                 timed steps replay the evaluate step's hipGraph (no host-side launches to bracket), so the events are taken on the
+                 same K steps launched eagerly right behind the timed region -- same kernels, same stream, same data shapes;
+                 `launch_mode.eager_ms_per_step` is that region's step time.  frac = achieved / peak <= 1.
                  time_at_peak_frac = (time all conv launches would take at the peak of the pipe each runs on) / measured conv time:
                  the one scalar that says how far the conv stack is from its matrix pipes.
                  algorithmic_tflops / end_to_end_algorithmic_frac count the DIRECT-convolution FLOPs 2*9*cin*cout*H*W
@@ -336,7 +338,15 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
-    if world > 1:
+    # STITO_BENCH_FORCE_DIST=1: at N = 1 build the one-rank process group anyway and send every step through the collective
+    # branch (RCCL communicator creation, device binding, all_gather_into_tensor, barrier) -- what a first multi-GPU run needs to work
+    force_dist = os.environ.get("STITO_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ["STITO_FORCE_COLLECTIVE"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -365,6 +375,7 @@ def main():
     P_total = args.pop_per_gpu * world
     es = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P_total, "seed": 42})
 
+    last_f = []   # fitness vector of the last step (its hash goes into the line: equal runs are comparable bit for bit)
     stage_s = [0.0, 0.0, 0.0]  # evaluate (ask + launches + the sync that ends them), gather, tell -- host clocks of this rank
 
     def step():
@@ -378,6 +389,7 @@ def main():
         t_b = time.perf_counter()
         f = gather_fitness(loss, P_total).tolist()  # .tolist() = the device->host sync the optimiser needs anyway
         t_c = time.perf_counter()
+        last_f[:] = f
         es.tell(W, f)
         t_d = time.perf_counter()
         stage_s[0] += t_b - t_a; stage_s[1] += t_c - t_b; stage_s[2] += t_d - t_c
@@ -392,8 +404,6 @@ def main():
         step()
     fence()
     timing = rank == 0 and not args.no_roofline
-    if timing:  # the library records HIP events around every MFMA conv launch of the timed steps
-        _hip.check(_hip.lib().stito_conv_timing_enable(1))
     stage_s[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -401,10 +411,29 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     stages_ms = [1e3 * v / args.steps for v in stage_s]
+    import hashlib
+    fitness_sha = hashlib.sha256(np.asarray(last_f, dtype=np.float64).tobytes()).hexdigest()[:16]
     conv_each, conv_launches = (ctypes.c_double * 65536)(), ctypes.c_int(0)
+    graph_replay = bool(ev._graphs)   # the timed steps replayed the evaluate step's hipGraph (the product default)
     if timing:
+        # The library records HIP events around every MFMA conv launch it makes from the host.  The timed steps above replay the
+        # captured graph (no host-side launches), so the per-launch durations come from the SAME steps repeated right behind the
+        # timed region with eager launches of the same kernels on the same stream (the CMA-ES simply keeps going); their device
+        # time is what rocprofv3 reports for the timed region's launches (profiles/round5_bench_kernel_stats.txt).
+        ev_timed = ev if not graph_replay else PopulationEvaluator(x, SR, plugins, model, te, use_graph=False)
+        ev_graph, ev = ev, ev_timed
+        if graph_replay:
+            step()   # warm (eager buffers)
+            fence()
+        _hip.check(_hip.lib().stito_conv_timing_enable(1))
+        t_e = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_eager = time.perf_counter() - t_e
         _hip.check(_hip.lib().stito_conv_timing_enable(0))
         _hip.check(_hip.lib().stito_conv_timing_read_each(conv_each, 65536, ctypes.byref(conv_launches)))
+        ev = ev_graph
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -466,9 +495,14 @@ def main():
                    f"{args.seconds:g} s, chain EQ/comp/reverb/EQ/gain (D={D}), AFx-Rep Cnn14 (seeded random weights), "
                    "CMA-ES seed 42", "pop_per_gpu": args.pop_per_gpu, "n_samples": n, "chain": kinds,
                    "parallelism": f"population sharded over {world} GPU(s), fitness all-gather",
-                   "backend": backend if world > 1 else None, "ranks": ranks_seen},
+                   "backend": backend if dist is not None else None, "ranks": ranks_seen},
+        "last_fitness_sha16": fitness_sha,   # of the full fitness vector of the last timed step (every rank holds the same one)
     }
     out["stages"] = stages
+    out["launch_mode"] = {"timed_region": "one hipGraph replay per evaluate step (render -> log-mel -> Cnn14 -> loss)" if graph_replay else "eager launches",
+                          "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3) if (timing and graph_replay) else None,
+                          "note": "per-launch conv durations (roofline) are HIP events around the eager launches of the same steps, repeated right "
+                                  "behind the timed region" if graph_replay else None}
     if pop512 is not None:
         out["north_star_pop512"] = pop512
     if rank == 0:

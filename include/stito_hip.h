@@ -214,7 +214,10 @@ enum { STITO_CONV_DIRECT = 0, STITO_CONV_WINOGRAD = 1, STITO_CONV_WINOGRAD_F4 = 
         * conv_block2.conv1): the transformed WEIGHTS (16 positions x 64 x 64 as f16 hi + lo = 256 KB) stay in the registers of
         * persistent workgroups for the whole launch, the input transform is done in registers straight into the MFMA operand
         * layout (no transformed input in LDS or HBM), the raw halo patches arrive by LDS-DMA.  cin == 64, cout % 64 == 0; own
-        * packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 7). */
+        * packing; workspace = one word per stream; stito_conv3x3_bn_relu_ws (ABI version 7).  gfx950 only by construction: a
+        * workgroup needs 512 registers per wave and ~144 KB of dynamic LDS (153 KB with the first conv fused);
+        * stito_conv3x3_supported / stito_conv_block1_f2reg_supported return 0 on a device whose LDS per workgroup is smaller,
+        * and the trunk then takes the F(4x4,3x3) kernels for those layers. */
        STITO_CONV_WINOGRAD_F2_REG = 8,
        /* The split-precision streaming convolution on 128-tile x 128-channel workgroup tiles, in SIX sweeps over the input
         * channels (one Winograd position row per sweep; the rows' contributions to the 4 x 4 outputs accumulate in a workgroup-

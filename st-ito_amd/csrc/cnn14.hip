@@ -1377,15 +1377,12 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     // ONE memset at the top of the pass (a memset per layer was ten more dispatches per pass)
     const size_t amax_stride = align_up((size_t)S * sizeof(unsigned), 256);
     unsigned *const amax_all = (unsigned *)((char *)vbuf + vbytes);
-    STITO_HIP_CHECK(hipMemsetAsync(amax_all, 0, amax_stride * STITO_CNN14_NUM_CONVS, st));
+    STITO_TRY(zero_async(amax_all, amax_stride * STITO_CNN14_NUM_CONVS, st));
     const unsigned *amax_have = nullptr;  // maxima of the current input, if its producer reported them
 
-    int n_cus = 256;
-    {
-        int dev_ = 0;
-        STITO_HIP_CHECK(hipGetDevice(&dev_));
-        STITO_HIP_CHECK(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_));
-    }
+    DeviceInfo dinfo;
+    STITO_TRY(device_info(dinfo));   // cached per device
+    const int n_cus = dinfo.cus;
     const float *cur = logmel_dev;
     // conv_block1 as one launch on the register-resident F(2x2,3x3) kernel, which computes the first conv into its patch ring
     const bool fuse1r = w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
@@ -1498,7 +1495,7 @@ extern "C" int stito_embed_loss(float *mid_dev, float *side_dev, int n_cand, int
     STITO_REQUIRE(n_cand > 0 && embed_dim > 0, STITO_E_INVALID, "empty embeddings");
     STITO_REQUIRE((target_mid_dev == nullptr) == (target_side_dev == nullptr), STITO_E_INVALID, "need both targets or none");
     STITO_REQUIRE(target_mid_dev == nullptr || loss_dev != nullptr, STITO_E_INVALID, "loss output missing");
-    STITO_HIP_CHECK(hipMemsetAsync(flags_dev, 0, 2 * sizeof(int32_t), st));
+    STITO_TRY(zero_async(flags_dev, 2 * sizeof(int32_t), st));
     const int64_t n = (int64_t)n_cand * embed_dim;
     hipLaunchKernelGGL(k_nan_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mid_dev, side_dev, n, flags_dev);
     STITO_LAUNCH_CHECK();

@@ -617,8 +617,23 @@ static int w23_nb(int cin) { return cin == 64 ? 2 : 0; }
 
 size_t wino23r_packed_floats(int cout, int cin) { return (size_t)16 * cout * cin + 64; }
 
+// dynamic LDS of k_conv_wino23r<4, 2, ., FUSE1>: patch ring + Z exchange + BN constants (+ first-conv weights and two log-mel buffers)
+static size_t w23_lds_bytes(bool fuse1) {
+    constexpr int NB = 2;
+    return (size_t)W23_RING * W23_ENTRY + (size_t)4 * 2 * NB * 4 * 1024 + (size_t)2 * 32 * NB * sizeof(float) +
+           (fuse1 ? (size_t)4096 + 2 * W23_MELBUF : 0);
+}
+
+// gfx950 only: the kernel needs ~144 KB of LDS per workgroup (153 KB with the first conv fused) and 512 registers per wave; on a
+// device that does not offer that much LDS per block the shape is reported unsupported and the trunk falls back to F(4x4,3x3).
+static bool w23_device_fits(bool fuse1) {
+    DeviceInfo d;
+    return device_info(d) == STITO_OK && (size_t)d.lds_per_block >= w23_lds_bytes(fuse1);
+}
+
 bool wino23r_supported(const ConvShape &c, bool pool) {
     if (w23_nb(c.Cin) == 0 || c.Cout % (32 * w23_nb(c.Cin)) != 0) return false;
+    if (!w23_device_fits(false)) return false;
     if (pool && (c.H < 2 || c.W < 2)) return false;
     if ((int64_t)c.H * c.W * 32 >= (1ll << 31)) return false;  // 32-bit byte offsets inside a channel-octet plane
     const int tr = pool ? c.H / 2 : (c.H + 1) / 2, tc = pool ? c.W / 2 : (c.W + 1) / 2;
@@ -643,7 +658,7 @@ int pack_wino23r(const float *w_oihw, int cout, int cin, float *packed, hipStrea
     STITO_REQUIRE(nb > 0 && cout % (32 * nb) == 0, STITO_E_UNSUPPORTED, "conv (winograd F(2x2,3x3), register-resident weights): cin %d / cout %d", cin, cout);
     const int64_t n = (int64_t)cout * cin;
     unsigned *hdr = (unsigned *)(packed + (size_t)16 * cout * cin);
-    STITO_HIP_CHECK(hipMemsetAsync(hdr, 0, 64 * sizeof(float), st));
+    STITO_TRY(zero_async(hdr, 64 * sizeof(float), st));
     hipLaunchKernelGGL(k_pack_wino23r<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, nb, (char *)packed, hdr);
     STITO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_wino23r_scale, dim3(1), dim3(1), 0, st, hdr);
@@ -685,13 +700,13 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
     g.n_cb = c.Cout / (32 * NB);
     g.fGPS = make_fdiv(g.n_bands * g.n_txb);
     g.fTXB = make_fdiv(g.n_txb);
-    int dev = 0, cus = 256;
-    STITO_HIP_CHECK(hipGetDevice(&dev));
-    STITO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    DeviceInfo dinfo;
+    STITO_TRY(device_info(dinfo));   // cached per device
     // persistent workgroups, one per CU; per channel block a multiple of 8 of them (one set per XCD)
-    int per_cb = (cus / g.n_cb) & ~7;
+    int per_cb = (dinfo.cus / g.n_cb) & ~7;
     if (per_cb < 8) per_cb = 8;
-    if (const char *e = getenv("STITO_W23_WG")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) per_cb = v; }  // tuning aid
+    // tuning / test aid, read per launch: the parity tests and tools/block1_fuzz.py sweep it inside one process (a getenv, no device query)
+    if (const char *e = getenv("STITO_W23_WG")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) per_cb = v; }
     g.wg_per_cb = per_cb;
     const unsigned *amax = amax_in;
     // measurement aid (tools/conv_bench.py): STITO_W23_AMAX_ONCE=1 keeps the maxima a previous call left in the same workspace
@@ -704,7 +719,7 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
         amax_have_in = in; amax_have_ws = ws;
         unsigned *amax_ws = (unsigned *)ws;
         amax = amax_ws;
-        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
+        STITO_TRY(zero_async(amax_ws, (size_t)c.S * sizeof(unsigned), st));
         const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
         int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
         const int cap = (4096 + c.S - 1) / c.S;
@@ -717,8 +732,7 @@ static int launch_w23(const float *in, const float *wpk, const float *scale, con
     g.u_inv = wpk + (size_t)16 * c.Cout * c.Cin + 1;
     if (FUSE1) { g.c1w = f1->c1w; g.c1_sm = f1->sm; g.c1_kinv = f1->kinv; }
     auto kern = k_conv_wino23r<KS, NB, POOL, FUSE1>;
-    const size_t lds = (size_t)W23_RING * W23_ENTRY + (size_t)4 * 2 * NB * 4 * 1024 + (size_t)2 * 32 * NB * sizeof(float) +
-                       (FUSE1 ? (size_t)4096 + 2 * W23_MELBUF : 0);
+    const size_t lds = w23_lds_bytes(FUSE1);
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const bool clk_probe = [] { const char *e = getenv("STITO_W23_CLK"); return e && atoi(e) != 0; }();
     static long long *clk_dev = nullptr;
@@ -840,7 +854,7 @@ __global__ __launch_bounds__(256) void k_w23_mel_params(const float *__restrict_
 }
 
 bool wino23r_fused1_supported(const ConvShape &c, bool pool) {   // c: the SECOND conv's shape (Cin = the first conv's channels)
-    return c.Cin == 64 && wino23r_supported(c, pool);
+    return c.Cin == 64 && wino23r_supported(c, pool) && w23_device_fits(true);
 }
 
 size_t wino23r_fused1_workspace_bytes(const ConvShape &c, bool pool) {

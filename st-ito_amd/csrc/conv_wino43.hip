@@ -95,6 +95,7 @@ struct Wino43Geom {
     int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
     int n_mblocks;     // pixel blocks (MODE 1: the grid is padded to whole XCD rounds)
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
+    int xcd_m;         // k_conv_wino43s3: the 8 XCDs as xcd_m pixel-block classes x 8 / xcd_m channel-tile ranges (8 = the other kernels' order)
     FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
     long long *clk;    // W43_CLK builds only
@@ -1142,11 +1143,15 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, oct = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup order: as the other streaming kernels, over pixel-block QUADS (g.n_mblocks = number of quads) and 128-cout tiles
-    const int n_tiles = g.Cout / 128;
+    // ... with the XCDs (b % 8, each with its own L2) split in TWO dimensions when there are few quads: XCD = (quad class xcd % xm,
+    // channel-tile range xcd / xm).  An XCD's L2 fetches the V slabs of its quads and the U slabs of its channel tiles -- the same
+    // number of bytes per quad as per tile -- so quads / xm + tiles / (8 / xm) is what the eight L2s pull over the fabric each
+    // (profiles/round5_conv_ea_pmc.txt: with every XCD running all 16 channel tiles of conv_block6.conv2, 8 x 604 MB of weights)
+    const int xm = g.xcd_m, n_tiles = (g.Cout / 128) / (8 / xm);   // channel tiles of this XCD's range
     const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
     const int a = g.ct_group, n_ctg = n_tiles / a;
-    const int ct = (gi % n_ctg) * a + (r % a);
-    const int m_quad = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+    const int ct = (xcd / xm) * n_tiles + (gi % n_ctg) * a + (r % a);
+    const int m_quad = ((gi / n_ctg) * (32 / a) + r / a) * xm + (xcd % xm);
     if (m_quad >= g.n_mblocks) return;
     W43_CLK_BEGIN()
     const int nP = g.Cin >> 3;   // periods per sweep: two per 16 input channels
@@ -1448,7 +1453,7 @@ int pack_wino43_split(const float *w_oihw, int cout, int cin, float *packed, int
     STITO_REQUIRE(cin % 64 == 0 && cout % (layout == 2 ? 128 : 64) == 0, STITO_E_UNSUPPORTED, "conv (split-precision winograd): cin %d / cout %d", cin, cout);
     const int64_t n = (int64_t)cout * cin;
     unsigned *hdr = (unsigned *)(packed + (size_t)36 * cout * cin);
-    STITO_HIP_CHECK(hipMemsetAsync(hdr, 0, 64 * sizeof(float), st));
+    STITO_TRY(zero_async(hdr, 64 * sizeof(float), st));
     hipLaunchKernelGGL(k_pack_wino43s<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_oihw, cout, cin, (char *)packed, hdr);
     STITO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pack_wino43s_scale, dim3(1), dim3(1), 0, st, hdr);
@@ -1700,7 +1705,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     if (amax_in == nullptr) {   // stream maxima (not supplied by the layer that produced `in`)
         unsigned *amax_ws = (unsigned *)(ws + align_up((size_t)m_blocks * (c.Cin / W43_K) * W43_V * sizeof(float), 256));
         amax = amax_ws;
-        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
+        STITO_TRY(zero_async(amax_ws, (size_t)c.S * sizeof(unsigned), st));
         const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
         int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));  // >= 16 float4 per thread
         const int cap = (4096 + c.S - 1) / c.S;                            // ~16 workgroups per CU in total
@@ -1809,7 +1814,7 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
     const unsigned *amax = amax_in != nullptr ? amax_in : amax_ws;
     f32x4 *partial = (f32x4 *)(ws + vbytes + align_up((size_t)c.S * sizeof(unsigned), 256));
     if (amax_in == nullptr) {   // stream maxima (not supplied by the layer that produced `in`)
-        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
+        STITO_TRY(zero_async(amax_ws, (size_t)c.S * sizeof(unsigned), st));
         const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
         int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
         const int cap = (4096 + c.S - 1) / c.S;
@@ -1867,29 +1872,39 @@ bool wino43_split3_supported(const ConvShape &c, bool pool) {
 }
 
 template <int TTW>
-static int64_t w43_split3_grid(const ConvShape &c, bool pool, int64_t &m_quads, int &ct_group) {
+static int64_t w43_split3_grid(const ConvShape &c, bool pool, int64_t &m_quads, int &ct_group, int &xcd_m) {
     Wino43Geom g;
     size_t lds;
     int64_t blocks;
     if (!w43_geometry<TTW>(c, pool, g, lds, blocks)) return 0;
     const int64_t m_blocks = blocks / (c.Cout / 64);
     m_quads = (m_blocks + 3) / 4;
-    const int n_tiles = c.Cout / 128;   // a multiple of 4 (wino43_split3_supported)
-    int a = 4;
+    const int n_tiles_all = c.Cout / 128;   // a multiple of 4 (wino43_split3_supported)
+    // XCD split (see the kernel): the xm in {8, 4, 2} with the fewest slab bytes per L2, quads / xm + tiles / (8 / xm); 8 on a tie
+    int xm = 8;
+    for (int cand = 4; cand >= 2; cand >>= 1)
+        if (n_tiles_all % (8 / cand) == 0 && (m_quads + cand - 1) / cand + n_tiles_all / (8 / cand) < (m_quads + xm - 1) / xm + n_tiles_all / (8 / xm)) xm = cand;
+    if (const char *e = getenv("STITO_W43S3_XM")) { const int xe = atoi(e); if ((xe == 8 || xe == 4 || xe == 2) && n_tiles_all % (8 / xe) == 0) xm = xe; }  // tuning aid
+    xcd_m = xm;
+    const int n_tiles = n_tiles_all / (8 / xm);
+    const int64_t mq_loc = (m_quads + xm - 1) / xm;
+    int a = n_tiles < 4 ? n_tiles : 4;
+    while (a < n_tiles && a < 32 && 32 / a > mq_loc) a *= 2;   // one round of workgroups: as many channel tiles side by side as it takes to fill it
     if (const char *e = getenv("STITO_W43S3_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }
     if (n_tiles % a != 0) return 0;
     ct_group = a;
     const int bm = 32 / a;
-    const int64_t m_groups = ((m_quads + 7) / 8 + bm - 1) / bm;
+    const int64_t m_groups = (mq_loc + bm - 1) / bm;
     return 8 * m_groups * (n_tiles / a) * 32;
 }
 
 static int64_t w43_split3_grid_any(const ConvShape &c, bool pool, int64_t &m_quads, int &ct_group) {
+    int xm;
     switch (w43_ttw(c, pool)) {
-        case 8: return w43_split3_grid<8>(c, pool, m_quads, ct_group);
-        case 4: return w43_split3_grid<4>(c, pool, m_quads, ct_group);
-        case 2: return w43_split3_grid<2>(c, pool, m_quads, ct_group);
-        default: return w43_split3_grid<1>(c, pool, m_quads, ct_group);
+        case 8: return w43_split3_grid<8>(c, pool, m_quads, ct_group, xm);
+        case 4: return w43_split3_grid<4>(c, pool, m_quads, ct_group, xm);
+        case 2: return w43_split3_grid<2>(c, pool, m_quads, ct_group, xm);
+        default: return w43_split3_grid<1>(c, pool, m_quads, ct_group, xm);
     }
 }
 
@@ -1932,15 +1947,15 @@ static int launch_w43_split3(const float *in, const float *upk, const float *sca
     STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     int64_t m_quads = 0;
-    int a = 4;
-    const int64_t grid = w43_split3_grid<TTW>(c, POOL, m_quads, a);
+    int a = 4, xm = 8;
+    const int64_t grid = w43_split3_grid<TTW>(c, POOL, m_quads, a, xm);
     STITO_REQUIRE(grid > 0 && grid < (1ll << 31), STITO_E_UNSUPPORTED, "conv (six-sweep split-precision winograd): grid / cout %d", c.Cout);
     const size_t vbytes = w43_split3_vbytes(c, m_quads);
     unsigned *amax_ws = (unsigned *)(ws + vbytes);
     const unsigned *amax = amax_in != nullptr ? amax_in : amax_ws;
     f32x4 *partial = (f32x4 *)(ws + vbytes + align_up((size_t)c.S * sizeof(unsigned), 256));
     if (amax_in == nullptr) {   // stream maxima (not supplied by the layer that produced `in`)
-        STITO_HIP_CHECK(hipMemsetAsync(amax_ws, 0, (size_t)c.S * sizeof(unsigned), st));
+        STITO_TRY(zero_async(amax_ws, (size_t)c.S * sizeof(unsigned), st));
         const int64_t per_stream = (int64_t)c.Cin * c.H * c.W;
         int splits = (int)((per_stream / 4 + 256 * 16 - 1) / (256 * 16));
         const int cap = (4096 + c.S - 1) / c.S;
@@ -1967,6 +1982,8 @@ static int launch_w43_split3(const float *in, const float *upk, const float *sca
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     g.n_mblocks = (int)m_quads;
     g.ct_group = a;
+    g.xcd_m = xm;
+    g.xcd_m = xm;
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
     W43_CLK_ARM(g)

@@ -770,7 +770,7 @@ extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n
 }
 
 static int peak_strided(const float *audio_dev, int pop, int64_t per, int64_t stride, float *peaks_dev, hipStream_t st) {
-    STITO_HIP_CHECK(hipMemsetAsync(peaks_dev, 0, sizeof(float) * pop, st));
+    STITO_TRY(zero_async(peaks_dev, sizeof(float) * pop, st));
     if (((uintptr_t)audio_dev & 15) == 0 && per % 4 == 0 && stride % 4 == 0) {
         dim3 grid(grid_x_for(per / 4, pop), pop);
         hipLaunchKernelGGL(k_peak, grid, dim3(256), 0, st, audio_dev, per, stride, peaks_dev);
@@ -878,7 +878,7 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                     fused_next = true;
                 }
                 if (peaks_dev != nullptr && i + (fused_next ? 2 : 1) == n_fx && Cn == C_out && !(fx.flags & STITO_FX_FLAG_NORMALIZE_AFTER)) {
-                    STITO_HIP_CHECK(hipMemsetAsync(peaks_dev, 0, sizeof(float) * pop, st));
+                    STITO_TRY(zero_async(peaks_dev, sizeof(float) * pop, st));
                     post.peaks = peaks_dev;
                     peaks_done = true;
                 }

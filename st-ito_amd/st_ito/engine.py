@@ -195,13 +195,15 @@ class PopulationEvaluator:
 
     def __init__(self, x: torch.Tensor, sample_rate: int, plugins: Dict[str, dict], model, target_embeds: dict,
                  device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None,
-                 embed_func=None, normalize_stages: bool = False, entry_weights: Optional[Dict[str, float]] = None):
+                 embed_func=None, normalize_stages: bool = False, entry_weights: Optional[Dict[str, float]] = None,
+                 use_graph: Optional[bool] = None):
         """embed_func: None or st_ito.utils.get_param_embeds -> the fused AFx-Rep path (render -> log-mel with the
         peak normalisations folded into the STFT loader -> Cnn14 -> loss).  Any other embed_func(x, model, sample_rate)
         -> dict of (P, E_k) embeddings (the MIR / MFCC metrics of st_ito.utils, or a user function working on GPU
         tensors) takes the generic path of style_transfer.py:531-571: the rendered population is peak-normalised in
         HBM, handed to embed_func as one (P, C, L) GPU tensor, and every entry of the returned dict is scored against
-        the target's entry of the same name."""
+        the target's entry of the same name.  use_graph: None = STITO_GRAPH (default on), False = eager launches only
+        (bench.py's per-launch event timing needs host-side launches)."""
         _hip.require_gpu()
         from . import utils as _utils
 
@@ -232,15 +234,14 @@ class PopulationEvaluator:
         self.entry_weights = dict(entry_weights or {})
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
-        self._streams = None
-        # EXPERIMENT, OFF (STITO_GRAPH=1 to try): the plain fused call -- one population per pass, no crop, no dropout, no audio
-        # handed back -- captured as one hipGraph (render -> log-mel -> Cnn14 -> loss: ~45 launches).  Measured on MI355X:
-        # 45.6 -> 44.4 ms per evaluate at pop 256, 6.4 -> 6.2 ms at pop 32, bitwise the eager result in most processes -- but
-        # in about one process in three every replay after the first returned a few wrong per-candidate peaks (the buffer the
-        # captured hipMemsetAsync node zeroes in front of the last render kernel held foreign bits), whatever synchronisation
-        # surrounded the calls; not root-caused (a torch-only graph under the same pattern is fine), so it does not ship on.
-        self._graph_on = os.environ.get("STITO_GRAPH", "0") == "1"
-        self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls)
+        # The plain fused call -- one population per pass, no crop, no dropout, no audio handed back: what run_es issues every
+        # iteration -- is captured as ONE hipGraph (render -> log-mel -> Cnn14 -> loss: ~45 launches) and replayed; W travels through
+        # a static device buffer.  STITO_GRAPH=0 keeps the eager launches.  (Round 4 had this off: every replay after the first kept
+        # the previous replay's per-candidate peaks and stream maxima, because the hipMemsetAsync nodes that zero those atomicMax
+        # targets were not ordered in front of their kernels on replay; the library now zeroes with kernels -- csrc/common.h
+        # zero_async -- and tests/test_gpu_es.py replays the graph in many fresh processes against the eager result, bit for bit.)
+        self._graph_on = (os.environ.get("STITO_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
+        self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls, buffers kept alive)
         self._x_padded = None
 
     def _input(self, random_crop: bool, rng, parallel: bool = False) -> torch.Tensor:
@@ -289,13 +290,10 @@ class PopulationEvaluator:
                                           _hip.ptr(self.flags[255]), _hip.stream_ptr()))
         return loss, mid, side, (normalize_audio_(audio, peaks) if want_audio else None), (audio, peaks), n_calls
 
-    def _evaluate_graph(self, W, x, per):
+    def _evaluate_graph(self, Wn: np.ndarray, x, per):
         """The plain fused call as one hipGraph launch.  Captured on first use per (population size, input buffer) after one
         eager pass (which also builds everything lazy: packed weights, workspaces, LDS attributes); W travels through a
         static device buffer; the outputs are copied out of the graph's buffers, so they stay valid across calls."""
-        Wn = np.asarray(W, dtype=np.float64)
-        if Wn.ndim != 2 or Wn.shape[1] != self.ndims:
-            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wn.shape)}")
         P = Wn.shape[0]
         key = (P, x.data_ptr(), tuple(x.shape))
         ent = self._graphs.get(key)
@@ -324,110 +322,53 @@ class PopulationEvaluator:
         self._n_flag_rows = min(n_calls, 255)
         return loss.clone(), {"mid": mid.clone(), "side": side.clone()}, None
 
-    def _groups(self, P: int) -> int:
-        """Number of candidate groups pipelined over two HIP streams (STITO_PIPELINE_GROUPS, default
-        1 = off).  Measured on MI355X at pop 256 x 10 s stereo: 101.1 ms/step with 1 group, 103.2
-        with 2 (111.1 / 113.4 / 117.2 with 1 / 2 / 3 groups earlier in the round) -- the render of
-        group g+1 does overlap the trunk of group g, but its
-        time-serial kernels (compressor envelope, reverb) do not shrink with the group, their
-        workgroups pin whole CUs away from the MFMA trunk, and the trunk loses efficiency at half the
-        batch.  Kept as an option for populations much larger than one trunk pass."""
-        g = int(os.environ.get("STITO_PIPELINE_GROUPS", "1"))
-        return max(1, min(g, P))
-
     def evaluate(self, W, random_crop: bool = False, rng=np.random, want_audio: bool = False, dropout: float = 0.0,
                  parallel: bool = False):
-        """Fitness of every row of W.  With more than one group (see _groups) the population is
-        software-pipelined over two HIP streams: while group g runs log-mel + Cnn14 + loss on the
-        embed stream, group g+1 runs its effect chain on the render stream.  A candidate's result
-        does not depend on the grouping."""
+        """Fitness of every row of W -> (loss (P,), embeddings dict, normalised audio or None).  The population goes through in
+        passes of at most `max_candidates_per_pass` candidates (whole pairs for a multi-pair batch), one after the other on the
+        current stream; a candidate's result does not depend on how the population is cut."""
+        Wn = np.asarray(W, dtype=np.float64)
+        if Wn.ndim != 2 or Wn.shape[1] != self.ndims:
+            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wn.shape)}")
         x = self._input(random_crop, rng, parallel)
-        P = len(W)
+        P = Wn.shape[0]
         B = self.n_inputs
         if P == 0 or P % B:
             raise ValueError(f"{P} candidates cannot be split over {B} inputs")
         per = P // B  # candidates per input
-        G = self._groups(P)
-        step = (P + G - 1) // G
-        if self.max_cand:
-            step = min(step, self.max_cand)
+        step = min(P, self.max_cand) if self.max_cand else P
         if B > 1:  # passes hold whole pairs
             step = max(per, step // per * per)
         bounds = [(p0, min(P, p0 + step)) for p0 in range(0, P, step)]
         cropped = random_crop and not parallel and self.x_full.shape[-1] > CROP_LEN   # a new input buffer per call
         if (self._graph_on and self.fused and len(bounds) == 1 and dropout == 0.0 and not want_audio and not cropped and
                 not torch.cuda.is_current_stream_capturing()):
-            return self._evaluate_graph(W, x, per)
-        Wt = torch.as_tensor(np.asarray(W, dtype=np.float64)).to(self.device)
-        if Wt.dim() != 2 or Wt.shape[1] != self.ndims:
-            raise ValueError(f"parameter vectors must be (P, {self.ndims}), got {tuple(Wt.shape)}")
-        L = _hip.lib()
-        main = torch.cuda.current_stream(self.device)
-        pipelined = len(bounds) > 1 and G > 1
-        if pipelined:
-            if self._streams is None:
-                self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
-            s_render, s_embed = self._streams
-            s_render.wait_stream(main)
-            s_embed.wait_stream(main)
-        else:
-            s_render = s_embed = main
-        losses, mids, sides, audios, keep, generic_embeds = [], [], [], [], [], []
+            return self._evaluate_graph(Wn, x, per)
+        Wt = torch.from_numpy(Wn).to(self.device)
+        losses, mids, sides, audios, generic_embeds = [], [], [], [], []
         n_calls = 0
         for p0, p1 in bounds:
-            b0, b1 = p0 // per, (p1 + per - 1) // per
-            with torch.cuda.stream(s_render):
-                Wc = Wt[p0:p1].contiguous()
+            Wc = Wt[p0:p1].contiguous()
+            if self.fused:
+                loss, mid, side, audio, _, n_calls = self._fused_pass(Wc, x, p0, p1, per, n_calls, dropout, want_audio)
+                mids.append(mid); sides.append(side)
+            else:
+                b0, b1 = p0 // per, (p1 + per - 1) // per
                 xin = x[0] if B == 1 else x[b0:b1]
                 audio, peaks = render_population(self.plugins, xin, Wc, self.sample_rate, chain=self.chain)
-                rendered = torch.cuda.Event()
-                rendered.record(s_render)
-            if not self.fused:
-                with torch.cuda.stream(s_embed):
-                    s_embed.wait_event(rendered)
-                    spans = [(0, 0, p1 - p0)] if B == 1 else [(b, (b - b0) * per, (b - b0 + 1) * per) for b in range(b0, b1)]
-                    loss, emb = self._generic_loss(normalize_audio_(audio, peaks), spans, dropout)
-                    if want_audio:
-                        audios.append(audio)
-                losses.append(loss); generic_embeds.append(emb)
-                keep.append((Wc, audio, peaks))
-                continue
-            with torch.cuda.stream(s_embed):
-                s_embed.wait_event(rendered)
-                mid, side = self.model.embed_raw(audio, peaks, norm_passes=2)
-                loss = torch.empty(mid.shape[0], dtype=torch.float32, device=self.device)
-                # dropout (style_transfer.py:549-551) hits the embeddings only inside the distance; the cosine is
-                # scale-invariant, so dropping the raw vectors and normalising afterwards is the same quantity.
-                # The returned embeddings stay undropped, like the reference's output_embeds.
-                md, sd = mid, side
-                if dropout > 0.0:
-                    md = torch.nn.functional.dropout(mid, p=dropout, training=True).contiguous()
-                    sd = torch.nn.functional.dropout(side, p=dropout, training=True).contiguous()
                 spans = [(0, 0, p1 - p0)] if B == 1 else [(b, (b - b0) * per, (b - b0 + 1) * per) for b in range(b0, b1)]
-                for b, q0, q1 in spans:  # candidates of pair b against target b
-                    _hip.check(L.stito_embed_loss(_hip.ptr(md[q0:q1]), _hip.ptr(sd[q0:q1]), q1 - q0, mid.shape[1],
-                                                  _hip.ptr(self.tmid[b]), _hip.ptr(self.tside[b]), _hip.ptr(loss[q0:q1]),
-                                                  _hip.ptr(self.flags[n_calls % 256]), _hip.stream_ptr()))
-                    n_calls += 1
-                if dropout > 0.0:  # NaN scrub + L2 norm of the embeddings handed back
-                    _hip.check(L.stito_embed_loss(_hip.ptr(mid), _hip.ptr(side), mid.shape[0], mid.shape[1], None, None, None,
-                                                  _hip.ptr(self.flags[255]), _hip.stream_ptr()))
-                if want_audio:
-                    audios.append(normalize_audio_(audio, peaks))
-            losses.append(loss); mids.append(mid); sides.append(side)
-            keep.append((Wc, audio, peaks))  # alive until both streams have been joined
-        if pipelined:
-            main.wait_stream(s_render)
-            main.wait_stream(s_embed)
+                loss, emb = self._generic_loss(normalize_audio_(audio, peaks), spans, dropout)
+                generic_embeds.append(emb)
+            losses.append(loss)
+            if want_audio:
+                audios.append(audio)
         loss = torch.cat(losses) if len(losses) > 1 else losses[0]
         if self.fused:
             embeds = {"mid": torch.cat(mids), "side": torch.cat(sides)}
         else:
             embeds = {k: torch.cat([e[k] for e in generic_embeds]) for k in generic_embeds[0]}
-        audio_out = torch.cat(audios) if want_audio else None
-        del keep  # side-stream buffers: reused only after the next evaluate() has made that stream wait on main
         self._n_flag_rows = min(n_calls, 255)
-        return loss, embeds, audio_out
+        return loss, embeds, (torch.cat(audios) if want_audio else None)
 
     def _generic_loss(self, audio: torch.Tensor, spans, dropout: float):
         """style_transfer.py:531-571 for an arbitrary metric: embed_func on the normalised population (GPU tensor),

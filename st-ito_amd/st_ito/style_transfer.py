@@ -22,29 +22,27 @@ from . import engine
 
 # ------- audio processing methods -------
 def load_plugins(plugins: dict):
-    """reference style_transfer.py:17-42: instantiate, prepend the (dead) "our_bypass" slot."""
-    total_num_params = 0
-    init_params = []
+    """Instantiate every plugin of the dict and record its parameter layout (reference style_transfer.py:17-42).
+
+    Fills plugin["instance"], plugin["parameter_names"] -- the (dead) "our_bypass" slot first, then the instance's
+    parameters in their own order -- and plugin["num_params"]; returns (plugins, total number of slots, the initial raw
+    values slot by slot), printing each parameter like the reference does."""
+    init_params: List[float] = []
     for plugin_name, plugin in plugins.items():
         if "vst_filepath" in plugin:
             raise NotImplementedError("VST plugins (pedalboard.load_plugin) are not supported in this build")
-        elif "class_path" in plugin:
-            plugin_instance = plugin["class_path"]()
-        else:
-            raise ValueError(f"Plugin must contain 'vst_filepath' or 'class_path'.")
-        plugin["parameter_names"] = ["our_bypass"]
-        init_params.append(0.0)
-        num_params = 1
-        for name, parameter in plugin_instance.parameters.items():
-            num_params += 1
-            print(f"{plugin_name}: {name} = {parameter.raw_value}")
-            init_params.append(parameter.raw_value)
-            plugin["parameter_names"].append(name)
+        if "class_path" not in plugin:
+            raise ValueError("Plugin must contain 'vst_filepath' or 'class_path'.")
+        instance = plugin["class_path"]()
+        raw = {name: prm.raw_value for name, prm in instance.parameters.items()}
+        for name, value in raw.items():
+            print(f"{plugin_name}: {name} = {value}")
         print()
-        plugin["num_params"] = num_params
-        plugin["instance"] = plugin_instance
-        total_num_params += num_params
-    return plugins, total_num_params, init_params
+        plugin["instance"] = instance
+        plugin["parameter_names"] = ["our_bypass", *raw]
+        plugin["num_params"] = 1 + len(raw)
+        init_params += [0.0, *raw.values()]
+    return plugins, len(init_params), init_params
 
 
 def process_audio(x: np.ndarray, w: np.ndarray, sr: int, plugins: List[dict], normalize_stages: bool = False):
@@ -60,30 +58,27 @@ def process_audio(x: np.ndarray, w: np.ndarray, sr: int, plugins: List[dict], no
 
 
 def parameters_to_dict(w: np.ndarray, plugins: List[dict]):
-    """Convert parameter vector to dictionary (reference style_transfer.py:324-359), including the
-    side effect of writing the values into the plugin instances."""
-    widx = 0
-    w_dict = {}
+    """{plugin: {parameter: value in its own unit}} for a vector on [0, 1] (reference style_transfer.py:324-359).
+
+    Like the reference this WRITES the values into the plugin instances on the way (raw value for a free slot,
+    `set_value` of the fixed value for a fixed one); "our_bypass" is reported as the raw slot."""
+    out = {}
+    slot = iter(w)
     for plugin_name, plugin in plugins.items():
-        if plugin_name not in w_dict:
-            w_dict[plugin_name] = {}
+        values = out.setdefault(plugin_name, {})
+        fixed = plugin["fixed_parameters"]
         for name in plugin["parameter_names"]:
+            raw = next(slot)  # every name consumes its slot, fixed or not
             if name == "our_bypass":
-                w_dict[plugin_name][name] = w[widx]
-                widx += 1
+                values[name] = raw
                 continue
-            parameter = engine._instance_of(plugin).parameters[name]
-            if name in plugin["fixed_parameters"]:
-                parameter.set_value(plugin["fixed_parameters"][name])
-                widx += 1
+            prm = engine._instance_of(plugin).parameters[name]
+            if name in fixed:
+                prm.set_value(fixed[name])
             else:
-                parameter.raw_value = w[widx]
-                widx += 1
-            if hasattr(parameter, "get_value"):
-                w_dict[plugin_name][name] = parameter.get_value()
-            else:
-                w_dict[plugin_name][name] = parameter.raw_value
-    return w_dict
+                prm.raw_value = raw
+            values[name] = prm.get_value() if hasattr(prm, "get_value") else prm.raw_value
+    return out
 
 
 def savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir: str, sample_rate: int, first: int = 0):
@@ -126,7 +121,9 @@ def gather_fitness(local: torch.Tensor, popsize: int) -> torch.Tensor:
     """All-gather the per-rank fitness shards into candidate order (RCCL when the tensors are on
     the GPU, gloo on CPU).  Shards may differ by one element, so pad to the largest."""
     dist, rank, world = _dist_info()
-    if world == 1:
+    # a one-rank group skips the collective unless STITO_FORCE_COLLECTIVE=1 (tests/test_gpu_es.py pushes a step through RCCL's
+    # communicator setup and all_gather_into_tensor on the one GPU a test box has)
+    if world == 1 and not (dist is not None and os.environ.get("STITO_FORCE_COLLECTIVE") == "1"):
         return local
     per = (popsize + world - 1) // world
     buf = torch.full((per,), float("inf"), dtype=local.dtype, device=local.device)
@@ -294,16 +291,12 @@ def run_es(
         if rank == 0:
             es.disp()
 
-        if iteration > 0:
-            fval_delta = min(fvals) - min(fval_history)
-        else:
-            fval_delta = -0.02
-        if fval_delta > -0.01:
-            iters_without_improvement += 1
-            if rank == 0:
-                print(f"Solution has not improved for {iters_without_improvement} iterations.")
-        else:
-            iters_without_improvement = 0
+        # early stop (reference 655-670): an iteration counts as stale unless its best candidate beats the best value on
+        # record (the pre-tell history) by more than 0.01; the first iteration never counts
+        stale = iteration > 0 and min(fvals) - min(fval_history) > -0.01
+        iters_without_improvement = iters_without_improvement + 1 if stale else 0
+        if stale and rank == 0:
+            print(f"Solution has not improved for {iters_without_improvement} iterations.")
         if early_stop and iters_without_improvement > 10:
             print("Stopping early due to no improvement.")
             break

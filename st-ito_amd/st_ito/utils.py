@@ -41,7 +41,8 @@ def get_param_embeds(
     place.  The HIP model always lives on the GPU; the device the reference's model would be on is the one
     load_param_model was asked for (`model.reference_device`: "cuda" for use_gpu=True, else "cpu"; a model built
     directly counts as living where its parameters are).  When x is float32 on that device type at 48 kHz it comes back
-    normalised, exactly as from the reference; otherwise it is left untouched, as there."""
+    normalised, exactly as from the reference; otherwise it is left untouched, as there.  One deviation: an expanded
+    (stride-0) view, on which the reference raises, is left un-normalised and still gets its embeddings."""
     if x.dim() != 3:
         raise ValueError("expected (bs, chs, seq_len)")
     if requires_grad:
@@ -76,10 +77,13 @@ def get_param_embeds(
         print("Warning: NaNs found in side_embeddings")
     ref_dev = getattr(model, "reference_device", None) or dev.type
     if x.dtype == torch.float32 and sample_rate == 48000 and x.device.type == ref_dev and not x.requires_grad:
-        try:
-            x.div_(peaks.to(x.device).clamp(min=1e-8).view(-1, 1, 1))  # utils.py:473-474 on the caller's tensor
-        except RuntimeError:
-            pass  # expanded / overlapping view: the reference's in-place division raises there too, after its embeddings are lost; here they are kept
+        # utils.py:473-474 on the caller's tensor.  DEVIATION: for an expanded view (a stride-0 dimension: several elements
+        # share one memory location) the reference's in-place division raises and its embeddings are lost; here that one
+        # case is detected up front, the view is left untouched and the embeddings are returned.  Any other failure of
+        # the division (a HIP error, a read-only tensor) propagates.
+        shared = any(st == 0 and sz > 1 for st, sz in zip(x.stride(), x.shape))
+        if not shared:
+            x.div_(peaks.to(x.device).clamp(min=1e-8).view(-1, 1, 1))
     return {"mid": mid.type_as(x_device), "side": side.type_as(x_device)}
 
 

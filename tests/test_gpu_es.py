@@ -213,9 +213,10 @@ def test_fitness_independent_of_batch_position_and_size(dev):
     np.testing.assert_array_equal(full, one)
 
 
-def test_stream_pipelined_groups_give_identical_fitness(dev, monkeypatch):
-    """STITO_PIPELINE_GROUPS > 1 (render of group g+1 overlapped with the trunk of group g on two
-    HIP streams) must return bitwise the fitness, embeddings and audio of the single-group path."""
+def test_sub_batched_passes_and_graph_replay_give_identical_fitness(dev, monkeypatch):
+    """The population cut into passes of at most `max_candidates_per_pass` candidates, the eager launches (STITO_GRAPH=0) and the
+    captured hipGraph (default) must all return bitwise the same fitness and embeddings; audio is only handed back by the
+    eager path and must not depend on the cut either."""
     from st_ito import effects as E
     from st_ito.engine import PopulationEvaluator
     from st_ito.utils import get_param_embeds, make_synthetic_param_model
@@ -224,19 +225,50 @@ def test_stream_pipelined_groups_give_identical_fitness(dev, monkeypatch):
     tgt = O.synth_audio(32, 2, 90000)[None]
     pp = E.make_plugins("bench5")
     te = get_param_embeds(tgt, pm, SR)
-    ev = PopulationEvaluator(x, SR, pp, pm, te)
     W = np.random.default_rng(1).random((7, 45))
-    monkeypatch.setenv("STITO_PIPELINE_GROUPS", "1")
+    monkeypatch.setenv("STITO_GRAPH", "0")
+    ev = PopulationEvaluator(x, SR, pp, pm, te)
+    assert not ev._graph_on
     l1, e1, a1 = ev.evaluate(W, want_audio=True)
-    for g in ("2", "3"):
-        monkeypatch.setenv("STITO_PIPELINE_GROUPS", g)
-        for _ in range(2):  # second call re-uses the side streams and their cached buffers
-            lg, eg, ag = ev.evaluate(W, want_audio=True)
-            torch.cuda.synchronize()
+    for cut in (2, 3, 7):
+        evc = PopulationEvaluator(x, SR, pp, pm, te, max_candidates_per_pass=cut)
+        for _ in range(2):
+            lg, eg, ag = evc.evaluate(W, want_audio=True)
             np.testing.assert_array_equal(l1.cpu().numpy(), lg.cpu().numpy())
             np.testing.assert_array_equal(e1["mid"].cpu().numpy(), eg["mid"].cpu().numpy())
             np.testing.assert_array_equal(e1["side"].cpu().numpy(), eg["side"].cpu().numpy())
             np.testing.assert_array_equal(a1.cpu().numpy(), ag.cpu().numpy())
+    monkeypatch.delenv("STITO_GRAPH")
+    evg = PopulationEvaluator(x, SR, pp, pm, te)
+    assert evg._graph_on
+    rng = np.random.default_rng(5)
+    for rep in range(6):   # replay with NEW parameters every time: peaks / stream maxima of the previous replay must not survive
+        Wr = W if rep == 0 else rng.random((7, 45))
+        le, ee, _ = ev.evaluate(Wr)
+        lg, eg, _ = evg.evaluate(Wr)
+        assert len(evg._graphs) == 1
+        np.testing.assert_array_equal(le.cpu().numpy(), lg.cpu().numpy(), err_msg=f"replay {rep}")
+        np.testing.assert_array_equal(ee["mid"].cpu().numpy(), eg["mid"].cpu().numpy())
+        np.testing.assert_array_equal(ee["side"].cpu().numpy(), eg["side"].cpu().numpy())
+
+
+def test_graph_replay_soak_in_fresh_processes(dev):
+    """the captured evaluate step against the eager launches, bit for bit, over 50 FRESH processes x 20 replays
+    with new parameters each (tools/graph_soak.py; the corruption of round 4 showed in every process from the second
+    replay on once the parameters changed between replays).  Eight processes at a time share the GPU."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "graph_soak.py"), "--pop", "16", "--samples", "48000", "--replays", "20"]
+    n_proc, width = 50, 10
+    out = []
+    for first in range(0, n_proc, width):
+        procs = [subprocess.Popen(cmd + ["--seed", str(i)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for i in range(first, min(n_proc, first + width))]
+        for pr in procs:
+            txt = pr.communicate(timeout=900)[0]
+            line = [l for l in txt.splitlines() if l.startswith("graph_soak:")]
+            out.append((pr.returncode, line[-1] if line else txt[-400:]))
+    bad = [o for o in out if o[0] != 0 or "OK" not in o[1]]
+    assert not bad, f"{len(bad)} of {n_proc} processes: {bad[:3]}"
 
 
 def test_multi_pair_render_and_batch_es_match_single_pair_runs(dev):
@@ -513,3 +545,50 @@ def test_bench_gpus2_self_launches_its_ranks(dev):
     for k in ("evaluate_ms", "gather_ms", "tell_ms"):
         assert 0.0 <= st[k]["min"] <= st[k]["max"]
     assert st["evaluate_ms"]["max"] + st["gather_ms"]["min"] <= 1.05 * d["ms_per_step"] + 5.0 and "rccl_version" in st
+
+
+def test_one_rank_rccl_group_runs_the_collective_branch(dev):
+    """RCCL itself has to execute once before a first 8-GPU run.  bench.py with STITO_BENCH_FORCE_DIST=1 at
+    N = 1 builds the one-rank `nccl` process group bound to cuda:0 (communicator creation, device binding) and sends every
+    step through gather_fitness's all_gather_into_tensor + the barrier bracket; the fitness of the last step must be bit for
+    bit the no-dist run's, and the line must carry the RCCL version."""
+    import subprocess
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "STITO_FORCE_COLLECTIVE", "STITO_BENCH_FORCE_DIST")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--seconds", "2",
+           "--pop-per-gpu", "12", "--no-cpu-baseline", "--no-roofline", "--no-pop512"]
+    lines = {}
+    for mode in ("plain", "rccl"):
+        env = dict(base)
+        if mode == "rccl":
+            env.update(STITO_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (mode, out.stderr[-2000:])
+        js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1, (mode, out.stdout[-500:])
+        lines[mode] = json.loads(js[0])
+    p, r = lines["plain"], lines["rccl"]
+    assert p["config"]["backend"] is None and p["stages"]["rccl_version"] is None
+    assert r["config"]["backend"] == "nccl" and r["n_gpus"] == 1
+    assert r["stages"]["rccl_version"], r["stages"]
+    assert r["last_fitness_sha16"] == p["last_fitness_sha16"]
+
+
+def test_gather_fitness_over_rccl_in_process(dev):
+    """The same branch inside this process: init_process_group("nccl", world_size=1, device_id=cuda:0), an uneven shard padded
+    and gathered on the device by all_gather_into_tensor, equal to the shortcut's answer."""
+    import torch.distributed as dist
+    from st_ito.style_transfer import gather_fitness
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ["STITO_FORCE_COLLECTIVE"] = "1"
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", world_size=1, rank=0, device_id=dev)
+        local = torch.arange(7, dtype=torch.float32, device=dev) * 0.25 - 1.0
+        got = gather_fitness(local, 7)
+        assert got.is_cuda and torch.equal(got, local) and got.data_ptr() != local.data_ptr()   # went through the gather buffer
+        dist.barrier()
+    finally:
+        os.environ.pop("STITO_FORCE_COLLECTIVE", None)
+        if dist.is_initialized():
+            dist.destroy_process_group()

@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/) against the golden vectors generated from the reference
 (tests/golden/make_golden.py) and against closed-form known answers."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -9,6 +10,7 @@ import torch
 import st_ito_oracle as O
 
 SR = 48000
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _g(golden_dir, name):
@@ -394,3 +396,64 @@ def test_chorus_and_dasp_compressor_known_answers():
         g[i] = acc
     ref = xs[0].double().numpy() * 10 ** (g / 20.0)
     assert np.abs(yf[0].numpy() - ref).max() < 2e-5
+
+
+def test_oracle_loudness_meter_known_answers():
+    """The oracle's BS.1770 meter (pyloudnorm restated, un-vendored: parity unpinned) against the published anchors: the
+    K-weighting coefficient table of ITU-R BS.1770-4 at 48 kHz (pyloudnorm designs its filters from (G, Q, fc), which lands
+    within 2e-4 of the table; its high pass is normalised to unit pass-band gain where the table's numerator is [1, -2, 1]),
+    EBU Tech 3341 case 1 (a stereo 997 Hz sine at -23 dBFS reads -23.0 +- 0.1 LUFS), the gates (digital silence -> -inf; a
+    silent half does not lower the reading), and the product's host meter, written independently on Python loops."""
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd"))
+    from st_ito.loudness import integrated_loudness as product_meter
+    sos = O.k_weighting_sos(48000.0)
+    np.testing.assert_allclose(sos[0], [1.53512485958697, -2.69169618940638, 1.19839281085285, 1.0, -1.69065929318241, 0.73248077421585], atol=2e-4)
+    np.testing.assert_allclose(sos[1][3:], [1.0, -1.99004745483398, 0.99007225036621], atol=1e-4)
+    np.testing.assert_allclose(sos[1][:3] / sos[1][0], [1.0, -2.0, 1.0], atol=1e-12)
+    sr = 48000
+    t = np.arange(sr * 6) / sr
+    tone = 10 ** (-23 / 20) * np.sin(2 * np.pi * 997 * t)
+    stereo = np.stack([tone, tone], 1)
+    assert abs(O.integrated_loudness(stereo, sr) - (-23.0)) < 0.1
+    assert abs(O.integrated_loudness(tone, sr) - (-23.0 - 10 * np.log10(2.0))) < 0.1      # one channel: half the power
+    assert O.integrated_loudness(np.zeros((sr, 2)), sr) == float("-inf")
+    gated = np.concatenate([stereo, np.zeros_like(stereo)])     # silence falls under both gates (ungated: -3 LU; only the three
+    assert abs(O.integrated_loudness(gated, sr) - O.integrated_loudness(stereo, sr)) < 0.15   # blocks across the edge count)
+    rng = np.random.default_rng(0)
+    for n, chs in ((sr * 3 + 17, 2), (sr // 2, 1), (sr * 7 + 123, 2)):
+        y = rng.standard_normal((n, chs)) * 0.1
+        y[: n // 3] *= 1e-3                                                                # a quiet stretch the relative gate removes
+        assert abs(O.integrated_loudness(y, sr) - product_meter(y, sr)) < 1e-9
+    with pytest.raises(ValueError):
+        O.integrated_loudness(np.zeros((100, 2)), sr)
+
+
+def test_oracle_es_drivers_on_a_stub_metric():
+    """Host logic of the oracle-side drivers (the GPU suite compares the product with them): run_es's find_w0 / pre-tell history
+    / early stop, run_staged_es's composition of the stage vectors and its per-stage seeds, with the product's CMA-ES as the
+    optimiser and a cheap embed_func (RMS per channel) so that it runs in seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd"))
+    from st_ito import cmaes
+    def embed(a, m, sr):
+        return {"rms": torch.sqrt((a.to(torch.float64) ** 2).mean(-1)).to(torch.float32)}
+    op = O.make_plugins(["Gain", "Distortion"])
+    D = sum(p["num_params"] for p in op.values())
+    x = O.synth_audio(5, 2, 20000)[None]
+    tgt = torch.from_numpy(O.process_audio(x[0].numpy(), np.full(D, 0.8), 48000, op))[None]
+    seen = []
+    r = O.run_es(x.clone(), tgt.clone(), 48000, op, None, cmaes.CMAEvolutionStrategy, embed_func=embed, max_iters=4, popsize=5,
+                 sigma0=0.3, seed=3, find_w0=True, on_population=lambda it, W, f, a: seen.append((it, len(W), tuple(a.shape))))
+    assert [s[0] for s in seen] == [-1, 0, 1, 2, 3] and r["num_evals"] == 25 and all(s[1] == 5 for s in seen)
+    assert seen[0][2] == (5, 2, 262144)                                                    # padded to the crop length (517-518)
+    assert r["fval_history"][0] == float("inf") and r["wopt_history"][0] is None and len(r["fval_history"]) == 4
+    assert r["wopt"].shape == (D,) and r["output_audio"].shape == (2, 20000)
+    s = O.run_staged_es(x.clone(), tgt.clone(), 48000, op, None, cmaes.CMAEvolutionStrategy, embed_func=embed, max_iters=4, popsize=4,
+                        sigma0=0.3, seed=11)
+    n0 = op["Gain"]["num_params"]
+    assert len(s["stage_wopts"]) == 2 and s["stage_wopts"][0].shape == (n0,) and s["wopt"].shape == (D,)
+    np.testing.assert_array_equal(s["wopt"], np.concatenate(s["stage_wopts"]))
+    assert len(s["fval_history"]) == 4 and s["num_evals"] == 16
+    # stage 0 alone = run_es on the first plugin with the same seed, no find_w0, no early stop
+    r0 = O.run_es(x.clone(), tgt.clone(), 48000, O.make_plugins(["Gain"]), None, cmaes.CMAEvolutionStrategy, embed_func=embed, max_iters=2,
+                  popsize=4, sigma0=0.3, seed=11, find_w0=False, early_stop=False)
+    np.testing.assert_array_equal(s["stage_wopts"][0], r0["wopt"])
