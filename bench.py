@@ -93,7 +93,7 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round4_conv_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round5_conv_pmc_traffic.json")
 
 
 def kernel_source_hash():
@@ -123,6 +123,36 @@ def pmc_traffic_per_launch(n_streams):
     if d.get("n_streams") != n_streams:
         return None, f"PMC file is for {d.get('n_streams')} streams"
     return float(d["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(PMC_TRAFFIC_JSON)}"
+
+
+PMC_DSP_JSON = os.path.join(ROOT, "profiles", "round5_dsp_pmc_traffic.json")
+
+
+def dsp_source_hash():
+    """sha256 over the effect-chain and front-end kernels' code (comments and blank lines dropped), like kernel_source_hash."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "st-ito_amd", "csrc")
+    for name in ("dsp.hip", "dsp_view.h", "compressor.hip", "comp_scan.inc", "frontend.hip", "common.h"):
+        for line in open(os.path.join(d, name), "r", encoding="utf-8", errors="replace"):
+            code = line.split("//", 1)[0].rstrip()
+            if code:
+                h.update(code.encode() + b"\n")
+    return h.hexdigest()[:16]
+
+
+def pmc_dsp_traffic(pop, n_samples):
+    """HBM bytes per step of the render + log-mel kernels from the committed PMC passes (profiles/summarize_pmc_dsp.py), quoted
+    only for the kernel sources and the workload they were taken on.  -> (bytes or None, note)"""
+    try:
+        d = json.load(open(PMC_DSP_JSON))
+    except OSError:
+        return None, "no committed PMC file"
+    if d.get("dsp_source_hash") != dsp_source_hash():
+        return None, f"{os.path.basename(PMC_DSP_JSON)} was taken on sources {d.get('dsp_source_hash')}, this tree is {dsp_source_hash()}"
+    if d.get("pop") != pop or d.get("n_samples") != n_samples:
+        return None, f"PMC file is for pop {d.get('pop')}, {d.get('n_samples')} samples"
+    return float(d["traffic_bytes_per_step"]), f"profiles/{os.path.basename(PMC_DSP_JSON)}"
 
 
 ALGO_NAMES = {0: "direct", 1: "winograd F(2x2,3x3)", 2: "winograd F(4x4,3x3)", 3: "winograd F(4x4,3x3), input transform hoisted (two kernels)",
@@ -371,7 +401,7 @@ def main():
     from st_ito.style_transfer import process_audio
     tgt = torch.from_numpy(process_audio(synth_audio(4321, 2, n).numpy(), np.random.default_rng(7).random(D), SR, plugins))[None]
     te = get_param_embeds(tgt, model, SR)
-    ev = PopulationEvaluator(x, SR, plugins, model, te)
+    ev = PopulationEvaluator(x, SR, plugins, model, te, capture_after=0)   # the evaluate step's graph is captured inside the warm-up
     P_total = args.pop_per_gpu * world
     es = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P_total, "seed": 42})
 
@@ -592,11 +622,14 @@ def main():
                 torch.cuda.synchronize()
             r_ms, l_ms = evs[0].elapsed_time(evs[1]), evs[1].elapsed_time(evs[2])
             dsp_bytes = DSP_BYTES_PER_CAND_10S * (n / 480000.0) * args.pop_per_gpu
+            dsp_traffic, dsp_traffic_note = pmc_dsp_traffic(args.pop_per_gpu, n)
             out["roofline_dsp"] = {"bound": "hbm", "kernel": "effect-chain render (k_eq, compressor, k_reverb, k_eq + gain + peak) + k_logmel_wave",
                                    "achieved": round(dsp_bytes / ((r_ms + l_ms) * 1e-3) / 1e12, 3), "peak": HBM_PEAK_TBPS, "unit": "TB/s",
                                    "frac": round(dsp_bytes / ((r_ms + l_ms) * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4),
                                    "algorithmic_bytes": dsp_bytes, "render_ms": round(r_ms, 3), "logmel_ms": round(l_ms, 3),
                                    "share_of_step": round((r_ms + l_ms) / (dt / args.steps * 1e3), 4),
+                                   "traffic": dsp_traffic, "traffic_unit": "HBM bytes per step (PMC: FETCH_SIZE x2 + WRITE_SIZE), render + log-mel kernels",
+                                   "traffic_source": dsp_traffic_note,
                                    "note": "algorithmic bytes of SURVEY 8(d) (input read once, audio written once, log-mel written) / time; the "
                                            "time-serial effects (float64 biquad cascade, envelope follower, comb / all-pass lines) are latency- "
                                            "and issue-bound as SURVEY 8(d) expected: DESIGN.md 4.2 gives the per-kernel account"}

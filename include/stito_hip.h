@@ -89,7 +89,9 @@ const char *stito_last_error(void);
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
- * rate / fs per sample, wrapped), n < n_samples.  One serial walk: cache the table per (sample rate, rate). */
+ * rate / fs per sample, wrapped), n < n_samples.  The recurrence is walked on the host and copied (this call BLOCKS on `stream`
+ * and must not be made while the stream is being captured); the sines are taken on the device.  Cache the table per (sample
+ * rate, rate). */
 int stito_chorus_lfo(double sample_rate, double rate_hz, int64_t n_samples, float *lfo_dev, void *stream);
 /* dasp_pytorch.functional.compressor as st_ito/dsp.py:49-78 (apply_random_compressor) calls it: side chain = channel sum,
  * soft-knee gain computer, ONE one-pole smoothing filter with the attack constant (the library evaluates it by frequency

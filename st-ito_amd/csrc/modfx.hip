@@ -5,6 +5,8 @@
 // oracle/st_ito_oracle.py: dasp_compressor) -- parity unpinned.
 #include "dsp_view.h"
 
+#include <vector>
+
 // hipcc contracts a * b + c into an fma by default (its __fmul_rn / __fadd_rn are plain operators, not barriers, and
 // -ffp-contract=fast ignores pragmas): the JUCE arithmetic restated here rounds every product, so this file is compiled with
 // -ffp-contract=off (Makefile)
@@ -13,18 +15,19 @@ namespace stito {
 
 // ---- chorus --------------------------------------------------------------------------------------------------------
 // The LFO is common to every candidate and channel (it depends on the sample rate and the -- fixed -- rate only):
-// juce::dsp::Oscillator accumulates its phase in float, sample by sample, so the table is produced once by ONE thread walking
-// that recurrence (stito_chorus_lfo: k_chorus_phase, then the sines in parallel; the Python layer caches the table per sample
-// rate) and handed to the stage as aux_dev.
-__global__ void k_chorus_phase(float rate_hz, float sample_rate, int64_t n, float *__restrict__ s) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// juce::dsp::Oscillator accumulates its phase in float, sample by sample.  That recurrence is inherently serial (every addition
+// rounds), so the phases are walked once on the HOST (stito_chorus_lfo: ~1 ms per 2^19 samples; a single GPU thread took ~4 ms of
+// device time at 10 dependent cycles per step) and copied to the table; the sines are taken on the device in parallel.  The Python
+// layer caches the table per sample rate and hands it to the stage as aux_dev.  (This file is compiled with -ffp-contract=off, host
+// pass included: the products and sums below round one by one, exactly like the device walk they replace.)
+static void chorus_phase_walk(float rate_hz, float sample_rate, int64_t n, float *s) {
     const float two_pi = 6.283185307179586f;
-    const float inc = __fdiv_rn(__fmul_rn(two_pi, rate_hz), sample_rate);
+    const float inc = (two_pi * rate_hz) / sample_rate;
     float phase = 0.0f;
     for (int64_t i = 0; i < n; ++i) {
         s[i] = phase;
-        float next = __fadd_rn(phase, inc);
-        while (next >= two_pi) next = __fsub_rn(next, two_pi);
+        float next = phase + inc;
+        while (next >= two_pi) next = next - two_pi;
         phase = next;
     }
 }
@@ -156,8 +159,12 @@ using namespace stito;
 
 extern "C" int stito_chorus_lfo(double sample_rate, double rate_hz, int64_t n_samples, float *lfo_dev, void *stream) {
     STITO_REQUIRE(n_samples > 0 && lfo_dev != nullptr && sample_rate > 0 && rate_hz > 0, STITO_E_INVALID, "stito_chorus_lfo: empty table");
-    hipLaunchKernelGGL(k_chorus_phase, dim3(1), dim3(1), 0, (hipStream_t)stream, (float)rate_hz, (float)sample_rate, n_samples, lfo_dev);
-    STITO_LAUNCH_CHECK();
+    {   // phases on the host, one blocking copy (the table is built once per sample rate and cached by the caller)
+        std::vector<float> phases((size_t)n_samples);
+        chorus_phase_walk((float)rate_hz, (float)sample_rate, n_samples, phases.data());
+        STITO_HIP_CHECK(hipMemcpyAsync(lfo_dev, phases.data(), sizeof(float) * (size_t)n_samples, hipMemcpyHostToDevice, (hipStream_t)stream));
+        STITO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));   // `phases` dies at the end of this block
+    }
     hipLaunchKernelGGL(k_chorus_sin, dim3((unsigned)((n_samples + 4095) / 4096 > 1024 ? 1024 : (n_samples + 4095) / 4096)), dim3(256), 0,
                        (hipStream_t)stream, n_samples, lfo_dev);
     STITO_LAUNCH_CHECK();

@@ -196,7 +196,7 @@ class PopulationEvaluator:
     def __init__(self, x: torch.Tensor, sample_rate: int, plugins: Dict[str, dict], model, target_embeds: dict,
                  device: Optional[torch.device] = None, max_candidates_per_pass: Optional[int] = None,
                  embed_func=None, normalize_stages: bool = False, entry_weights: Optional[Dict[str, float]] = None,
-                 use_graph: Optional[bool] = None):
+                 use_graph: Optional[bool] = None, capture_after: Optional[int] = None):
         """embed_func: None or st_ito.utils.get_param_embeds -> the fused AFx-Rep path (render -> log-mel with the
         peak normalisations folded into the STFT loader -> Cnn14 -> loss).  Any other embed_func(x, model, sample_rate)
         -> dict of (P, E_k) embeddings (the MIR / MFCC metrics of st_ito.utils, or a user function working on GPU
@@ -236,11 +236,19 @@ class PopulationEvaluator:
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         # The plain fused call -- one population per pass, no crop, no dropout, no audio handed back: what run_es issues every
         # iteration -- is captured as ONE hipGraph (render -> log-mel -> Cnn14 -> loss: ~45 launches) and replayed; W travels through
-        # a static device buffer.  STITO_GRAPH=0 keeps the eager launches.  (Round 4 had this off: every replay after the first kept
+        # a static device buffer.  STITO_GRAPH=0 keeps the eager launches.  What it buys on an idle host is small (the eager
+        # launches already run ahead of the device: pop 32 6.62 against 6.63 ms per step, pop 256 43.4 against 43.5); what it
+        # removes is the step's dependence on the host's launch rate -- one launch per step instead of ~45 per rank.  (Round 4 had this off: every replay after the first kept
         # the previous replay's per-candidate peaks and stream maxima, because the hipMemsetAsync nodes that zero those atomicMax
         # targets were not ordered in front of their kernels on replay; the library now zeroes with kernels -- csrc/common.h
         # zero_async -- and tests/test_gpu_es.py replays the graph in many fresh processes against the eager result, bit for bit.)
         self._graph_on = (os.environ.get("STITO_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
+        # a graph is captured on the (capture_after + 1)-th eligible call with the same population size and input buffer: the
+        # capture costs about one evaluation (measured on MI355X: pop 32 first call 17.1 ms against 8.6 eager, pop 256 53.0
+        # against 26.3), which a run of two or three iterations would not earn back; run_es's find_w0 batch and first iteration go
+        # eagerly, the second iteration captures.  0 = capture on the first call (bench.py: inside its warm-up)
+        self.capture_after = int(os.environ.get("STITO_GRAPH_AFTER", "2")) if capture_after is None else int(capture_after)
+        self._graph_calls = {}
         self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls, buffers kept alive)
         self._x_padded = None
 
@@ -291,20 +299,27 @@ class PopulationEvaluator:
         return loss, mid, side, (normalize_audio_(audio, peaks) if want_audio else None), (audio, peaks), n_calls
 
     def _evaluate_graph(self, Wn: np.ndarray, x, per):
-        """The plain fused call as one hipGraph launch.  Captured on first use per (population size, input buffer) after one
-        eager pass (which also builds everything lazy: packed weights, workspaces, LDS attributes); W travels through a
-        static device buffer; the outputs are copied out of the graph's buffers, so they stay valid across calls."""
+        """The plain fused call as one hipGraph launch, or None while this (population size, input buffer) has been seen fewer than
+        capture_after times.  W travels through a static device buffer; the outputs are copied out of the graph's buffers, so
+        they stay valid across calls."""
         P = Wn.shape[0]
         key = (P, x.data_ptr(), tuple(x.shape))
         ent = self._graphs.get(key)
         if ent is None:
+            seen = self._graph_calls.get(key, 0)
+            self._graph_calls[key] = seen + 1
+            if seen < self.capture_after:
+                return None   # not yet: the caller launches eagerly
             Wbuf = torch.empty((P, self.ndims), dtype=torch.float64, device=self.device)
             Wbuf.copy_(torch.from_numpy(Wn))
-            side_stream = torch.cuda.Stream(self.device)
-            side_stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side_stream):
-                self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)   # eager warm-up (not part of the graph)
-            torch.cuda.current_stream(self.device).wait_stream(side_stream)
+            if seen == 0:
+                # nothing of this shape has run yet: one eager pass first (not part of the graph), which builds everything lazy
+                # -- packed weights, workspaces, LDS attributes -- outside the capture
+                side_stream = torch.cuda.Stream(self.device)
+                side_stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side_stream):
+                    self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
+                torch.cuda.current_stream(self.device).wait_stream(side_stream)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="relaxed"):
@@ -343,7 +358,9 @@ class PopulationEvaluator:
         cropped = random_crop and not parallel and self.x_full.shape[-1] > CROP_LEN   # a new input buffer per call
         if (self._graph_on and self.fused and len(bounds) == 1 and dropout == 0.0 and not want_audio and not cropped and
                 not torch.cuda.is_current_stream_capturing()):
-            return self._evaluate_graph(Wn, x, per)
+            out = self._evaluate_graph(Wn, x, per)
+            if out is not None:
+                return out
         Wt = torch.from_numpy(Wn).to(self.device)
         losses, mids, sides, audios, generic_embeds = [], [], [], [], []
         n_calls = 0

@@ -288,15 +288,20 @@ class Cnn14(nn.Module):
         return self._ws
 
     # ------------------------------------------------------------------------------------
-    def logmel(self, audio: torch.Tensor, peaks: Optional[torch.Tensor] = None, norm_passes: int = 0) -> torch.Tensor:
-        """(B, C, L) float32 on the GPU -> normalised log-mel (B*C, T, M) (panns.py:213-245)."""
+    def logmel(self, audio: torch.Tensor, peaks: Optional[torch.Tensor] = None, norm_passes: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(B, C, L) float32 on the GPU -> normalised log-mel (B*C, T, M) (panns.py:213-245); `out`: the (contiguous) slice of a
+        larger population's log-mel buffer to write into."""
         W, FE, _ = self._ensure()
         B, C, n = audio.shape
         if C not in (1, 2):
             raise ValueError(f"Invalid number of channels: {C}")
         L = _hip.lib()
         T = L.stito_num_frames(n, self.hop_size)
-        out = torch.empty((B * C, T, self.mel_bins), dtype=torch.float32, device=audio.device)
+        if out is None:
+            out = torch.empty((B * C, T, self.mel_bins), dtype=torch.float32, device=audio.device)
+        assert out.shape == (B * C, T, self.mel_bins) and out.is_contiguous() and out.dtype == torch.float32
+        assert audio.is_contiguous() and (peaks is None or peaks.is_contiguous())
         _hip.check(L.stito_logmel(FE, _hip.ptr(audio), _hip.ptr(peaks), norm_passes, B, C, n, _hip.ptr(out), _hip.stream_ptr()))
         return out
 

@@ -47,7 +47,7 @@ def main():
         loss, emb, _ = ev_e.evaluate(W)
         ref.append((loss.cpu().numpy().copy(), emb["mid"].cpu().numpy().copy(), emb["side"].cpu().numpy().copy()))
     os.environ["STITO_GRAPH"] = "1"
-    ev_g = PopulationEvaluator(x, 48000, plugins, pm, te)
+    ev_g = PopulationEvaluator(x, 48000, plugins, pm, te, capture_after=0)
     bad = []
     for i, W in enumerate(Ws):
         loss, emb, _ = ev_g.evaluate(W)
