@@ -452,6 +452,9 @@ __device__ __forceinline__ float rv_dpp(float v) {
 // (An LDS-only barrier -- s_waitcnt lgkmcnt(0); s_barrier, without __syncthreads()'s vmcnt(0) -- was measured too: 2.16
 // against 2.06 ms on the same box; hipcc then drains vmcnt in front of the LDS writes instead.)
 #define RV_BARRIER() __syncthreads()
+#ifndef RV_ABL
+#define RV_ABL 0   // timing builds only (tools/reverb_ablate.sh): 1 = comb role idle, 2 = all-pass role idle
+#endif
 
 __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restrict__ out, int64_t cand_stride,
                                                         int64_t L, const double *__restrict__ coef, ReverbGeom g) {
@@ -472,7 +475,10 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
     float *yl = out + (int64_t)cand * cand_stride, *yr = yl + L;
 
     for (int i = tid; i < g.state_floats; i += RV_THREADS) state[i] = 0.0f;
-    const int ntiles = (int)((L + RV_TT - 1) / RV_TT);
+    // tiles, rounded up to whole turns of the staging ring: every role runs ntiles + 1 barrier steps, and the staging loop has no
+    // early exit inside its unrolled turn (with one, hipcc gives up counting its loads and drains vmcnt(0) every turn); the tiles
+    // past the end of the signal are zeros in, nothing out
+    const int ntiles = (int)((L + RV_TT - 1) / RV_TT + RV_PD - 1) / RV_PD * RV_PD + (RV_PD - 1);
 
     if (wv < RV_COMB_WAVES) {
         // ---- comb role: lanes 0..31 of wave w are comb 2 w, lanes 32..63 comb 2 w + 1; lane l of a comb owns samples 6 l .. 6 l + 5
@@ -491,14 +497,21 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
         const float m15 = (cl & 16) ? powf(apw[0], (float)((cl & 15) + 1)) : 0.0f;  // from lane 15 of the comb's first row
         // the line's values for tile k + 1 are read at the end of tile k: they were written a whole delay (>= 2 tiles) ago, so
         // the LDS round trip is off the tile's dependent chain (read -> 5 FMAs -> scan -> 6 FMAs -> write)
-        int base = RV_RUN * cl;  // cpos = 0, and csz > RV_TT: the first run is straight
-        bool straight = true;
+        // A lane's run of RV_RUN consecutive slots is always read and written STRAIGHT: every line carries RV_RUN - 1 junk floats in
+        // front of it and a mirror of its first RV_RUN - 1 slots (+ junk) behind it (reverb_geometry).  The run that crosses the
+        // end of the circular line is written a second time RV_RUN - 1 .. 1 slots in front of slot 0 (its tail lands on the real
+        // slots 0 ..), the run that starts inside the first RV_RUN - 1 slots a second time behind the end (the mirror); reads never
+        // wrap.  (Rounds 1 - 4 wrapped slot by slot under `if (!straight)`: ~100 instructions that only one lane of one comb
+        // needs, but with 16 combs wrapping every 6 - 8 tiles nearly EVERY tile had one, and all sixteen waves meet at the tile's
+        // barrier: the comb waves' instruction count -- ~190 per tile on that path, ~8 cycles each -- was the tile time.)
+        int base = RV_RUN * cl;  // cpos = 0
         float o[RV_RUN];
 #pragma unroll
         for (int i = 0; i < RV_RUN; ++i) o[i] = 0.0f;  // the lines start empty
         for (int k = 0; k <= ntiles; ++k) {
             RV_BARRIER();
             if (k == ntiles) break;
+            if (RV_ABL & 1) continue;
             const float *in_c = s_in + (k & 1) * RV_TT + RV_RUN * cl;
             float *cmb = s_comb + (k & 1) * RV_CB + cidx * RV_TT + (cidx >= 8 ? RV_PAD : 0) + RV_RUN * cl;
             float pq[RV_RUN], w[RV_RUN];
@@ -526,15 +539,14 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
                 filt = fmaf(filt, damp, pq[i]);
                 w[i] = inv[i] + (filt * fbk);
             }
-            if (straight) {
 #pragma unroll
-                for (int i = 0; i < RV_RUN; ++i) cbuf[base + i] = w[i];
-            } else {
+            for (int i = 0; i < RV_RUN; ++i) cbuf[base + i] = w[i];
+            {
+                const bool cross = base + (RV_RUN - 1) >= csz, head = base < RV_RUN - 1;
+                if (cross || head) {   // one lane of a comb, once per trip around its line
+                    float *c2 = cbuf + (cross ? base - csz : base + csz);
 #pragma unroll
-                for (int i = 0; i < RV_RUN; ++i) {
-                    int p = base + i;
-                    p = p >= csz ? p - csz : p;
-                    cbuf[p] = w[i];
+                    for (int i = 0; i < RV_RUN; ++i) c2[i] = w[i];
                 }
             }
             *(f2 *)cmb = (f2){o[0], o[1]};
@@ -548,18 +560,8 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
             cpos = cpos >= csz ? cpos - csz : cpos;
             base = cpos + RV_RUN * cl;
             base = base >= csz ? base - csz : base;
-            straight = base + RV_RUN <= csz;  // the lane's run does not cross the end of the circular line
-            if (straight) {
 #pragma unroll
-                for (int i = 0; i < RV_RUN; ++i) o[i] = cbuf[base + i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < RV_RUN; ++i) {
-                    int p = base + i;
-                    p = p >= csz ? p - csz : p;
-                    o[i] = cbuf[p];
-                }
-            }
+            for (int i = 0; i < RV_RUN; ++i) o[i] = cbuf[base + i];   // (runs into the mirror behind the line's end)
         }
     } else if (wv < RV_COMB_WAVES + RV_AP_WAVES) {
         // ---- all-pass role: thread u = (channel u & 1, sample u >> 1) of tile k - 1: comb sum, 4 series all-passes, width mix
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
         int64_t t_out = -(int64_t)RV_TT + t2;
         for (int k = 0; k <= ntiles; ++k) {
             RV_BARRIER();
-            if (k >= 1) {
+            if (k >= 1 && !(RV_ABL & 2)) {
                 const float *cmb = s_comb + ((k - 1) & 1) * RV_CB + c2 * (8 * RV_TT + RV_PAD) + t2;
                 float cs[8], bv[4];
                 float *abp[4];
@@ -612,35 +614,55 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
         const int v = tid - (RV_COMB_WAVES + RV_AP_WAVES) * 64;
         const bool act = v < RV_TT / 2;
         const int64_t Lm1 = L - 1;
-        f4 ring[RV_PD];  // (l0, l1, r0, r1) of tile t in ring[t % RV_PD]
-        auto fetch = [&](int64_t t) -> f4 {
+        // Register ring of RV_PD tiles, loaded by inline-asm global_load_dword and waited for by hand: (l0, l1, r0, r1) of tile t
+        // in slot t % RV_PD.  Why by hand: given plain loads hipcc waits for them where it loses count -- right behind the load
+        // when the end-of-signal select follows it (rounds 1 - 4: vmcnt(0) on the load just issued, one full memory latency per
+        // tile in front of the barrier every other wave is waiting at), and with vmcnt(0) at the head of every unrolled turn even
+        // when nothing touches the values early (it does not carry its counters over the loop's back edge).  This wave issues no
+        // other vector-memory instruction, so the count is exact: a slot is consumed RV_PD fetches after its own, i.e. with
+        // 4 (RV_PD - 1) younger loads in flight.  The zeroing of samples past the end of the signal happens in put().
+        float ra[RV_PD], rb[RV_PD], rc[RV_PD], rd[RV_PD];
+        auto fetch = [&](int64_t t, float &a0, float &a1, float &b0, float &b1) {
             const int64_t i0 = t * RV_TT + 2 * (act ? v : 0), i1 = i0 + 1;
             const int64_t j0 = i0 < Lm1 ? i0 : Lm1, j1 = i1 < Lm1 ? i1 : Lm1;
-            const float a0 = xl[j0], a1 = xl[j1], b0 = xr[j0], b1 = xr[j1];
-            return (f4){i0 < L ? a0 : 0.0f, i1 < L ? a1 : 0.0f, i0 < L ? b0 : 0.0f, i1 < L ? b1 : 0.0f};
+            asm volatile("global_load_dword %0, %1, off" : "=v"(a0) : "v"(xl + j0) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(a1) : "v"(xl + j1) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(b0) : "v"(xr + j0) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(b1) : "v"(xr + j1) : "memory");
         };
-        auto put = [&](const f4 &q, int buf3, int buf2) {
+        auto put = [&](float a0, float a1, float b0, float b1, int64_t t, int buf3, int buf2) {
+            const int64_t i0 = t * RV_TT + 2 * (act ? v : 0);
+            const bool in0 = i0 < L, in1 = i0 + 1 < L;
+            const float l0 = in0 ? a0 : 0.0f, l1 = in1 ? a1 : 0.0f, r0 = in0 ? b0 : 0.0f, r1 = in1 ? b1 : 0.0f;
             if (act) {
-                *(f2 *)(s_x + buf3 * RV_XB + 2 * v) = (f2){q.x, q.y};
-                *(f2 *)(s_x + buf3 * RV_XB + RV_TT + RV_PAD + 2 * v) = (f2){q.z, q.w};
-                *(f2 *)(s_in + buf2 * RV_TT + 2 * v) = (f2){(q.x + q.z) * 0.015f, (q.y + q.w) * 0.015f};
+                *(f2 *)(s_x + buf3 * RV_XB + 2 * v) = (f2){l0, l1};
+                *(f2 *)(s_x + buf3 * RV_XB + RV_TT + RV_PAD + 2 * v) = (f2){r0, r1};
+                *(f2 *)(s_in + buf2 * RV_TT + 2 * v) = (f2){(l0 + r0) * 0.015f, (l1 + r1) * 0.015f};
             }
         };
-        put(fetch(0), 0, 0);
+#define RV_RING_WAIT(S_, N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" : "+v"(ra[S_]), "+v"(rb[S_]), "+v"(rc[S_]), "+v"(rd[S_])::"memory")
+        static_assert(RV_PD == 4, "the wait counts below are 4 (RV_PD - 1) = 12 loads");
+        fetch(0, ra[0], rb[0], rc[0], rd[0]);
+        RV_RING_WAIT(0, 0);
+        put(ra[0], rb[0], rc[0], rd[0], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < RV_PD; ++j) ring[(j + 1) % RV_PD] = fetch(j + 1);
+        for (int j = 0; j < RV_PD; ++j) fetch(j + 1, ra[(j + 1) % RV_PD], rb[(j + 1) % RV_PD], rc[(j + 1) % RV_PD], rd[(j + 1) % RV_PD]);
         int m3 = 1;  // (k + 1) % 3 at k = 0
-        for (int k0 = 0; k0 <= ntiles; k0 += RV_PD) {
+        for (int k0 = 0; k0 <= ntiles; k0 += RV_PD) {   // ntiles + 1 is a multiple of RV_PD
 #pragma unroll
             for (int kk = 0; kk < RV_PD; ++kk) {
                 const int k = k0 + kk;
-                if (k > ntiles) break;
+                constexpr int dummy = 0; (void)dummy;
+                const int sl = (kk + 1) % RV_PD;
                 RV_BARRIER();
-                put(ring[(kk + 1) % RV_PD], m3, (k + 1) & 1);   // tile k + 1 (zeros past the end of the signal)
-                ring[(kk + 1) % RV_PD] = fetch((int64_t)k + 1 + RV_PD);
+                RV_RING_WAIT(sl, 12);   // tile k + 1 has landed (the three fetches behind it may still be in flight)
+                put(ra[sl], rb[sl], rc[sl], rd[sl], (int64_t)k + 1, m3, (k + 1) & 1);   // zeros past the end of the signal
+                fetch((int64_t)k + 1 + RV_PD, ra[sl], rb[sl], rc[sl], rd[sl]);
                 m3 = m3 == 2 ? 0 : m3 + 1;
             }
         }
+#undef RV_RING_WAIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the ring may land after the wave has ended
     }
 }
 
@@ -707,11 +729,12 @@ static void reverb_geometry(double sr, ReverbGeom &g) {
     static const int ap_t[4] = {556, 441, 341, 225};
     const int isr = (int)sr;
     int off = 0;
+    // a comb line in LDS: [RV_RUN - 1 junk][the line][mirror of its first RV_RUN - 1 slots + RV_RUN junk] (k_reverb, comb role)
     for (int c = 0; c < 2; ++c)
         for (int j = 0; j < 8; ++j) {
             g.comb_size[c * 8 + j] = (int)(((int64_t)isr * (comb_t[j] + (c ? 23 : 0))) / 44100);
-            g.comb_off[c * 8 + j] = off;
-            off += g.comb_size[c * 8 + j];
+            g.comb_off[c * 8 + j] = off + (RV_RUN - 1);
+            off += g.comb_size[c * 8 + j] + (RV_RUN - 1) + (2 * RV_RUN - 1);
         }
     for (int c = 0; c < 2; ++c)
         for (int j = 0; j < 4; ++j) {

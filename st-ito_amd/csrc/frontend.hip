@@ -334,14 +334,24 @@ __global__ __launch_bounds__(FE_THREADS, FW_OCC) void k_logmel_wave(FrontendDev 
     auto load_hop = [&](int64_t h, float2 (&hm)[8], float2 (&hs)[8]) {
         const int64_t b = h * HOP;
         const bool fast = al8 && b >= 0 && b + HOP <= L;
+        // interior hop: all sixteen 8-byte loads are issued before the first one is used -- one memory round trip per hop instead
+        // of eight (with the loads inside the loop below, behind the uniform test, hipcc waits for each pair before it issues the next)
+        if (fast) {
+            const float *pl = xl + b + 2 * lane, *pr = xr + b + 2 * lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hm[j] = *(const float2 *)(pl + 128 * j);
+            if (C == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hs[j] = *(const float2 *)(pr + 128 * j);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t i = b + 2 * lane + 128 * j;
             float a0, a1, b0 = 0.0f, b1 = 0.0f;
             if (fast) {
-                const float2 a = *(const float2 *)(xl + i);
-                a0 = a.x; a1 = a.y;
-                if (C == 2) { const float2 bb = *(const float2 *)(xr + i); b0 = bb.x; b1 = bb.y; }
+                a0 = hm[j].x; a1 = hm[j].y;
+                if (C == 2) { b0 = hs[j].x; b1 = hs[j].y; }
             } else {
                 const int64_t i0 = reflect_idx(i, L), i1 = reflect_idx(i + 1, L);
                 a0 = xl[i0]; a1 = xl[i1];
