@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void k_delay(InView in, float *__restrict__ ou
 // Freeverb: juce::Reverb::processStereo, effects.py:952-959
 // ------------------------------------------------------------------------------------------------
 static constexpr int RV_TT = 192;       // tile length; must be <= the shortest delay line (244 @ 48 kHz)
-static constexpr int RV_RUN = 6;        // consecutive samples of a comb per lane: a comb's tile is 32 lanes, two combs per wave
-static constexpr int RV_COMB_WAVES = 8;
+static constexpr int RV_RUN = 12;       // consecutive samples of a comb per lane: a comb's tile is ONE 16-lane DPP row, four combs per wave
+static constexpr int RV_COMB_WAVES = 4;
 static constexpr int RV_AP_WAVES = 2 * RV_TT / 64;   // one all-pass / mix thread per (channel, sample)
 static constexpr int RV_STAGE_WAVES = 2;             // input staging: thread v < RV_TT / 2 moves samples 2v, 2v + 1 of both channels
 static constexpr int RV_THREADS = (RV_COMB_WAVES + RV_AP_WAVES + RV_STAGE_WAVES) * 64;
@@ -418,7 +418,7 @@ static constexpr int RV_PAD = 32;       // floats: half the LDS banks
 static constexpr int RV_XB = 2 * RV_TT + RV_PAD;    // floats per dry-input buffer
 static constexpr int RV_CB = 16 * RV_TT + RV_PAD;   // floats per comb-output buffer
 static constexpr int RV_TILE_FLOATS = 2 * RV_TT + 3 * RV_XB + 2 * RV_CB;  // s_in + s_x + s_comb
-static_assert(RV_RUN * 32 == RV_TT && RV_THREADS <= 1024, "a comb's tile is 32 lanes x RV_RUN samples");
+static_assert(RV_RUN * 16 == RV_TT && RV_RUN % 4 == 0 && RV_THREADS <= 1024, "a comb's tile is 16 lanes x RV_RUN samples");
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -447,8 +447,8 @@ __device__ __forceinline__ float rv_dpp(float v) {
 //                  (branch-free, so hipcc counts the waits instead of draining);
 //   all-pass waves only stores: comb sums, all four all-pass reads and the dry sample are fetched together, then the chain
 //                  runs on registers;
-//   comb waves     a comb's tile is 32 lanes x 6 consecutive samples: the damping one-pole runs serially inside the lane
-//                  (5 + 6 dependent FMAs) and a 5-step scan of affine maps crosses the lanes on the DPP network.
+//   comb waves     a comb's tile is 16 lanes (one DPP row) x 12 consecutive samples: the damping one-pole runs serially inside
+//                  the lane (11 + 12 dependent FMAs) and a 4-step scan of affine maps crosses the row's lanes on the DPP network.
 // (An LDS-only barrier -- s_waitcnt lgkmcnt(0); s_barrier, without __syncthreads()'s vmcnt(0) -- was measured too: 2.16
 // against 2.06 ms on the same box; hipcc then drains vmcnt in front of the LDS writes instead.)
 #define RV_BARRIER() __syncthreads()
@@ -481,29 +481,31 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
     const int ntiles = (int)((L + RV_TT - 1) / RV_TT + RV_PD - 1) / RV_PD * RV_PD + (RV_PD - 1);
 
     if (wv < RV_COMB_WAVES) {
-        // ---- comb role: lanes 0..31 of wave w are comb 2 w, lanes 32..63 comb 2 w + 1; lane l of a comb owns samples 6 l .. 6 l + 5
-        const int cidx = 2 * wv + (lane >> 5), cl = lane & 31;
+        // ---- comb role: the four 16-lane rows of wave w are combs 4 w .. 4 w + 3; lane l of a row owns samples 12 l .. 12 l + 11.
+        // The kernel is bound by the instructions its waves issue between two barriers, summed per SIMD (tools/reverb_ablate.sh: the
+        // roles' times ADD -- barriers only 0.4 ms, + all-pass 0.4, + comb 0.7 at 256 candidates -- at ~4.8 cycles per instruction and
+        // SIMD): with two combs of 32 lanes x 6 samples per wave (rounds 2 - 4) the eight comb waves issued 8 x 92 instructions per
+        // tile; a row per comb halves the waves for ~100 each, and the scan needs no step across rows.
+        const int cidx = 4 * wv + (lane >> 4), cl = lane & 15;
         const int csz = g.comb_size[cidx];
         float *cbuf = state + g.comb_off[cidx];
         int cpos = 0;
-        float last_in = 0.0f;  // filterStore entering the tile (meaningful in lane 0 of the comb)
-        float apw[4];          // damp^6, ^12, ^24, ^48: the affine maps' slopes at scan distances 1, 2, 4, 8
+        float last_in = 0.0f;  // filterStore entering the tile (meaningful in lane 0 of the comb's row)
+        float apw[4];          // damp^12, ^24, ^48, ^96: the affine maps' slopes at scan distances 1, 2, 4, 8
         {
-            float a = damp * damp * damp;
-            a = a * a;
+            const float d2 = damp * damp, d4 = d2 * d2;
+            float a = (d4 * d4) * d4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { apw[k] = a; a *= a; }
         }
-        const float m15 = (cl & 16) ? powf(apw[0], (float)((cl & 15) + 1)) : 0.0f;  // from lane 15 of the comb's first row
         // the line's values for tile k + 1 are read at the end of tile k: they were written a whole delay (>= 2 tiles) ago, so
-        // the LDS round trip is off the tile's dependent chain (read -> 5 FMAs -> scan -> 6 FMAs -> write)
+        // the LDS round trip is off the tile's dependent chain (read -> 11 FMAs -> scan -> 12 FMAs -> write)
         // A lane's run of RV_RUN consecutive slots is always read and written STRAIGHT: every line carries RV_RUN - 1 junk floats in
         // front of it and a mirror of its first RV_RUN - 1 slots (+ junk) behind it (reverb_geometry).  The run that crosses the
         // end of the circular line is written a second time RV_RUN - 1 .. 1 slots in front of slot 0 (its tail lands on the real
         // slots 0 ..), the run that starts inside the first RV_RUN - 1 slots a second time behind the end (the mirror); reads never
         // wrap.  (Rounds 1 - 4 wrapped slot by slot under `if (!straight)`: ~100 instructions that only one lane of one comb
-        // needs, but with 16 combs wrapping every 6 - 8 tiles nearly EVERY tile had one, and all sixteen waves meet at the tile's
-        // barrier: the comb waves' instruction count -- ~190 per tile on that path, ~8 cycles each -- was the tile time.)
+        // needs, but with 16 combs wrapping every 6 - 8 tiles nearly EVERY tile had one, and all waves meet at the tile's barrier.)
         int base = RV_RUN * cl;  // cpos = 0
         float o[RV_RUN];
 #pragma unroll
@@ -515,29 +517,28 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
             const float *in_c = s_in + (k & 1) * RV_TT + RV_RUN * cl;
             float *cmb = s_comb + (k & 1) * RV_CB + cidx * RV_TT + (cidx >= 8 ? RV_PAD : 0) + RV_RUN * cl;
             float pq[RV_RUN], w[RV_RUN];
-            const f2 n0 = *(const f2 *)in_c, n1 = *(const f2 *)(in_c + 2), n2 = *(const f2 *)(in_c + 4);
-            // the lane's 6 damping steps as one affine map of the state entering it: out = damp^6 in + b
+            f4 nin[RV_RUN / 4];
+#pragma unroll
+            for (int q = 0; q < RV_RUN / 4; ++q) nin[q] = *(const f4 *)(in_c + 4 * q);
+            // the lane's 12 damping steps as one affine map of the state entering it: out = damp^12 in + b
 #pragma unroll
             for (int i = 0; i < RV_RUN; ++i) pq[i] = o[i] * omd;
             float b = pq[0];
 #pragma unroll
             for (int i = 1; i < RV_RUN; ++i) b = fmaf(b, damp, pq[i]);
             b = fmaf(apw[0], cl == 0 ? last_in : 0.0f, b);  // the state entering the tile rides on lane 0's map
-            // inclusive scan over the comb's 32 lanes on the DPP network: shifts 1, 2, 4, 8 inside the 16-lane rows (lanes
-            // shifted in from outside read 0), then lane 15 of the first row into the second with the lane's distance
+            // inclusive scan over the comb's 16 lanes = one DPP row: shifts 1, 2, 4, 8 (lanes shifted in from outside the row read 0)
             b = fmaf(apw[0], rv_dpp<0x111>(b), b);
             b = fmaf(apw[1], rv_dpp<0x112>(b), b);
             b = fmaf(apw[2], rv_dpp<0x114>(b), b);
             b = fmaf(apw[3], rv_dpp<0x118>(b), b);
-            b = fmaf(m15, rv_dpp<0x142, 0xA>(b), b);
-            // state entering this lane's run = the scan of the lane before it (lane 0 of the comb: the tile's entering state)
-            const float prev = rv_dpp<0x138>(b);  // wave_shr:1
+            // state entering this lane's run = the scan of the lane before it (lane 0 of the row: the tile's entering state)
+            const float prev = rv_dpp<0x111>(b);  // row_shr:1
             float filt = cl == 0 ? last_in : prev;
-            const float inv[RV_RUN] = {n0.x, n0.y, n1.x, n1.y, n2.x, n2.y};
 #pragma unroll
             for (int i = 0; i < RV_RUN; ++i) {
                 filt = fmaf(filt, damp, pq[i]);
-                w[i] = inv[i] + (filt * fbk);
+                w[i] = nin[i >> 2][i & 3] + (filt * fbk);
             }
 #pragma unroll
             for (int i = 0; i < RV_RUN; ++i) cbuf[base + i] = w[i];
@@ -549,13 +550,10 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
                     for (int i = 0; i < RV_RUN; ++i) c2[i] = w[i];
                 }
             }
-            *(f2 *)cmb = (f2){o[0], o[1]};
-            *(f2 *)(cmb + 2) = (f2){o[2], o[3]};
-            *(f2 *)(cmb + 4) = (f2){o[4], o[5]};
-            // the comb's last lane holds the state leaving the tile
-            const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(filt), 31));
-            const float e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(filt), 63));
-            last_in = lane < 32 ? e0 : e1;
+#pragma unroll
+            for (int q = 0; q < RV_RUN / 4; ++q) *(f4 *)(cmb + 4 * q) = (f4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+            // the row's last lane holds the state leaving the tile: rotate it into lane 0 (row_ror:1; the other lanes do not use it)
+            last_in = rv_dpp<0x121>(filt);
             cpos += RV_TT;
             cpos = cpos >= csz ? cpos - csz : cpos;
             base = cpos + RV_RUN * cl;
