@@ -10,7 +10,7 @@ kernel is a host-side dispatch the counters are attributed to):
 Per kernel: launches per step, device time per step, FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md section HBM:
 128-byte requests are tallied at 64 B; Infinity-Cache hits are inside: L2-miss traffic) and WRITE_SIZE per step.  A step = the
 dispatches between two consecutive k_head launches (one trunk pass per step at pop 256); the LAST step of the process is used.
-Algorithmic bytes: shared input read once, rendered audio written once, log-mel written: 4 C L + 4 P C L + 4 P C T M."""
+Algorithmic bytes, per candidate: shared input read, rendered audio written, log-mel written: P (4 C L + 4 C L + 4 C T M)."""
 import json
 import os
 import sqlite3
@@ -50,15 +50,14 @@ for (name, fv, fd), (_, wv, wd) in zip(f, w):
     e["write"] += wv * 1024 / 1e9
 C = 2
 T = n // 1024 + 1
-alg = (4.0 * C * n + 4.0 * P * C * n + 4.0 * P * C * T * 128) / 1e9
+# SURVEY 8(d), per candidate: the shared input read (4 C L), the rendered audio written (4 C L), the log-mel written (4 C T M)
+alg = P * (4.0 * C * n + 4.0 * C * n + 4.0 * C * T * 128) / 1e9
 print(f"{'kernel':40s} {'launches':>8s} {'ms/step':>9s} {'fetch_GB(x2)':>13s} {'write_GB':>9s}")
 tf = tw = tm = 0.0
 for k, e in tab.items():
     print(f"{k[:40]:40s} {e['n']:8d} {e['ms']:9.3f} {e['fetch']:13.3f} {e['write']:9.3f}")
     tf += e["fetch"]; tw += e["write"]; tm += e["ms"]
 print(f"{'total (render + log-mel), one step':40s} {'':8s} {tm:9.3f} {tf:13.3f} {tw:9.3f}   traffic {tf + tw:.3f} GB vs algorithmic {alg:.3f} GB = {(tf + tw) / alg:.2f} x")
-print("(ms/step adds up the kernels' own durations: with the candidate groups running side by side on separate streams the step's "
-      "front end takes less wall time than this sum)")
 if len(sys.argv) > 5:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bench import dsp_source_hash

@@ -243,11 +243,12 @@ class PopulationEvaluator:
         # targets were not ordered in front of their kernels on replay; the library now zeroes with kernels -- csrc/common.h
         # zero_async -- and tests/test_gpu_es.py replays the graph in many fresh processes against the eager result, bit for bit.)
         self._graph_on = (os.environ.get("STITO_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
-        # a graph is captured on the (capture_after + 1)-th eligible call with the same population size and input buffer: the
-        # capture costs about one evaluation (measured on MI355X: pop 32 first call 17.1 ms against 8.6 eager, pop 256 53.0
-        # against 26.3), which a run of two or three iterations would not earn back; run_es's find_w0 batch and first iteration go
-        # eagerly, the second iteration captures.  0 = capture on the first call (bench.py: inside its warm-up)
-        self.capture_after = int(os.environ.get("STITO_GRAPH_AFTER", "2")) if capture_after is None else int(capture_after)
+        # a graph is captured on the (capture_after + 1)-th eligible call with the same population size and input buffer.  The
+        # capture costs about one evaluation (measured on MI355X: pop 32 first graph call 17.1 ms against 8.6 eager, pop 256 53.0
+        # against 26.3 at 262 144 samples) and a replay saves 0.2 - 1 % of a step on an idle host, so a short run never earns it
+        # back: the first eight calls (find_w0 + seven iterations) launch eagerly, longer runs switch to replay.  STITO_GRAPH_AFTER
+        # overrides; 0 = capture on the first call (bench.py: inside its warm-up)
+        self.capture_after = int(os.environ.get("STITO_GRAPH_AFTER", "8")) if capture_after is None else int(capture_after)
         self._graph_calls = {}
         self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls, buffers kept alive)
         self._x_padded = None

@@ -271,8 +271,9 @@ def test_sub_batched_passes_and_graph_replay_give_identical_fitness(dev, monkeyp
             np.testing.assert_array_equal(e1["side"].cpu().numpy(), eg["side"].cpu().numpy())
             np.testing.assert_array_equal(a1.cpu().numpy(), ag.cpu().numpy())
     monkeypatch.delenv("STITO_GRAPH")
-    evg = PopulationEvaluator(x, SR, pp, pm, te)
-    assert evg._graph_on and evg.capture_after == 2
+    assert PopulationEvaluator(x, SR, pp, pm, te).capture_after == 8   # the default: short runs never pay for a capture
+    evg = PopulationEvaluator(x, SR, pp, pm, te, capture_after=2)
+    assert evg._graph_on
     rng = np.random.default_rng(5)
     for rep in range(8):   # replay with NEW parameters every time: peaks / stream maxima of the previous replay must not survive
         Wr = W if rep == 0 else rng.random((7, 45))
