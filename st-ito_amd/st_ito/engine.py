@@ -244,11 +244,12 @@ class PopulationEvaluator:
         # zero_async -- and tests/test_gpu_es.py replays the graph in many fresh processes against the eager result, bit for bit.)
         self._graph_on = (os.environ.get("STITO_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         # a graph is captured on the (capture_after + 1)-th eligible call with the same population size and input buffer.  The
-        # capture costs about one evaluation (measured on MI355X: pop 32 first graph call 17.1 ms against 8.6 eager, pop 256 53.0
-        # against 26.3 at 262 144 samples) and a replay saves 0.2 - 1 % of a step on an idle host, so a short run never earns it
-        # back: the first eight calls (find_w0 + seven iterations) launch eagerly, longer runs switch to replay.  STITO_GRAPH_AFTER
-        # overrides; 0 = capture on the first call (bench.py: inside its warm-up)
-        self.capture_after = int(os.environ.get("STITO_GRAPH_AFTER", "8")) if capture_after is None else int(capture_after)
+        # capture costs ~10 ms at pop 32 and ~30 ms at pop 256 (private-pool allocations + hipGraphInstantiate of ~45 kernel nodes)
+        # and a replay saves 0.2 - 1 % of a step on an idle host, so a short run never earns it back (the reference's CLI default
+        # stops after ~25 iterations, its PST harness runs 32: 7.5 -> 7.9 ms per iteration with a capture at call 9, measured):
+        # the first 32 calls launch eagerly, longer runs switch to replay.  STITO_GRAPH_AFTER overrides; 0 = capture on the first
+        # call (bench.py: inside its warm-up)
+        self.capture_after = int(os.environ.get("STITO_GRAPH_AFTER", "32")) if capture_after is None else int(capture_after)
         self._graph_calls = {}
         self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls, buffers kept alive)
         self._x_padded = None
@@ -321,10 +322,19 @@ class PopulationEvaluator:
                 with torch.cuda.stream(side_stream):
                     self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
                 torch.cuda.current_stream(self.device).wait_stream(side_stream)
-            torch.cuda.synchronize(self.device)
+            # capture by hand on a side stream: the torch.cuda.graph() context manager also runs gc.collect() and
+            # torch.cuda.empty_cache(), i.e. it hands every cached block back to the driver (the CLI-default point: 8.2 ms per
+            # iteration with it, 7.9 without, 7.5 - 7.6 eager)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="relaxed"):
-                loss, mid, side, _, keep, n_calls = self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
+            cap_stream = torch.cuda.Stream(self.device)
+            cap_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(cap_stream):
+                g.capture_begin(capture_error_mode="relaxed")
+                try:
+                    loss, mid, side, _, keep, n_calls = self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
+                finally:
+                    g.capture_end()
+            torch.cuda.current_stream(self.device).wait_stream(cap_stream)
             # the graph holds raw pointers: everything it touches stays referenced here -- the outputs, the render and trunk
             # workspaces as they were at capture (a later, larger call replaces those objects; the graph keeps its own)
             keep = (keep, _WS._bufs.get("render"), getattr(self.model, "_ws", None), x)

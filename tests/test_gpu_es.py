@@ -271,7 +271,7 @@ def test_sub_batched_passes_and_graph_replay_give_identical_fitness(dev, monkeyp
             np.testing.assert_array_equal(e1["side"].cpu().numpy(), eg["side"].cpu().numpy())
             np.testing.assert_array_equal(a1.cpu().numpy(), ag.cpu().numpy())
     monkeypatch.delenv("STITO_GRAPH")
-    assert PopulationEvaluator(x, SR, pp, pm, te).capture_after == 8   # the default: short runs never pay for a capture
+    assert PopulationEvaluator(x, SR, pp, pm, te).capture_after == 32   # the default: short runs never pay for a capture
     evg = PopulationEvaluator(x, SR, pp, pm, te, capture_after=2)
     assert evg._graph_on
     rng = np.random.default_rng(5)
