@@ -34,7 +34,10 @@ The JSON line also carries
                  kernel source (hash check);
   roofline_dsp : render + log-mel against HBM: SURVEY 8(d)'s algorithmic bytes (8.16 MB per 10 s stereo candidate: shared input
                  read, rendered audio written, log-mel written) / the time of those kernels (HIP events around the two stages
-                 of a separate, untimed pass) against 8 TB/s;
+                 of a separate, untimed pass) against 8 TB/s; traffic = FETCH_SIZE x2 + WRITE_SIZE of those kernels per step from the
+                 committed PMC passes (profiles/round5_dsp_pmc_traffic.json), quoted only for the sources and workload they were taken on;
+  launch_mode  : whether the timed steps replayed the evaluate step's hipGraph, and the step time of the eager region behind them;
+  last_fitness_sha16 : sha256 of the last timed step's fitness vector (runs of the same tree are comparable bit for bit);
   stages       : per-rank (evaluate, gather, tell) milliseconds per step, min / max over ranks (diagnosis of a first multi-GPU run);
   cpu_baseline : the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample of the
                  same workload (rank 0, N = 1 only): mode A = the reference's serial loop (parallel=False), and
