@@ -54,7 +54,33 @@ def process_audio(x: np.ndarray, w: np.ndarray, sr: int, plugins: List[dict], no
         x = x.detach().cpu().numpy()
     if isinstance(w, torch.Tensor):
         w = w.detach().cpu().numpy()
-    return engine.process_audio_gpu(x, w, sr, plugins, normalize_stages=normalize_stages)
+    out = engine.process_audio_gpu(x, w, sr, plugins, normalize_stages=normalize_stages)
+    # side effect of the reference's loop (71-87): the plugin instances end up holding the values they were rendered with (raw
+    # slot for a free parameter, set_value of the fixed one) -- scripts/eval/eval_case_study.py:372-388 reads them back after a
+    # dummy call.  The GPU render takes its values from w, so they are written here, on the host.
+    _write_parameters(w, plugins)
+    return out
+
+
+def _write_parameters(w, plugins):
+    """Walk w over the plugins' slots and leave every value in its Parameter; -> the values in the parameters' own units."""
+    values = {}
+    slot = iter(w)
+    for plugin_name, plugin in plugins.items():
+        mine = values.setdefault(plugin_name, {})
+        fixed = plugin["fixed_parameters"]
+        for name in plugin["parameter_names"]:
+            raw = next(slot)  # every name consumes its slot, fixed or not
+            if name == "our_bypass":
+                mine[name] = raw
+                continue
+            prm = engine._instance_of(plugin).parameters[name]
+            if name in fixed:
+                prm.set_value(fixed[name])
+            else:
+                prm.raw_value = raw
+            mine[name] = prm.get_value() if hasattr(prm, "get_value") else prm.raw_value
+    return values
 
 
 def parameters_to_dict(w: np.ndarray, plugins: List[dict]):
@@ -62,23 +88,7 @@ def parameters_to_dict(w: np.ndarray, plugins: List[dict]):
 
     Like the reference this WRITES the values into the plugin instances on the way (raw value for a free slot,
     `set_value` of the fixed value for a fixed one); "our_bypass" is reported as the raw slot."""
-    out = {}
-    slot = iter(w)
-    for plugin_name, plugin in plugins.items():
-        values = out.setdefault(plugin_name, {})
-        fixed = plugin["fixed_parameters"]
-        for name in plugin["parameter_names"]:
-            raw = next(slot)  # every name consumes its slot, fixed or not
-            if name == "our_bypass":
-                values[name] = raw
-                continue
-            prm = engine._instance_of(plugin).parameters[name]
-            if name in fixed:
-                prm.set_value(fixed[name])
-            else:
-                prm.raw_value = raw
-            values[name] = prm.get_value() if hasattr(prm, "get_value") else prm.raw_value
-    return out
+    return _write_parameters(w, plugins)
 
 
 def savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir: str, sample_rate: int, first: int = 0):

@@ -3,6 +3,7 @@ selected-parameter-vector determinism claim of north_star."""
 import json
 import os
 import sys
+from collections import OrderedDict
 
 import numpy as np
 import pytest
@@ -734,3 +735,36 @@ def test_gather_fitness_over_rccl_in_process(dev):
         os.environ.pop("STITO_FORCE_COLLECTIVE", None)
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def test_case_study_point_against_the_oracle(dev, tmp_path):
+    """Widening beyond SURVEY 8(f) ("other run_es callers"): one point of the parameter-recovery case study
+    (scripts/eval/eval_case_study.py:346-522) for the compressor and for the reverb, product against oracle.case_study_point under
+    the same generator and the same seeded CMA-ES: the dummy render leaves the target value in the plugin instance
+    (process_audio's side effect), the crops are the same, the target is rendered with the fixed parameters, run_es (random crop
+    active) selects a bit-identical vector; then the harness end to end on synthetic sources."""
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import eval_case_study as C
+    from st_ito import cmaes
+    om = O.make_synthetic_model(0)
+    pm = _product_model(dev, om)
+    src = [O.synth_audio(801, 2, C.MIN_LEN + 30000), O.synth_audio(802, 1, C.MIN_LEN + 50000)]
+    for plugin_name, kind, value in (("pb_Compressor", "Compressor", 0.3), ("pb_Reverb", "Reverb", 0.7)):
+        spec, param, lo, hi = C.get_case(plugin_name)
+        got = C.study_point(spec, plugin_name, param, value, lambda r: (src[0], src[1]), pm, np.random.RandomState(11), max_iters=2, popsize=6, seed=4)
+        op = O.make_plugins([kind], with_bypass=True)
+        op = OrderedDict([(plugin_name, op[kind])])
+        op[plugin_name]["fixed_parameters"] = dict(spec[plugin_name]["fixed_parameters"])
+        est, fopt, target_value, wopt = O.case_study_point(op, plugin_name, param, value, src[0], src[1], om, cmaes.CMAEvolutionStrategy,
+                                                           np.random.RandomState(11), max_iters=2, popsize=6, seed=4)
+        np.testing.assert_array_equal(got["wopt"], wopt, err_msg=plugin_name)
+        assert got["estimated_param"] == est and abs(got["fopt"] - fopt) < 1e-4
+        assert got["target_value"] == pytest.approx(target_value, abs=1e-12)
+        prm_lo, prm_hi = {"pb_Compressor": (-80.0, 0.0), "pb_Reverb": (0.0, 1.0)}[plugin_name]
+        assert got["target_value"] == pytest.approx(prm_lo + value * (prm_hi - prm_lo))
+    res = C.run_case_study(["pb_Distortion"], src, pm, str(tmp_path), num_runs=1, num_steps=2, max_iters=1, popsize=4, seed=2, save_audio=True)
+    runs = res["pb_Distortion"]["different"]["param-panns"]["drive_db"]
+    assert sorted(runs) == [0.5, 1.0] and all(len(v) == 1 and 0.0 <= v[0][0] <= 1.0 and -1.0 <= v[0][1] <= 1.0 for v in runs.values())
+    saved = json.load(open(tmp_path / "pb_Distortion" / "case_study_results.json"))
+    assert list(saved["different"]["param-panns"]["drive_db"]) == ["0.5", "1.0"]
+    assert len(os.listdir(tmp_path / "pb_Distortion" / "audio")) == 4

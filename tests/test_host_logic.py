@@ -566,3 +566,39 @@ def test_cmaes_prefetch_does_not_change_the_run():
     a, ra = run(False)
     b, rb = run(True)
     assert np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
+def test_case_study_cases_mirror_the_reference_table():
+    """scripts/eval_case_study.py: the six pb_* cases of the reference's eval_case_study.py:226-344 -- one free parameter, every
+    other one fixed in its own units (Parameter.set_value must accept them), the free parameter's slot index counted with the
+    leading our_bypass slot -- compile into a chain whose fixed mask covers exactly the fixed names; vst_* cases say why they
+    are not built; unknown names raise like the reference's KeyError-free else branch would not."""
+    import copy
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import eval_case_study as C
+    from st_ito import engine
+    from st_ito.style_transfer import load_plugins
+    want = {"pb_ParametricEQ": ("low_shelf_gain_db", 0.0, 1.0, 18), "pb_Chorus": ("mix", 0.0, 1.0, 5), "pb_Compressor": ("threshold_db", 0.0, 1.0, 4),
+            "pb_Distortion": ("drive_db", 0.5, 1.0, 2), "pb_Delay": ("mix", 0.0, 1.0, 3), "pb_Reverb": ("room_size", 0.0, 1.0, 4)}
+    for name, (param, lo, hi, n_real) in want.items():
+        spec, p, a, b = C.get_case(name)
+        assert (p, a, b) == (param, lo, hi) and list(spec) == [name] and spec[name]["fixed_parameters"]["our_bypass"] == 0.0
+        plugins, total, init = load_plugins(copy.deepcopy(spec))
+        assert total == n_real + 1 and plugins[name]["parameter_names"][0] == "our_bypass" and init[0] == 0.0
+        descs, D = engine.compile_chain(plugins)
+        real = plugins[name]["parameter_names"][1:]
+        fixed = {i for i, nm in enumerate(real) if nm in spec[name]["fixed_parameters"]}
+        assert D == total and descs[0].has_bypass == 1 and descs[0].fixed_mask == sum(1 << i for i in fixed)
+        assert set(range(n_real)) - fixed == {real.index(param)}            # exactly one free parameter
+        for i in fixed:                                                    # the fixed raw values are the normalised own-unit values
+            prm = plugins[name]["instance"].parameters[real[i]]
+            assert descs[0].fixed_raw[i] == pytest.approx((spec[name]["fixed_parameters"][real[i]] - prm.min_value) / (prm.max_value - prm.min_value))
+    with pytest.raises(NotImplementedError):
+        C.get_case("vst_RoughRider3")
+    with pytest.raises(ValueError):
+        C.get_case("pb_Flanger")
+    x = torch.zeros((2, C.MIN_LEN + 1000)); x[:, ::7] = 0.5
+    rng = np.random.RandomState(3)
+    a, b = C.crop_pair(x[:1], x, rng)                                       # mono source -> stereo crop; lengths and guards
+    assert a.shape[0] == 2 and b.shape[0] == 2 and 262144 <= a.shape[1] < 524288 and 262144 <= b.shape[1] < 524288
+    assert float(a.abs().max()) == 1.0 and float(b.abs().max()) == 1.0
