@@ -448,7 +448,8 @@ def main():
     fitness_sha = hashlib.sha256(np.asarray(last_f, dtype=np.float64).tobytes()).hexdigest()[:16]
     conv_each, conv_launches = (ctypes.c_double * 65536)(), ctypes.c_int(0)
     graph_replay = bool(ev._graphs)   # the timed steps replayed the evaluate step's hipGraph (the product default)
-    if timing:
+    eager_region = not args.no_roofline   # EVERY rank runs it (its steps contain the fitness collective); rank 0 records the events
+    if eager_region:
         # The library records HIP events around every MFMA conv launch it makes from the host.  The timed steps above replay the
         # captured graph (no host-side launches), so the per-launch durations come from the SAME steps repeated right behind the
         # timed region with eager launches of the same kernels on the same stream (the CMA-ES simply keeps going); their device
@@ -458,14 +459,16 @@ def main():
         if graph_replay:
             step()   # warm (eager buffers)
             fence()
-        _hip.check(_hip.lib().stito_conv_timing_enable(1))
+        if timing:
+            _hip.check(_hip.lib().stito_conv_timing_enable(1))
         t_e = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         dt_eager = time.perf_counter() - t_e
-        _hip.check(_hip.lib().stito_conv_timing_enable(0))
-        _hip.check(_hip.lib().stito_conv_timing_read_each(conv_each, 65536, ctypes.byref(conv_launches)))
+        if timing:
+            _hip.check(_hip.lib().stito_conv_timing_enable(0))
+            _hip.check(_hip.lib().stito_conv_timing_read_each(conv_each, 65536, ctypes.byref(conv_launches)))
         ev = ev_graph
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

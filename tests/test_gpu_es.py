@@ -675,12 +675,15 @@ def test_bench_gpus2_self_launches_its_ranks(dev):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["STITO_BENCH_BACKEND"] = "gloo"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--seconds", "2",
-                          "--pop-per-gpu", "8", "--no-cpu-baseline", "--no-roofline", "--no-pop512"], env=env, capture_output=True, text=True, timeout=900)
+                          "--pop-per-gpu", "8", "--no-cpu-baseline", "--no-pop512"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # WITH the roofline leg, as the driver runs it: the eager, event-timed steps behind the timed region contain the fitness
+    # collective, so every rank has to run them (round 5 first had rank 0 alone in there: a deadlock at N > 1)
+    assert d["roofline"]["launches_timed"] > 0 and d["launch_mode"]["eager_ms_per_step"] > 0
     assert [r[0] for r in d["config"]["ranks"]] == [0, 1] and d["config"]["backend"] == "gloo"
     assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-2 * d["value"]
     # the per-rank stage breakdown of a multi-GPU run (what would diagnose rank skew / host jitter on a first 8-GPU run)
@@ -768,3 +771,49 @@ def test_case_study_point_against_the_oracle(dev, tmp_path):
     saved = json.load(open(tmp_path / "pb_Distortion" / "case_study_results.json"))
     assert list(saved["different"]["param-panns"]["drive_db"]) == ["0.5", "1.0"]
     assert len(os.listdir(tmp_path / "pb_Distortion" / "audio")) == 4
+
+
+def test_eval_synthetic_harness_against_the_oracle(dev, tmp_path):
+    """The other run_es caller of the reference's evaluation scripts (scripts/eval/eval_synthetic.py:263-456, ES method on the pb
+    plugin set): a two-example data set on disk (dry/ and easy-1/ = the dry examples through the oracle's chain at one setting),
+    the product's run_synthetic_benchmark against oracle.run_synthetic_example with the pairing the harness must choose (the
+    OTHER example of the source type) and the same seeded CMA-ES: selected vectors bit-identical, the four scores and the three
+    saved files (common-length crop, -22 LUFS) within tolerance."""
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import eval_synthetic as S
+    from st_ito import cmaes
+    from st_ito.audio_io import load_wav, save_wav
+    om = O.make_synthetic_model(0)
+    pm = _product_model(dev, om)
+    kinds = ["ParametricEQ", "Compressor", "Distortion", "Delay", "Reverb"]
+    D = sum(p_["num_params"] for p_ in O.make_plugins(kinds).values())
+    w_case = np.random.default_rng(12).random(D) * 0.7
+    root = tmp_path / "data"
+    names = ["music_a", "music_b"]
+    for d in ("dry", "easy-1"):
+        os.makedirs(root / d)
+    raw = {}
+    for i, nm in enumerate(names):
+        x = O.synth_audio(900 + i, 2, 70000 + 3000 * i)
+        raw[nm] = x
+        save_wav(str(root / "dry" / f"{nm}.wav"), x, SR)
+        save_wav(str(root / "easy-1" / f"{nm}.wav"), torch.from_numpy(O.process_audio(x.numpy(), w_case, SR, O.make_plugins(kinds))), SR)
+    got = S.run_synthetic_benchmark(str(root), str(tmp_path / "out"), pm, max_iters=2, popsize=6, seed=3)
+    assert list(got) == ["easy-1"] and len(got["easy-1"]) == 2
+    for n_ex, (dry_name, test_name) in enumerate((("music_a", "music_b"), ("music_b", "music_a"))):
+        ex = f"{dry_name}->easy-1-{test_name}"
+        row = got["easy-1"][ex]["style-es (param-panns)_pb"]
+        rd = lambda sub, nm: O.apply_fade_in(load_wav(str(root / sub / f"{nm}.wav"))[0], 32768).unsqueeze(0)   # noqa: E731
+        ref_row, (o, t, g), res = O.run_synthetic_example(rd("dry", dry_name), rd("easy-1", test_name), rd("easy-1", dry_name),
+                                                          O.make_plugins(kinds, with_bypass=True), om, cmaes.CMAEvolutionStrategy,
+                                                          max_iters=2, popsize=6, seed=3 + n_ex)
+        for k in ("style_error_gt", "style_error_target"):
+            assert abs(row[k] - ref_row[k]) < 1e-4, (ex, k)
+        for k in ("mrstft_error", "mrstft_error_norm"):
+            assert abs(row[k] - ref_row[k]) < 2e-3 * max(1.0, ref_row[k]), (ex, k, row[k], ref_row[k])
+        params = json.load(open(tmp_path / "out" / "results.json"))["easy-1"][ex]["style-es (param-panns)_pb"]
+        assert params["mrstft_error"] == row["mrstft_error"]
+        for stem, want in ((f"{ex}_style-es (param-panns)_pb.wav", o), (f"{ex}_target.wav", t), (f"{ex}_gt.wav", g)):
+            y, sr = load_wav(str(tmp_path / "out" / ex / stem))
+            assert sr == SR and tuple(y.shape) == tuple(want.shape) and np.abs(y.numpy() - want.numpy()).max() < 1e-4, stem
+            assert abs(O.integrated_loudness(y.numpy().T, sr) - (-22.0)) < 0.01

@@ -457,3 +457,25 @@ def test_oracle_es_drivers_on_a_stub_metric():
     r0 = O.run_es(x.clone(), tgt.clone(), 48000, O.make_plugins(["Gain"]), None, cmaes.CMAEvolutionStrategy, embed_func=embed, max_iters=2,
                   popsize=4, sigma0=0.3, seed=11, find_w0=False, early_stop=False)
     np.testing.assert_array_equal(s["stage_wopts"][0], r0["wopt"])
+
+
+def test_mrstft_restatements_agree_and_known_answers():
+    """auraloss' MultiResolutionSTFTLoss (absent: unpinned) restated twice -- the oracle on numpy frames + rfft, the product's
+    harness (st-ito_amd/scripts/eval_synthetic.py) on torch.stft: identical signals give 0, the two agree to float32 rounding,
+    scaling the estimate by a moves only the log-magnitude term by |log a| and the convergence term by |1 - a| (both in closed
+    form from the definition), and the measure is not symmetric in its arguments (the reference's norm is in the denominator)."""
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "st-ito_amd", "scripts"))
+    import eval_synthetic as S
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn((1, 2, 30000), generator=g) * 0.1
+    x = y + 0.01 * torch.randn((1, 2, 30000), generator=g)
+    assert O.mrstft_error(y, y) == 0.0 and float(S.mrstft_error(y, y)) == 0.0
+    a, b = O.mrstft_error(x, y), float(S.mrstft_error(x, y))
+    assert abs(a - b) < 1e-6 * a and 0.05 < a < 0.5
+    assert abs(O.mrstft_error(0.5 * y, y) - (0.5 + np.log(2.0))) < 1e-5       # |Y - Y/2| / |Y| + |log(1/2)| (a few bins sit at the clamp)
+    assert abs(O.mrstft_error(y, 0.5 * y) - (1.0 + np.log(2.0))) < 1e-5       # not symmetric
+    assert S.get_source_type("music_01") == "music" and S.get_source_type("straight_a") == "vocals" and S.get_source_type("speech-3") == "speech"
+    with pytest.raises(ValueError):
+        S.get_source_type("drums_1")
+    assert list(S.get_pb_plugins()) == ["ParametricEQ", "Compressor", "Distortion", "Delay", "Reverb"]
