@@ -14,10 +14,30 @@ identical replica.  Not bit-compatible with pycma (different random stream); sam
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import List, Optional, Sequence
 
 import numpy as np
+
+# ask() and tell() are a handful of (lambda x N) x (N x N) products with N <= 50: a few MFLOP.  A multi-threaded BLAS turns them into
+# a liability as soon as lambda crosses its threading threshold -- measured with OpenBLAS on 8 cores: lambda 512 ask 11.7 ms / tell
+# 11.6 ms against 0.6 / 0.9 ms on one thread, lambda 2048 (8 GPUs x 256) 7.9 / 13.5 against 2.3 / 1.7 -- and every rank of a
+# multi-GPU run steps its own replica on the same host, so eight ranks would each wake a full thread pool.  Both calls therefore run
+# with the BLAS limited to one thread (threadpoolctl, when it is installed); a single thread also makes the replicas' arithmetic
+# independent of the host's core count.
+_BLAS = None
+
+
+def _one_blas_thread():
+    global _BLAS
+    if _BLAS is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _BLAS = ThreadpoolController()
+        except Exception:  # noqa: BLE001 -- not installed: run as the BLAS is configured
+            _BLAS = False
+    return _BLAS.limit(limits=1, user_api="blas") if _BLAS else contextlib.nullcontext()
 
 
 class BoundTransform:
@@ -130,6 +150,10 @@ class CMAEvolutionStrategy:
 
     def ask(self) -> List[np.ndarray]:
         """lambda candidate solutions (phenotypes, inside the bounds)."""
+        with _one_blas_thread():
+            return self._ask()
+
+    def _ask(self) -> List[np.ndarray]:
         z = self._z_next if self._z_next is not None else self.rng.standard_normal((self.lam, self.N))
         self._z_next = None
         y = z * self.D[None, :] @ self.B.T
@@ -145,6 +169,10 @@ class CMAEvolutionStrategy:
             self._z_next = self.rng.standard_normal((self.lam, self.N))
 
     def tell(self, solutions: Sequence[np.ndarray], function_values: Sequence[float]):
+        with _one_blas_thread():
+            self._tell(solutions, function_values)
+
+    def _tell(self, solutions: Sequence[np.ndarray], function_values: Sequence[float]):
         f = np.asarray(function_values, dtype=np.float64)
         if len(f) != self.lam or self._geno is None:
             raise ValueError("tell() needs the fitness of the lambda solutions of the last ask()")
