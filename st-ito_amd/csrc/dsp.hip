@@ -169,8 +169,12 @@ __global__ void k_prepare(ChainArgs chain, const double *__restrict__ w, int P, 
 // ------------------------------------------------------------------------------------------------
 // Parametric EQ
 // ------------------------------------------------------------------------------------------------
-static constexpr int EQ_NC = 256;  // time chunks per stream == threads per workgroup
-static constexpr int EQ_TS = 32;   // samples per LDS tile row
+#ifndef EQ_NC_BUILD
+#define EQ_NC_BUILD 256
+#endif
+static constexpr int EQ_NC = EQ_NC_BUILD;  // time chunks per stream == threads per workgroup
+static constexpr int EQ_TS = 32;   // samples per LDS tile row (= tile floats per thread)
+static constexpr int EQ_NG = EQ_NC / 32;   // 32-lane groups of the workgroup: a group stages one 32-sample row of the tile at a time
 
 struct EqSec { double b0, b1, b2, a1, a2; };
 
@@ -188,8 +192,11 @@ __device__ __forceinline__ double eq_step(double x, const EqSec (&c)[6], double 
 
 __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__restrict__ out, int64_t out_cand_stride,
                                                int C, int64_t L, const double *__restrict__ coef) {
-    __shared__ float tile[EQ_NC][EQ_TS + 1];
-    __shared__ double zst[12][EQ_NC];
+    // the chunk states are only alive between the two passes, while the tile is not: one buffer for both
+    constexpr size_t TILE_B = sizeof(float) * EQ_NC * (EQ_TS + 1), ZST_B = sizeof(double) * 12 * EQ_NC;
+    __shared__ __attribute__((aligned(16))) char tz[TILE_B > ZST_B ? TILE_B : ZST_B];
+    float (*tile)[EQ_TS + 1] = (float (*)[EQ_TS + 1])tz;
+    double (*zst)[EQ_NC] = (double (*)[EQ_NC])tz;
     __shared__ double mat[3][144];
 
     const int s = blockIdx.x;
@@ -215,27 +222,27 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
     double z[12];
     // tile staging: every thread fetches EQ_NC/8 = 32 scattered 4-byte pieces per tile; all of them
     // are issued together into registers one tile ahead of use so HBM latency overlaps the cascade.
-    float pre[EQ_NC / 8];
+    float pre[EQ_TS];
     // Index arithmetic in 32 bits (the launchers refuse streams of 2^31 samples), one add and one min per load: the staging of a
     // tile, not the float64 recurrence, is where this kernel's time went (profiles/README.md; the same lesson as k_conv_first).
     // A tile is INTERIOR when all of its 256 x 32 samples exist (58 of the 59 tiles of a 10 s stream): no masks at all then.
-    const unsigned vbase = (unsigned)lr * (unsigned)B + (unsigned)lj, stride8 = 8u * (unsigned)B, last = (unsigned)L - 1u;
+    const unsigned vbase = (unsigned)lr * (unsigned)B + (unsigned)lj, stride8 = (unsigned)EQ_NG * (unsigned)B, last = (unsigned)L - 1u;
     auto interior = [&](int64_t t0) { return t0 + EQ_TS <= B && (int64_t)(EQ_NC - 1) * B + t0 + EQ_TS <= L; };
     auto fetch = [&](int64_t t0) {  // unconditional loads (clamped); masked in stage(), one tile later
         const unsigned o0 = vbase + (unsigned)t0;
 #pragma unroll
-        for (int it = 0; it < EQ_NC / 8; ++it) pre[it] = x[min(o0 + (unsigned)it * stride8, last)];
+        for (int it = 0; it < EQ_TS; ++it) pre[it] = x[min(o0 + (unsigned)it * stride8, last)];
     };
     auto stage = [&](int64_t t0) {
         if (interior(t0)) {
 #pragma unroll
-            for (int it = 0; it < EQ_NC / 8; ++it) tile[it * 8 + lr][lj] = pre[it];
+            for (int it = 0; it < EQ_TS; ++it) tile[it * EQ_NG + lr][lj] = pre[it];
             return;
         }
         const unsigned o0 = vbase + (unsigned)t0;
         const bool in_chunk = t0 + lj < B;
 #pragma unroll
-        for (int it = 0; it < EQ_NC / 8; ++it) tile[it * 8 + lr][lj] = (in_chunk && o0 + (unsigned)it * stride8 <= last) ? pre[it] : 0.0f;
+        for (int it = 0; it < EQ_TS; ++it) tile[it * EQ_NG + lr][lj] = (in_chunk && o0 + (unsigned)it * stride8 <= last) ? pre[it] : 0.0f;
     };
     // ---- pass A: zero-state response of every chunk, keep only the final state -------------
 #pragma unroll
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
         n = n < 0 ? 0 : (n > EQ_TS ? EQ_TS : n);
         for (int j = 0; j < (int)n; ++j) (void)eq_step((double)tile[tid][j], sec, z);
     }
+    __syncthreads();   // the states go where the tile was: every thread has finished reading its last tile row
 #pragma unroll
     for (int k = 0; k < 12; ++k) zst[k][tid] = z[k];
 
@@ -317,10 +325,10 @@ __global__ __launch_bounds__(EQ_NC) void k_eq(InView in, PostOp post, float *__r
             const unsigned o0 = vbase + (unsigned)t0;
             const bool all = interior(t0), in_chunk = t0 + lj < B;
 #pragma unroll
-            for (int it = 0; it < EQ_NC / 8; ++it) {
+            for (int it = 0; it < EQ_TS; ++it) {
                 const unsigned o = o0 + (unsigned)it * stride8;
                 if (all || (in_chunk && o <= last)) {
-                    const float v = tile[it * 8 + lr][lj] * post_gain;
+                    const float v = tile[it * EQ_NG + lr][lj] * post_gain;
                     y[o] = v;
                     post_max = fmaxf(post_max, fabsf(v));
                 }
