@@ -658,7 +658,6 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
 #pragma unroll
             for (int kk = 0; kk < RV_PD; ++kk) {
                 const int k = k0 + kk;
-                constexpr int dummy = 0; (void)dummy;
                 const int sl = (kk + 1) % RV_PD;
                 RV_BARRIER();
                 RV_RING_WAIT(sl, 12);   // tile k + 1 has landed (the three fetches behind it may still be in flight)
