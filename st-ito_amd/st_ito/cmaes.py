@@ -37,7 +37,12 @@ def _one_blas_thread():
             _BLAS = ThreadpoolController()
         except Exception:  # noqa: BLE001 -- not installed: run as the BLAS is configured
             _BLAS = False
-    return _BLAS.limit(limits=1, user_api="blas") if _BLAS else contextlib.nullcontext()
+    if _BLAS:
+        try:
+            return _BLAS.limit(limits=1, user_api="blas")
+        except Exception:  # noqa: BLE001 -- a BLAS build the controller cannot steer: run as configured from now on
+            _BLAS = False
+    return contextlib.nullcontext()
 
 
 class BoundTransform:
