@@ -235,13 +235,14 @@ class PopulationEvaluator:
         self.max_cand = max_candidates_per_pass
         self.flags = torch.zeros((256, 2), dtype=torch.int32, device=self.device)  # NaN flags, one row per loss call
         # The plain fused call -- one population per pass, no crop, no dropout, no audio handed back: what run_es issues every
-        # iteration -- is captured as ONE hipGraph (render -> log-mel -> Cnn14 -> loss: ~45 launches) and replayed; W travels through
-        # a static device buffer.  STITO_GRAPH=0 keeps the eager launches.  What it buys on an idle host is small (the eager
-        # launches already run ahead of the device: pop 32 6.62 against 6.63 ms per step, pop 256 43.4 against 43.5); what it
-        # removes is the step's dependence on the host's launch rate -- one launch per step instead of ~45 per rank.  (Round 4 had this off: every replay after the first kept
-        # the previous replay's per-candidate peaks and stream maxima, because the hipMemsetAsync nodes that zero those atomicMax
-        # targets were not ordered in front of their kernels on replay; the library now zeroes with kernels -- csrc/common.h
-        # zero_async -- and tests/test_gpu_es.py replays the graph in many fresh processes against the eager result, bit for bit.)
+        # iteration -- is captured as ONE hipGraph (render -> log-mel -> Cnn14 -> loss: ~45 launches) and replayed; W travels
+        # through a static device buffer.  STITO_GRAPH=0 keeps the eager launches.  On an idle host a replay buys little (the
+        # eager launches already run ahead of the device: pop 32 6.56 against 6.60 ms per step, pop 256 43.0 against 43.1); what it
+        # removes is the step's dependence on the host's launch rate: one launch per step and rank instead of ~45.
+        # (Round 4 had this off: every replay after the first kept the previous replay's per-candidate peaks and stream maxima,
+        # because the hipMemsetAsync nodes that zero those atomicMax targets were not ordered in front of their kernels on
+        # replay.  The library now zeroes with a kernel -- csrc/common.h zero_async -- and tests/test_gpu_es.py replays the graph
+        # in 50 fresh processes against the eager result, bit for bit.)
         self._graph_on = (os.environ.get("STITO_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         # a graph is captured on the (capture_after + 1)-th eligible call with the same population size and input buffer.  The
         # capture costs ~10 ms at pop 32 and ~30 ms at pop 256 (private-pool allocations + hipGraphInstantiate of ~45 kernel nodes)
