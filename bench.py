@@ -581,7 +581,10 @@ def main():
                     d["bound_note"] = ("bound by filling LDS from L2, not by the matrix pipe: 4 bytes per operand element (f16 hi + lo) for 21.3 "
                                        "(one sweep) / 32 (two sweeps) MACs; lds_fill = those bytes / launch time (the transform pass is inside the "
                                        "time).  Ceilings: 24 TB/s = the L2 -> LDS rate this build measured for L2-resident streams "
-                                       "(tools/ubench/split_mfma.hip, profiles/round3_split_mfma_ubench.txt); 34.5 TB/s = the guide's L2 bandwidth")
+                                       "(tools/ubench/split_mfma.hip, profiles/round3_split_mfma_ubench.txt); 34.5 TB/s = the guide's L2 bandwidth.  "
+                                       "What the L2 misses are (memory-side counters, profiles/round5_conv_ea_pmc.txt): 2.1 - 2.9 TB/s of reads at "
+                                       "830 - 1 230 L2 clocks, a 30 - 95 % HBM / Infinity-Cache mix far below the fabric's 6.5 - 7.6 TB/s: they cost the "
+                                       "CU's copy queue latency slots, not bandwidth, so the bound stays the L2 -> LDS copy rate")
                     fill_tbps = f["fill"] / f["ms"] / 1e9
                     d["lds_fill"] = {"achieved": round(fill_tbps, 2), "peak": 24.0, "peak_source": "self-measured (split_mfma ubench)", "unit": "TB/s",
                                      "frac": round(fill_tbps / 24.0, 4), "frac_of_guide_l2_34.5": round(fill_tbps / 34.5, 4)}
