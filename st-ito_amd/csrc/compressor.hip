@@ -131,10 +131,14 @@ __global__ __launch_bounds__(256) void k_comp_blockfn(InView in, float *__restri
 // block per lane); states leave as one b128 per four blocks.  z_end[k] = state after block k.  The loop body
 // is generated asm (comp_scan.inc, tools/gen/gen_comp_scan_asm.py): 9.6 instructions per block.
 // ------------------------------------------------------------------------------------------------
+// spw = streams per wave (a power of two <= 16): with fewer than sixteen, the upper quads shadow the lower ones (same values from and to
+// the same addresses, like the idle quads past the last stream) and the launch has 16 / spw times as many waves.  The scan is one
+// dependent chain per stream, but at sixteen streams a wave also pulls 16 x 2 MB of intercepts through ONE CU's memory pipe (35 GB/s
+// per CU at 512 streams: 0.93 ms against a chain of ~0.72); spreading the streams over more CUs takes that off the chain.
 __global__ __launch_bounds__(64) void k_comp_blockscan(const float *__restrict__ fn, float *__restrict__ z_end, CompGeom g,
-                                                        int C, int S, const double *__restrict__ coef) {
+                                                        int C, int S, const double *__restrict__ coef, int spw) {
     const int lane = threadIdx.x, q = lane & 3;
-    const int s_raw = blockIdx.x * 16 + (lane >> 2);
+    const int s_raw = blockIdx.x * spw + ((lane >> 2) & (spw - 1));
     const int s = s_raw < S ? s_raw : S - 1;  // idle quads shadow the last stream (same values to the same addresses)
     const CompCoef cc = comp_coef(coef, s / C);
     const double ca = fmaxf(cc.cat, CB_CMIN), cr = fmaxf(cc.crl, CB_CMIN);
@@ -207,7 +211,14 @@ int compressor_stage(const InView &in, float *audio_dev, int64_t cand_stride, in
     if (g.n_fn > 0) {
         hipLaunchKernelGGL(k_comp_blockfn, dim3((unsigned)((g.n_fn + CB_TILE - 1) / CB_TILE), S), dim3(256), 0, st, in, fn, g, C, coef);
         STITO_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_comp_blockscan, dim3((S + 15) / 16), dim3(64), 0, st, fn, z_end, g, C, S, coef);
+        // streams per wave: eight (measured at 512 streams x 480 000 samples, the whole stage: 2.06 ms with sixteen, 1.85 with eight,
+        // 1.86 with four or two, 1.93 with one), fewer while that leaves three quarters of the CUs without a wave
+        DeviceInfo dinfo;
+        STITO_TRY(device_info(dinfo));
+        int spw = 8;
+        while (spw > 1 && (S + spw - 1) / spw < dinfo.cus / 4) spw >>= 1;
+        if (const char *e = getenv("STITO_COMP_SPW")) { const int v = atoi(e); if (v >= 1 && v <= 16 && (v & (v - 1)) == 0) spw = v; }  // tuning aid
+        hipLaunchKernelGGL(k_comp_blockscan, dim3((S + spw - 1) / spw), dim3(64), 0, st, fn, z_end, g, C, S, coef, spw);
         STITO_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_comp_apply, dim3((unsigned)((g.n_blocks + CA_TILE - 1) / CA_TILE), S), dim3(CA_TILE), 0, st, in, audio_dev,
