@@ -79,13 +79,13 @@ typedef struct {
 } stito_fx_desc;
 
 const char *stito_last_error(void);
-/* ABI version: 9 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
+/* ABI version: 10 (1 = first round; 2: stito_fx_desc.flags was `reserved`; 3: stito_cnn14_weights.conv_wino_algo;
  * 4: STITO_CONV_WINOGRAD_F4_PRE, stito_conv3x3_bn_relu_ws / stito_conv3x3_workspace_bytes; stito_frontend.mel_w_stride
  * was `reserved`: 0 keeps the packed-run layout of versions 1-3; 5: STITO_CONV_WINOGRAD_F4_SPLIT, _F4_SPLIT2,
  * _F4_SPLITK, stito_conv_timing_read_each; 6: STITO_CONV_DIRECT_SPLIT;
  * 7: STITO_CONV_WINOGRAD_F2_REG; 8: stito_conv_block1_f2reg + stito_cnn14_weights.conv1_f2reg_w_dev (appended);
  * 9: algorithms 6 and 7 and stito_conv_block1_fused / stito_cnn14_pack_conv1_fused retired;
- * STITO_CONV_WINOGRAD_F4_SPLIT3). */
+ * STITO_CONV_WINOGRAD_F4_SPLIT3; 10: stito_cnn14_weights.chunk_* (appended), stito_conv_timing_read_tagged). */
 int stito_version(void);
 
 /* LFO of STITO_FX_CHORUS: lfo_dev[n] = sin(phase_n - pi) with juce::dsp::Oscillator's float phase recurrence (phase += 2 pi
@@ -257,6 +257,17 @@ typedef struct {
      * choice cannot be seen in the results. */
     const float *conv_alt_dev[STITO_CNN14_NUM_CONVS];
     int32_t conv_alt_algo[STITO_CNN14_NUM_CONVS];
+    /* ABI v10: depth-first schedule of a run of convs over chunks of streams (replaces the layer-by-layer order of
+     * panns.py:250-261 for that run; same results bit for bit, a stream never meets another one inside a kernel).
+     * chunk_streams > 0: convs chunk_first_conv .. chunk_last_conv (indices 0 .. 11, conv_block<b>.conv<j> = 2 (b - 1) + (j - 1))
+     * run on chunk_streams streams at a time with the maps between them in two chunk-sized scratch buffers that every chunk
+     * reuses, so that the hand-offs of a chunk can stay in the 256 MiB Infinity Cache.  chunk_first_conv == chunk_last_conv:
+     * one layer launched chunk by chunk (only its transformed input is reused).  0 = layer by layer.  Runs the forward cannot
+     * schedule (they would overwrite their own input) fall back to layer by layer. */
+    int32_t chunk_streams;
+    int32_t chunk_first_conv;
+    int32_t chunk_last_conv;
+    int32_t reserved2;
 } stito_cnn14_weights;
 
 /* Number of floats of a packed conv weight for (cout, cin) and algorithm. */
@@ -320,6 +331,9 @@ int stito_conv_timing_read(double *total_ms, int *n_launches);
 /* The same per launch, in launch order (bench.py attributes the launches to the matrix pipe they run on): fills
  * ms_each[0 .. min(cap, n) - 1], returns n in *n_launches and clears the list. */
 int stito_conv_timing_read_each(double *ms_each, int cap, int *n_launches);
+/* The same with the conv index (0 .. 11; 1 for conv_block1 in one launch) of every launch in conv_each (may be NULL): with a
+ * chunked schedule a layer is several launches per pass (ABI v10). */
+int stito_conv_timing_read_tagged(double *ms_each, int *conv_each, int cap, int *n_launches);
 /* FLOPs of the MFMA instructions one launch of this shape issues with `algo`, tile padding included (0 if unsupported or
  * cin % 8 != 0; STITO_CONV_WINOGRAD_F4_SPLIT: the three f16 products per element, i.e. f16-pipe FLOPs).  Measurement aid: bench.py divides it by the launch time for `roofline.achieved`. */
 double stito_conv3x3_issued_flops(int n, int H, int W, int cin, int cout, int pool, int algo);

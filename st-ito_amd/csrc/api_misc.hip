@@ -44,4 +44,4 @@ int device_info(DeviceInfo &info) {
 }  // namespace stito
 
 extern "C" const char *stito_last_error(void) { return stito::g_err; }
-extern "C" int stito_version(void) { return 9; }
+extern "C" int stito_version(void) { return 10; }

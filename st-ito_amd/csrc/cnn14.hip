@@ -1289,6 +1289,58 @@ static size_t cnn14_pre_bytes(const stito_cnn14_weights *w, int n_streams, const
     return align_up(v, 256);
 }
 
+// ---- depth-first schedule of a run of conv layers over chunks of streams (ABI version 10) ----
+// stito_cnn14_weights.chunk_streams > 0: the convs chunk_first_conv .. chunk_last_conv run chunk by chunk -- every layer of the run on
+// the first chunk_streams streams, then on the next ones -- with the maps between them in two chunk-sized scratch buffers that every
+// chunk reuses (and the transformed-input workspace at the same addresses), so that a chunk's X -> transform -> V -> conv hand-offs
+// can stay inside the 256 MiB Infinity Cache instead of making a round trip through HBM.  A stream's results do not depend on
+// which launch it rides in (the kernels never mix streams), so the schedule cannot be seen in the outputs (tested bitwise).
+struct ChunkPlan {
+    int first = -1, last = -1, streams = 0;   // first < 0: no chunked run
+    size_t scratch_floats = 0;                // per scratch buffer (two of them)
+};
+
+static size_t conv_out_floats_per_stream(const stito_cnn14_weights *w, const int H[7], const int W[7], int i) {
+    const int blk = i / 2, j = i % 2;
+    return (j == 1 && blk < 5) ? (size_t)H[blk + 1] * W[blk + 1] * w->channels[blk + 1] : (size_t)H[blk] * W[blk] * w->channels[blk + 1];
+}
+
+static ChunkPlan cnn14_chunk_plan(const stito_cnn14_weights *w, int n_streams, const int H[7], const int W[7], bool fuse1r) {
+    ChunkPlan p;
+    int first = w->chunk_first_conv, last = w->chunk_last_conv;
+    const int sc = w->chunk_streams;
+    if (sc <= 0 || sc >= n_streams || first < 0 || last >= STITO_CNN14_NUM_CONVS || first > last) return p;
+    if (fuse1r && first == 1) first = 0;            // conv_block1 is one launch: both convs or neither
+    if (fuse1r && last == 0) last = 1;
+    if (!fuse1r && first == 0 && w->channels[0] % 8 != 0 && last == 0) return p;   // a lone first conv has nothing to hand over
+    if (first == last) {                            // a single layer: its transformed input is what stays in the cache; no scratch maps
+        p.first = first; p.last = last; p.streams = sc;
+        return p;
+    }
+    // the run's output lands in the buffer the layer-by-layer schedule would use (actA for a block's first conv, actB for its
+    // second); the run's input must not be overwritten by an earlier chunk's output: it is, when both live in actB, unless a
+    // stream's output is no larger than its input (chunk c's output then ends before chunk c + 1's input starts)
+    if (last % 2 == 1 && first % 2 == 0 && first > 0) {
+        const size_t in_ps = conv_out_floats_per_stream(w, H, W, first - 1), out_ps = conv_out_floats_per_stream(w, H, W, last);
+        if (out_ps > in_ps) return p;
+    }
+    if (last % 2 == 0 && first % 2 == 1) return p;  // input and output both in actA (mid-block start): not scheduled
+    size_t m = 0;
+    for (int i = first; i < last; ++i) {
+        if (fuse1r && i == 0) continue;             // never materialised
+        const size_t f = conv_out_floats_per_stream(w, H, W, i);
+        m = f > m ? f : m;
+    }
+    p.first = first; p.last = last; p.streams = sc;
+    p.scratch_floats = m * (size_t)sc;
+    return p;
+}
+
+static bool cnn14_fuse1r(const stito_cnn14_weights *w, int S, const int H[7], const int W[7]) {
+    return w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr && w->conv_wino_algo[1] == STITO_CONV_WINOGRAD_F2_REG &&
+           w->channels[0] == 1 && stito_conv_block1_f2reg_supported(S, H[0], W[0], w->channels[1], w->channels[1], 1);
+}
+
 extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int n_streams, int64_t n_frames) {
     int H[7], W[7];
     cnn14_dims(n_frames, w->n_mels, H, W);
@@ -1300,8 +1352,10 @@ extern "C" size_t stito_cnn14_workspace_bytes(const stito_cnn14_weights *w, int 
         b = pooled > b ? pooled : b;
     }
     const size_t feat = (size_t)n_streams * w->channels[6];
+    const ChunkPlan plan = cnn14_chunk_plan(w, n_streams, H, W, cnn14_fuse1r(w, n_streams, H, W));
     return align_up(a * 4, 256) + align_up(b * 4, 256) + align_up(feat * 4, 256) + cnn14_pre_bytes(w, n_streams, H, W) +
-           STITO_CNN14_NUM_CONVS * align_up((size_t)n_streams * sizeof(unsigned), 256) + 256;  // + per-stream output maxima, one buffer per conv (split-precision layers)
+           STITO_CNN14_NUM_CONVS * align_up((size_t)n_streams * sizeof(unsigned), 256) + 256 +  // + per-stream output maxima, one buffer per conv (split-precision layers)
+           2 * align_up(plan.scratch_floats * 4, 256);                                         // + the chunked run's two scratch maps
 }
 
 // ---- optional launch timing for bench.py: HIP events on the launch stream around the MFMA convs ----
@@ -1309,6 +1363,7 @@ namespace {
 struct ConvTiming {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;  // created on demand, reused
+    std::vector<int> conv;                                // conv index of the launch (the second conv's for conv_block1 in one launch)
     size_t used = 0;
 };
 thread_local ConvTiming g_conv_timing;  // one host thread drives one GPU: the state is per thread, like stito_last_error
@@ -1335,17 +1390,123 @@ extern "C" int stito_conv_timing_read(double *total_ms, int *n_launches) {
 }
 
 extern "C" int stito_conv_timing_read_each(double *ms_each, int cap, int *n_launches) {
+    return stito_conv_timing_read_tagged(ms_each, nullptr, cap, n_launches);
+}
+
+extern "C" int stito_conv_timing_read_tagged(double *ms_each, int *conv_each, int cap, int *n_launches) {
     STITO_REQUIRE(ms_each != nullptr && n_launches != nullptr && cap >= 0, STITO_E_INVALID, "null output");
     for (size_t i = 0; i < g_conv_timing.used; ++i) {
         float ms = 0.f;
         STITO_HIP_CHECK(hipEventSynchronize(g_conv_timing.pool[i].second));
         STITO_HIP_CHECK(hipEventElapsedTime(&ms, g_conv_timing.pool[i].first, g_conv_timing.pool[i].second));
-        if ((int)i < cap) ms_each[i] = ms;
+        if ((int)i < cap) {
+            ms_each[i] = ms;
+            if (conv_each != nullptr) conv_each[i] = g_conv_timing.conv[i];
+        }
     }
     *n_launches = (int)g_conv_timing.used;
     g_conv_timing.used = 0;
     return STITO_OK;
 }
+
+namespace {
+struct TimedLaunch {   // brackets one conv launch with events when the bench asked for them
+    hipStream_t st;
+    bool on;
+    TimedLaunch(hipStream_t s, bool enable) : st(s), on(enable) {}
+    int begin(int conv) {
+        if (!on) return STITO_OK;
+        if (g_conv_timing.used == g_conv_timing.pool.size()) {
+            hipEvent_t e0, e1;
+            STITO_HIP_CHECK(hipEventCreate(&e0));
+            STITO_HIP_CHECK(hipEventCreate(&e1));
+            g_conv_timing.pool.emplace_back(e0, e1);
+            g_conv_timing.conv.push_back(0);
+        }
+        g_conv_timing.conv[g_conv_timing.used] = conv;
+        STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
+        return STITO_OK;
+    }
+    int end() {
+        if (!on) return STITO_OK;
+        STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
+        return STITO_OK;
+    }
+};
+
+struct Trunk {
+    const stito_cnn14_weights *w;
+    int H[7], W[7];
+    void *stream;
+    void *vbuf;
+    size_t vbytes;
+    unsigned *amax_all;
+    size_t amax_stride;
+    int n_cus;
+    bool fuse1r;
+
+    unsigned *amax_of(int conv, int s0) const { return (unsigned *)((char *)amax_all + amax_stride * conv) + s0; }
+
+    // does conv i + 1 run a kernel that scales its transformed input by per-stream maxima of conv i's output?
+    bool next_wants_amax(int i, int S) const {
+        if (i + 1 >= STITO_CNN14_NUM_CONVS) return false;
+        const int nb = (i + 1) / 2, nj = (i + 1) % 2;
+        const int nci = nj == 0 ? w->channels[nb] : w->channels[nb + 1], npool = (nj == 1 && nb < 5) ? 1 : 0;
+        const int nalgo = w->conv_wino_algo[i + 1];
+        return w->conv_wino_dev[i + 1] != nullptr &&
+               (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
+                nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
+               stito_conv3x3_supported(S, H[nb], W[nb], nci, w->channels[nb + 1], npool, nalgo);
+    }
+
+    // conv_block1 as one launch on the register-resident F(2x2,3x3) kernel (it computes the first conv into its patch ring)
+    int block1(const float *in, float *out, int S, int s0, bool &have_amax) const {
+        TimedLaunch t((hipStream_t)stream, g_conv_timing.on);
+        STITO_TRY(t.begin(1));
+        unsigned *amax_out = next_wants_amax(1, S) ? amax_of(1, s0) : nullptr;
+        const int cout = w->channels[1];
+        const int rc = stito_conv_block1_f2reg(in, w->conv1_f2reg_w_dev, w->conv_wino_dev[1], w->bn_scale_dev[1], w->bn_shift_dev[1], out,
+                                               S, H[0], W[0], cout, cout, 1, vbuf, vbytes, stream, amax_out);
+        if (rc) return rc;
+        have_amax = amax_out != nullptr;
+        return t.end();
+    }
+
+    // conv i on streams s0 .. s0 + S - 1: in / out point at the first of them; have_amax: in -- the producer of `in` reported
+    // these streams' maxima (buffer of conv i - 1), out -- this launch reported its own
+    int conv(int i, const float *in, float *out, int S, int s0, bool &have_amax) const {
+        const int blk = i / 2, j = i % 2;
+        const int cin = w->channels[blk], cout = w->channels[blk + 1];
+        const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
+        // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
+        int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE ||
+                     w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
+                     w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F2_REG)
+                        ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;  // (a split packing has no float32 fallback: the direct kernel takes over)
+        if (walgo == STITO_CONV_WINOGRAD_F4_PRE && !stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo))
+            walgo = STITO_CONV_WINOGRAD_F4;  // same packing
+        const float *wino_w = w->conv_wino_dev[i];
+        if (walgo == STITO_CONV_WINOGRAD_F4_SPLIT3 && w->conv_alt_dev[i] != nullptr && w->conv_alt_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 &&
+            4 * wino43_split3_workgroups(ConvShape{S, H[blk], W[blk], ci, cout}, pool != 0) < 3 * n_cus &&
+            stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, STITO_CONV_WINOGRAD_F4_SPLIT2)) {
+            walgo = STITO_CONV_WINOGRAD_F4_SPLIT2;   // too few of the large workgroups for this batch: the alternative packing
+            wino_w = w->conv_alt_dev[i];
+        }
+        const bool wino = wino_w != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
+        TimedLaunch t((hipStream_t)stream, g_conv_timing.on && ci % 8 == 0);
+        STITO_TRY(t.begin(i));
+        const int algo_i = wino ? walgo : STITO_CONV_DIRECT;
+        // can this layer's kernel report the maxima the next one wants?
+        unsigned *amax_out = nullptr;
+        if ((algo_i >= STITO_CONV_WINOGRAD_F4 || (algo_i == STITO_CONV_DIRECT && ci == 1 && !pool)) && next_wants_amax(i, S)) amax_out = amax_of(i, s0);
+        const int rc = conv3x3_ws(in, wino ? wino_w : w->conv_w_dev[i], w->bn_scale_dev[i], w->bn_shift_dev[i], out, S, H[blk], W[blk], ci, cout, pool,
+                                  algo_i, vbuf, vbytes, stream, (have_amax && i > 0) ? amax_of(i - 1, s0) : nullptr, amax_out);
+        if (rc) return rc;
+        have_amax = amax_out != nullptr;
+        return t.end();
+    }
+};
+}  // namespace
 
 extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *logmel_dev, int n_cand, int channels,
                                    int64_t n_frames, float *mid_dev, float *side_dev, void *workspace_dev,
@@ -1354,8 +1515,11 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     STITO_REQUIRE(channels == 1 || channels == 2, STITO_E_INVALID, "Invalid number of channels: %d", channels);
     STITO_REQUIRE(n_cand > 0, STITO_E_INVALID, "empty batch");
     const int S = n_cand * channels;
-    int H[7], W[7];
-    cnn14_dims(n_frames, w->n_mels, H, W);
+    Trunk tr;
+    tr.w = w;
+    tr.stream = stream;
+    cnn14_dims(n_frames, w->n_mels, tr.H, tr.W);
+    const int *H = tr.H, *W = tr.W;
     STITO_REQUIRE(H[5] >= 1 && W[5] >= 1, STITO_E_INVALID,
                   "Given input size: (%dx%dx%d). Calculated output size is too small (audio shorter than 5 poolings)",
                   w->channels[5], H[4], W[4]);
@@ -1371,109 +1535,66 @@ extern "C" int stito_cnn14_forward(const stito_cnn14_weights *w, const float *lo
     float *actA = (float *)ws;
     float *actB = (float *)(ws + align_up(a * 4, 256));
     float *feat = (float *)(ws + align_up(a * 4, 256) + align_up(b * 4, 256));
-    const size_t vbytes = cnn14_pre_bytes(w, S, H, W);
-    void *vbuf = ws + align_up(a * 4, 256) + align_up(b * 4, 256) + align_up((size_t)S * w->channels[6] * 4, 256);
+    tr.vbytes = cnn14_pre_bytes(w, S, H, W);
+    tr.vbuf = ws + align_up(a * 4, 256) + align_up(b * 4, 256) + align_up((size_t)S * w->channels[6] * 4, 256);
     // per-stream output maxima, handed from a layer to the split-precision layer behind it: one buffer per conv, all zeroed by
-    // ONE memset at the top of the pass (a memset per layer was ten more dispatches per pass)
-    const size_t amax_stride = align_up((size_t)S * sizeof(unsigned), 256);
-    unsigned *const amax_all = (unsigned *)((char *)vbuf + vbytes);
-    STITO_TRY(zero_async(amax_all, amax_stride * STITO_CNN14_NUM_CONVS, st));
-    const unsigned *amax_have = nullptr;  // maxima of the current input, if its producer reported them
-
+    // ONE launch at the top of the pass (one per layer was ten more dispatches per pass)
+    tr.amax_stride = align_up((size_t)S * sizeof(unsigned), 256);
+    tr.amax_all = (unsigned *)((char *)tr.vbuf + tr.vbytes);
+    STITO_TRY(zero_async(tr.amax_all, tr.amax_stride * STITO_CNN14_NUM_CONVS, st));
     DeviceInfo dinfo;
     STITO_TRY(device_info(dinfo));   // cached per device
-    const int n_cus = dinfo.cus;
-    const float *cur = logmel_dev;
-    // conv_block1 as one launch on the register-resident F(2x2,3x3) kernel, which computes the first conv into its patch ring
-    const bool fuse1r = w->conv1_f2reg_w_dev != nullptr && w->conv_wino_dev[1] != nullptr &&
-                        w->conv_wino_algo[1] == STITO_CONV_WINOGRAD_F2_REG && w->channels[0] == 1 &&
-                        stito_conv_block1_f2reg_supported(S, H[0], W[0], w->channels[1], w->channels[1], 1) &&
-                        vbytes >= stito_conv_block1_f2reg_workspace_bytes(S, H[0], W[0], w->channels[1], w->channels[1], 1);
-    for (int blk = 0; blk < 6; ++blk) {
-        const int cin = w->channels[blk], cout = w->channels[blk + 1];
-        if (blk == 0 && fuse1r) {
-            const bool timed = g_conv_timing.on;
-            if (timed) {
-                if (g_conv_timing.used == g_conv_timing.pool.size()) {
-                    hipEvent_t e0, e1;
-                    STITO_HIP_CHECK(hipEventCreate(&e0));
-                    STITO_HIP_CHECK(hipEventCreate(&e1));
-                    g_conv_timing.pool.emplace_back(e0, e1);
+    tr.n_cus = dinfo.cus;
+    tr.fuse1r = cnn14_fuse1r(w, S, H, W) && tr.vbytes >= stito_conv_block1_f2reg_workspace_bytes(S, H[0], W[0], w->channels[1], w->channels[1], 1);
+    const ChunkPlan plan = cnn14_chunk_plan(w, S, H, W, tr.fuse1r);
+    float *chA = (float *)((char *)tr.amax_all + tr.amax_stride * STITO_CNN14_NUM_CONVS);   // the chunked run's two scratch maps
+    float *chB = (float *)((char *)chA + align_up(plan.scratch_floats * 4, 256));
+
+    const float *cur = logmel_dev;   // input of conv i
+    bool have_amax = false;          // its producer reported the per-stream maxima
+    // the buffer the layer-by-layer schedule gives conv i's output: a block's first conv writes actA, its second actB
+    auto home = [&](int i) { return i % 2 == 0 ? actA : actB; };
+    for (int i = 0; i < STITO_CNN14_NUM_CONVS;) {
+        if (i == plan.first) {
+            // ---- the chunked run: every layer of it on one chunk of streams after the other ----
+            const size_t in_ps = i == 0 ? (size_t)H[0] * W[0] * (w->channels[0] >= 8 ? w->channels[0] : 1) : conv_out_floats_per_stream(w, H, W, i - 1);
+            const size_t out_ps = conv_out_floats_per_stream(w, H, W, plan.last);
+            float *const run_out = home(plan.last);
+            bool all_amax = true;
+            for (int s0 = 0; s0 < S; s0 += plan.streams) {
+                const int sc = S - s0 < plan.streams ? S - s0 : plan.streams;
+                const float *cin_ptr = cur + (size_t)s0 * in_ps;
+                bool camax = have_amax;
+                int flip = 0;
+                for (int k = plan.first; k <= plan.last;) {
+                    const bool b1 = k == 0 && tr.fuse1r;   // conv_block1's two convs are one launch writing conv 1's output
+                    const int k_out = b1 ? 1 : k;
+                    float *o = k_out == plan.last ? run_out + (size_t)s0 * out_ps : (flip ? chB : chA);
+                    if (b1) STITO_TRY(tr.block1(cin_ptr, o, sc, s0, camax));
+                    else STITO_TRY(tr.conv(k, cin_ptr, o, sc, s0, camax));
+                    cin_ptr = o;
+                    flip ^= 1;
+                    k = k_out + 1;
                 }
-                STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
+                all_amax = all_amax && camax;
             }
-            unsigned *amax_out = nullptr;   // maxima for conv_block2.conv1 when it runs a split-precision kernel
-            {
-                const int nalgo = w->conv_wino_algo[2];
-                if (w->conv_wino_dev[2] != nullptr &&
-                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
-                     nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
-                    stito_conv3x3_supported(S, H[1], W[1], w->channels[1], w->channels[2], 0, nalgo)) {
-                    amax_out = (unsigned *)((char *)amax_all + amax_stride * 1);
-                }
-            }
-            const int rc = stito_conv_block1_f2reg(cur, w->conv1_f2reg_w_dev, w->conv_wino_dev[1], w->bn_scale_dev[1], w->bn_shift_dev[1], actB,
-                                                   S, H[0], W[0], cout, cout, 1, vbuf, vbytes, stream, amax_out);
-            if (rc) return rc;
-            amax_have = amax_out;
-            if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
-            cur = actB;
+            have_amax = all_amax;
+            cur = run_out;
+            i = plan.last + 1;
             continue;
         }
-        for (int j = 0; j < 2; ++j) {
-            const int i = 2 * blk + j;
-            const int ci = j == 0 ? cin : cout, pool = (j == 1 && blk < 5) ? 1 : 0;
-            // Winograd where a transformed weight set was supplied and the map fits; direct otherwise
-            int walgo = (w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_PRE ||
-                         w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 || w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
-                                                  w->conv_wino_algo[i] == STITO_CONV_WINOGRAD_F2_REG)
-                            ? w->conv_wino_algo[i] : STITO_CONV_WINOGRAD;  // (a split packing has no float32 fallback: the direct kernel takes over)
-            if (walgo == STITO_CONV_WINOGRAD_F4_PRE && !stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo))
-                walgo = STITO_CONV_WINOGRAD_F4;  // same packing
-            const float *wino_w = w->conv_wino_dev[i];
-            if (walgo == STITO_CONV_WINOGRAD_F4_SPLIT3 && w->conv_alt_dev[i] != nullptr && w->conv_alt_algo[i] == STITO_CONV_WINOGRAD_F4_SPLIT2 &&
-                4 * wino43_split3_workgroups(ConvShape{S, H[blk], W[blk], ci, cout}, pool != 0) < 3 * n_cus &&
-                stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, STITO_CONV_WINOGRAD_F4_SPLIT2)) {
-                walgo = STITO_CONV_WINOGRAD_F4_SPLIT2;   // too few of the large workgroups for this batch: the alternative packing
-                wino_w = w->conv_alt_dev[i];
-            }
-            const bool wino = wino_w != nullptr && stito_conv3x3_supported(S, H[blk], W[blk], ci, cout, pool, walgo);
-            const bool timed = g_conv_timing.on && ci % 8 == 0;
-            if (timed) {
-                if (g_conv_timing.used == g_conv_timing.pool.size()) {
-                    hipEvent_t e0, e1;
-                    STITO_HIP_CHECK(hipEventCreate(&e0));
-                    STITO_HIP_CHECK(hipEventCreate(&e1));
-                    g_conv_timing.pool.emplace_back(e0, e1);
-                }
-                STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used].first, st));
-            }
-            const int algo_i = wino ? walgo : STITO_CONV_DIRECT;
-            // does the next conv run a split-precision kernel (it scales its transformed input by this layer's per-stream maxima)
-            // and can this layer's kernel report them?
-            unsigned *amax_out = nullptr;
-            if (i + 1 < STITO_CNN14_NUM_CONVS && (algo_i >= STITO_CONV_WINOGRAD_F4 || (algo_i == STITO_CONV_DIRECT && ci == 1 && !pool))) {
-                const int nb = (i + 1) / 2, nj = (i + 1) % 2;
-                const int nci = nj == 0 ? w->channels[nb] : w->channels[nb + 1], npool = (nj == 1 && nb < 5) ? 1 : 0;
-                const int nalgo = w->conv_wino_algo[i + 1];
-                if (w->conv_wino_dev[i + 1] != nullptr &&
-                    (nalgo == STITO_CONV_WINOGRAD_F4_SPLIT || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT2 || nalgo == STITO_CONV_WINOGRAD_F4_SPLIT3 ||
-                     nalgo == STITO_CONV_WINOGRAD_F2_REG) &&
-                    stito_conv3x3_supported(S, H[nb], W[nb], nci, w->channels[nb + 1], npool, nalgo)) {
-                    amax_out = (unsigned *)((char *)amax_all + amax_stride * i);
-                }
-            }
-            const int rc = conv3x3_ws(j == 0 ? cur : actA, wino ? wino_w : w->conv_w_dev[i], w->bn_scale_dev[i],
-                                      w->bn_shift_dev[i], j == 0 ? actA : actB, S, H[blk], W[blk], ci, cout, pool,
-                                      algo_i, vbuf, vbytes, stream, amax_have, amax_out);
-            if (rc) return rc;
-            amax_have = amax_out;
-            if (timed) STITO_HIP_CHECK(hipEventRecord(g_conv_timing.pool[g_conv_timing.used++].second, st));
+        if (i == 0 && tr.fuse1r) {
+            STITO_TRY(tr.block1(cur, actB, S, 0, have_amax));
+            cur = actB;
+            i = 2;
+            continue;
         }
-        cur = actB;
+        STITO_TRY(tr.conv(i, cur, home(i), S, 0, have_amax));
+        cur = home(i);
+        ++i;
     }
     const int C6 = w->channels[6], E = w->embed_dim;
-    hipLaunchKernelGGL(k_head, dim3((C6 + 255) / 256, S), dim3(256), 0, st, actB, feat, H[6], W[6], C6);
+    hipLaunchKernelGGL(k_head, dim3((C6 + 255) / 256, S), dim3(256), 0, st, cur, feat, H[6], W[6], C6);
     STITO_LAUNCH_CHECK();
     const size_t lds = (size_t)FC_SB * (C6 > 256 ? C6 : 256) * sizeof(float);  // the features of 8 streams; reused for 4 x 64 x 8 partial sums
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_fc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

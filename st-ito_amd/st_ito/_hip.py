@@ -53,6 +53,7 @@ class Cnn14Weights(Structure):
         ("reserved_ptr", c_void_p),
         ("conv1_f2reg_w_dev", c_void_p),
         ("conv_alt_dev", c_void_p * 12), ("conv_alt_algo", c_int32 * 12),
+        ("chunk_streams", c_int32), ("chunk_first_conv", c_int32), ("chunk_last_conv", c_int32), ("reserved2", c_int32),
     ]
 
 
@@ -92,6 +93,7 @@ SIGNATURES = {
     "stito_conv_timing_enable": (c_int, [c_int]),
     "stito_conv_timing_read": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "stito_conv_timing_read_each": (c_int, [POINTER(ctypes.c_double), c_int, POINTER(c_int)]),
+    "stito_conv_timing_read_tagged": (c_int, [POINTER(ctypes.c_double), POINTER(c_int), c_int, POINTER(c_int)]),
     "stito_cnn14_packed_conv1_f2reg_floats": (c_size_t, []),
     "stito_cnn14_pack_conv1_f2reg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "stito_conv_block1_f2reg_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),

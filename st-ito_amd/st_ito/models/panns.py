@@ -144,6 +144,11 @@ class Cnn14(nn.Module):
         self.conv_f2reg = os.environ.get("STITO_CONV_F2REG", "1") != "0"
         # conv_block1 as ONE launch of that kernel (the first conv computed into its patch ring); STITO_CONV_FUSE1=0: two launches
         self.conv_fuse1 = os.environ.get("STITO_CONV_FUSE1", "1") != "0"
+        # depth-first schedule (stito_cnn14_weights.chunk_*, ABI v10): STITO_TRUNK_CHUNK = streams per chunk (0 = layer by layer),
+        # STITO_TRUNK_CHUNK_CONVS = "first:last" conv indices of the run (conv_block<b>.conv<j> = 2 (b - 1) + (j - 1))
+        self.trunk_chunk = int(os.environ.get("STITO_TRUNK_CHUNK", "0"))
+        first, _, last = os.environ.get("STITO_TRUNK_CHUNK_CONVS", "2:6").partition(":")
+        self.trunk_chunk_convs = (int(first), int(last or first))
 
     # ------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -177,6 +182,7 @@ class Cnn14(nn.Module):
         keep = []
         W = _hip.Cnn14Weights()
         W.embed_dim, W.n_mels = self.embed_dim, self.mel_bins
+        W.chunk_streams, (W.chunk_first_conv, W.chunk_last_conv) = self.trunk_chunk, self.trunk_chunk_convs
         chans = [1, 64, 128, 256, 512, 1024, 2048]
         for i, c in enumerate(chans):
             W.channels[i] = c

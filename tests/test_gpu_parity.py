@@ -791,6 +791,46 @@ def test_trunk_small_batches_take_the_two_sweep_packing(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("first,last,chunk", [(2, 6, 4), (2, 6, 6), (0, 6, 4), (2, 5, 4), (3, 7, 4), (4, 4, 4), (0, 11, 3), (2, 11, 2), (1, 2, 4), (3, 6, 4)])
+def test_trunk_depth_first_chunks_are_bitwise_the_layer_by_layer_schedule(dev, first, last, chunk):
+    """stito_cnn14_weights.chunk_* (ABI v10): a run of convs scheduled depth-first over chunks of streams (round 6: the hand-offs
+    of a chunk stay in the Infinity Cache) returns the embeddings of the layer-by-layer order bit for bit -- chunk sizes that do
+    and do not divide the batch (14 streams), runs that start / end on either conv of a block, the run with conv_block1's single
+    launch inside, one layer alone, a run that starts on conv_block1's second conv (it takes the whole one-launch block), and a run the forward
+    refuses to schedule ((3, 6): a mid-block start ending on a first conv -- input and output would share a buffer -- runs layer by
+    layer) -- and every layer is still timed (launch count = layers x chunks)."""
+    from st_ito import _hip
+    from st_ito.models.panns import Cnn14
+    L = _hip.lib()
+    om = O.fill_deterministic(O.Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "minmax"), 0).eval()
+    base = [O.synth_audio(50 + k, 2, 120000) for k in range(3)]
+    x = torch.stack([base[i % 3] * (1.0 if i != 2 else 1e-3) * (1.0 + 0.05 * i) for i in range(7)]).to(dev)   # 14 streams
+    outs, counts = {}, {}
+    for kind in ("layers", "chunks"):
+        pm = Cnn14(512, SR, 2048, 1024, 128, 20, 20000, True, "minmax")
+        pm.load_state_dict(om.state_dict())
+        pm.eval().to(dev)
+        pm.trunk_chunk, pm.trunk_chunk_convs = (chunk, (first, last)) if kind == "chunks" else (0, (2, 6))
+        _hip.check(L.stito_conv_timing_enable(1))
+        try:
+            outs[kind] = [t.clone() for t in pm(x)]
+            ms, tag, cnt = (ctypes.c_double * 512)(), (ctypes.c_int * 512)(), ctypes.c_int()
+            _hip.check(L.stito_conv_timing_read_tagged(ms, tag, 512, ctypes.byref(cnt)))
+        finally:
+            _hip.check(L.stito_conv_timing_enable(0))
+        counts[kind] = [list(tag[: cnt.value]).count(i) for i in range(12)]
+    assert counts["layers"] == [0] + [1] * 11, counts
+    n_chunks = -(-14 // chunk)
+    if first == 1:
+        first = 0   # conv_block1 is one launch
+    unscheduled = (first % 2 == 1 and last % 2 == 0 and first != last)
+    lo = 1 if first == 0 else first
+    want = [0] + [n_chunks if (lo <= i <= last and not unscheduled) else 1 for i in range(1, 12)]
+    assert counts["chunks"] == want, (counts, want)
+    for a, b in zip(outs["layers"], outs["chunks"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("norm", ["batchnorm", "minmax", "none"])
 def test_trunk_block1_one_launch_is_the_default_and_matches_two_launches(dev, norm):
     """The default trunk runs conv_block1 as ONE launch (conv1_f2reg_w_dev set -> stito_cnn14_forward calls

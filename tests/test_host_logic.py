@@ -22,7 +22,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/stito_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
-    assert lib.stito_version() == 9
+    assert lib.stito_version() == 10
     for retired in (6, 7):   # the split-precision experiments of rounds 3 - 4: numbers reserved, nothing behind them
         assert lib.stito_conv3x3_supported(2, 32, 32, 64, 64, 0, retired) == 0
         assert lib.stito_cnn14_packed_conv_floats(64, 64, retired) == 0
