@@ -307,17 +307,57 @@ def cpu_baseline(n_samples, kinds, budget_s=12.0):
     return out
 
 
+# The BASELINE.json configurations bench.py can run (the first 8-GPU run must be able to measure the two
+# 8-GPU configurations BASELINE names, not only weak-scaled configs[1]).  pop_per_gpu x N = the configuration's population at N = 8.
+BASELINE_CONFIGS = {
+    1: dict(baseline="1xMI355X, pop=256, 48 kHz stereo 10 s, 5-effect chain (EQ/comp/reverb/EQ/gain), AFx-Rep param metric, 25 iters",
+            pop_per_gpu=256, seconds=10.0, steps=5, chain="bench5"),
+    3: dict(baseline="8xMI355X, pop=2048 sharded 256/GPU, RCCL all-gather fitness over xGMI, 48 kHz stereo 30 s, 50 iters",
+            pop_per_gpu=256, seconds=30.0, steps=50, chain="bench5"),
+    4: dict(baseline="8xMI355X, convolution-reverb IR=2 s in chain (partitioned FFT-conv), pop=1024, 48 kHz stereo 30 s -- HBM-bound long-FIR stress",
+            pop_per_gpu=128, seconds=30.0, steps=10, chain="bench5-convreverb"),
+}
+
+
+def bench_plugins(chain):
+    """-> (plugin dict in the reference's schema, effect kinds for the workload string / the CPU oracle).  "bench5" = EQ / compressor /
+    Freeverb / EQ / gain; "bench5-convreverb" = the same with the noise-shaped CONVOLUTION reverb (96 000 taps = 2 s at 48 kHz,
+    partitioned FFT convolution: csrc/convreverb.hip) in the reverb's place -- BASELINE.json configs[4]."""
+    import functools
+    from st_ito import effects as E
+    if chain == "bench5":
+        return E.make_plugins("bench5"), ["ParametricEQ", "Compressor", "Reverb", "ParametricEQ", "Gain"]
+    spec = [("ParametricEQ", E.BasicParametricEQ, 1), ("Compressor", E.BasicCompressor, 1),
+            ("ConvReverb", functools.partial(E.NoiseShapedReverb, num_samples=96000), 2),
+            ("ParametricEQ2", E.BasicParametricEQ, 1), ("Gain", E.BasicGain, 1)]
+    return E.make_plugins(spec), ["ParametricEQ", "Compressor", "NoiseShapedReverb(96000 taps)", "ParametricEQ", "Gain"]
+
+
+def workload_string(args, cfg, world, D, kinds):
+    P_total = args.pop_per_gpu * world
+    return (f"BASELINE.json configs[{args.config}] ({cfg['baseline']}) as run here: ES evaluate-population, pop={args.pop_per_gpu}/GPU "
+            f"({P_total} total), 48 kHz stereo {args.seconds:g} s, chain {'/'.join(kinds)} (D={D}), AFx-Rep Cnn14 (seeded random weights), "
+            "CMA-ES seed 42")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 5; --config 3: its 50 iterations; --config 4: 10)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pop-per-gpu", type=int, default=256)
-    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(BASELINE_CONFIGS),
+                    help="BASELINE.json configs[] index: 1 = the configuration the metric is quoted on (default); 3 and 4 = the two 8-GPU "
+                         "configurations (their per-GPU share at any --gpus)")
+    ap.add_argument("--pop-per-gpu", type=int, default=None)
+    ap.add_argument("--seconds", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pop512", action="store_true", help="skip the second timed region at BASELINE.json's target population (512 per GPU)")
     args = ap.parse_args()
+    cfg = BASELINE_CONFIGS[args.config]
+    args.steps = cfg["steps"] if args.steps is None else args.steps
+    args.pop_per_gpu = cfg["pop_per_gpu"] if args.pop_per_gpu is None else args.pop_per_gpu
+    args.seconds = cfg["seconds"] if args.seconds is None else args.seconds
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started from a bare shell: launch one rank per GPU through torch.distributed.run (what the driver does itself
@@ -356,8 +396,12 @@ def main():
         stages = {name: {"min": min(s_[i] for s_ in stages_all), "max": max(s_[i] for s_ in stages_all)}
                   for i, name in enumerate(("evaluate_ms", "gather_ms", "tell_ms"))}
         if rank == 0:
+            pl, kinds_d = bench_plugins(cfg["chain"])
+            D_d = sum(p_["num_params"] for p_ in pl.values())
             print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": seen, "max_over_ranks": float(t.item()),
-                              "steps": args.steps, "warmup": args.warmup, "stages": stages}), flush=True)
+                              "steps": args.steps, "warmup": args.warmup, "stages": stages,
+                              "config": {"workload": workload_string(args, cfg, world, D_d, kinds_d), "baseline_config": args.config,
+                                         "pop_per_gpu": args.pop_per_gpu, "n_samples": int(round(args.seconds * SR)), "chain": kinds_d}}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -395,8 +439,7 @@ def main():
     _hip.lib()
 
     n = int(round(args.seconds * SR))
-    kinds = ["ParametricEQ", "Compressor", "Reverb", "ParametricEQ", "Gain"]
-    plugins = E.make_plugins("bench5")
+    plugins, kinds = bench_plugins(cfg["chain"])
     D = sum(p["num_params"] for p in plugins.values())
     model = make_synthetic_param_model(seed=0, input_norm="minmax")
     x = synth_audio(1234, 2, n)[None]
@@ -478,7 +521,7 @@ def main():
     # second timed region: BASELINE.json's target line is quoted at pop = 512 (per GPU); configs[1], on which `value` is
     # measured, has 256.  Same chain / input / model, fresh CMA-ES state, same barrier + max-over-ranks bracket.
     pop512 = None
-    if not args.no_pop512 and args.pop_per_gpu != 512:
+    if not args.no_pop512 and args.pop_per_gpu != 512 and args.config == 1:
         P512 = 512 * world
         es512 = cmaes.CMAEvolutionStrategy(np.ones(D) * 0.5, 0.33, {"bounds": [0, 1], "popsize": P512, "seed": 42})
 
@@ -520,16 +563,15 @@ def main():
         stages["rccl_version"] = None
 
     out = {
-        "metric": "candidate-evals/sec (pop x iters), 48 kHz 10 s stereo, 5-effect chain",
+        "metric": f"candidate-evals/sec (pop x iters), 48 kHz {args.seconds:g} s stereo, 5-effect chain",
         "value": round(P_total * args.steps / dt, 3), "unit": "candidate-evals/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (effects f32 / f64 as the reference; trunk convs with >= 256 output channels: f32 operands carried as f16 hi + lo pairs "
                  "on the f16 matrix pipe, f32 accumulate -- as close to float64 as the f32 pipe, tools/ubench/split_mfma.hip)",
         "data": "synthetic",
-        "config": {"workload": f"ES evaluate-population: pop={args.pop_per_gpu}/GPU ({P_total} total), 48 kHz stereo "
-                   f"{args.seconds:g} s, chain EQ/comp/reverb/EQ/gain (D={D}), AFx-Rep Cnn14 (seeded random weights), "
-                   "CMA-ES seed 42", "pop_per_gpu": args.pop_per_gpu, "n_samples": n, "chain": kinds,
+        "config": {"workload": workload_string(args, cfg, world, D, kinds), "baseline_config": args.config,
+                   "pop_per_gpu": args.pop_per_gpu, "n_samples": n, "chain": kinds,
                    "parallelism": f"population sharded over {world} GPU(s), fitness all-gather",
                    "backend": backend if dist is not None else None, "ranks": ranks_seen},
         "last_fitness_sha16": fitness_sha,   # of the full fitness vector of the last timed step (every rank holds the same one)
@@ -563,7 +605,7 @@ def main():
                 f = fam[pipe]
                 f["ms"] += conv_each[i]; f["flops"] += issued * sc; f["fill"] += fill * sc; f["n"] += 1
                 conv_ms_total += conv_each[i]
-            traffic, traffic_note = pmc_traffic_per_launch(streams_per_launch)
+            traffic, traffic_note = pmc_traffic_per_launch(streams_per_launch) if (args.config == 1 and n == 480000) else (None, "the committed PMC passes are of configs[1]")
 
             def family(pipe):
                 f = fam[pipe]
@@ -642,8 +684,10 @@ def main():
                                    "note": "algorithmic bytes of SURVEY 8(d) (input read once, audio written once, log-mel written) / time; the "
                                            "time-serial effects (float64 biquad cascade, envelope follower, comb / all-pass lines) are latency- "
                                            "and issue-bound as SURVEY 8(d) expected: DESIGN.md 4.2 gives the per-kernel account"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 1:
             out["cpu_baseline"] = cpu_baseline(n, kinds)
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = {"value": None, "note": "the CPU port is timed on configs[1], the configuration the metric is quoted on (run without --config)"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,5 +1,8 @@
 // api_misc.hip -- error reporting and version for libstito_hip.so
 #include "common.h"
+#include <atomic>
+#include <mutex>
+#include <cstring>
 
 namespace stito {
 static thread_local char g_err[512] = "";
@@ -27,16 +30,32 @@ int zero_async(void *p, size_t bytes, hipStream_t st) {
 int device_info(DeviceInfo &info) {
     constexpr int MAX_DEV = 64;
     static DeviceInfo cache[MAX_DEV];
-    static bool have[MAX_DEV];   // written once per device; a racing second writer stores the same values
+    static std::atomic<bool> have[MAX_DEV];   // release / acquire: a reader that sees the flag sees the entry
     int dev = 0;
     STITO_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= MAX_DEV || !have[dev]) {
+    const bool cached = dev >= 0 && dev < MAX_DEV;
+    if (!cached || !have[dev].load(std::memory_order_acquire)) {
         DeviceInfo d{};
         STITO_HIP_CHECK(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
         STITO_HIP_CHECK(hipDeviceGetAttribute(&d.lds_per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-        if (dev < 0 || dev >= MAX_DEV) { info = d; return STITO_OK; }
-        cache[dev] = d;
-        have[dev] = true;
+        // gfx950 has 160 KB of LDS per CU and lets one workgroup take all of it; a runtime that still reports the 64 KB of
+        // earlier parts for it would silently switch the register-resident F(2x2,3x3) kernel (and conv_block1 as one launch)
+        // off -- a large, quiet slowdown.  The architecture string wins, and the disagreement is said once.
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0 && d.lds_per_block < 160 * 1024) {
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "libstito_hip: device %d is %s but reports %d bytes of LDS per workgroup; using the architecture's 163840\n",
+                        dev, prop.gcnArchName, d.lds_per_block);
+            d.lds_per_block = 160 * 1024;
+        }
+        if (!cached) { info = d; return STITO_OK; }
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!have[dev].load(std::memory_order_relaxed)) {
+            cache[dev] = d;
+            have[dev].store(true, std::memory_order_release);
+        }
     }
     info = cache[dev];
     return STITO_OK;

@@ -1867,8 +1867,13 @@ int launch_wino43_split2(const float *in, const float *upk, const float *scale, 
 }
 
 // Six-sweep variant (k_conv_wino43s3): workspace = V slabs of the pixel-block quads | stream maxima | per-workgroup partial outputs (1 MB each).
+static int64_t w43_split3_grid_any(const ConvShape &c, bool pool, int64_t &m_quads, int &ct_group);
 bool wino43_split3_supported(const ConvShape &c, bool pool) {
-    return c.Cin % 64 == 0 && c.Cout % 512 == 0 && wino43_supported(c, pool) && ((int64_t)c.Cin * c.H * c.W) % 8 == 0;
+    if (!(c.Cin % 64 == 0 && c.Cout % 512 == 0 && wino43_supported(c, pool) && ((int64_t)c.Cin * c.H * c.W) % 8 == 0)) return false;
+    int64_t m_quads = 0;
+    int a;
+    const int64_t grid = w43_split3_grid_any(c, pool, m_quads, a);   // "supported" means the launcher finds a grid for it
+    return grid > 0 && grid < (1ll << 31);
 }
 
 template <int TTW>
@@ -1888,8 +1893,11 @@ static int64_t w43_split3_grid(const ConvShape &c, bool pool, int64_t &m_quads, 
     xcd_m = xm;
     const int n_tiles = n_tiles_all / (8 / xm);
     const int64_t mq_loc = (m_quads + xm - 1) / xm;
-    int a = n_tiles < 4 ? n_tiles : 4;
-    while (a < n_tiles && a < 32 && 32 / a > mq_loc) a *= 2;   // one round of workgroups: as many channel tiles side by side as it takes to fill it
+    // channel tiles side by side in a round of 32 workgroups: a power of two that divides the tile count (cout 1536 has 12 tiles,
+    // 6 per XCD half: ADVICE r5), grown while a round is not full
+    int a = 4;
+    while (a > 1 && n_tiles % a != 0) a >>= 1;
+    while (a < n_tiles && a < 32 && 32 / a > mq_loc && n_tiles % (2 * a) == 0) a *= 2;
     if (const char *e = getenv("STITO_W43S3_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }
     if (n_tiles % a != 0) return 0;
     ct_group = a;
@@ -1982,7 +1990,6 @@ static int launch_w43_split3(const float *in, const float *upk, const float *sca
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     g.n_mblocks = (int)m_quads;
     g.ct_group = a;
-    g.xcd_m = xm;
     g.xcd_m = xm;
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;

@@ -627,14 +627,42 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
         // when nothing touches the values early (it does not carry its counters over the loop's back edge).  This wave issues no
         // other vector-memory instruction, so the count is exact: a slot is consumed RV_PD fetches after its own, i.e. with
         // 4 (RV_PD - 1) younger loads in flight.  The zeroing of samples past the end of the signal happens in put().
-        float ra[RV_PD], rb[RV_PD], rc[RV_PD], rd[RV_PD];
-        auto fetch = [&](int64_t t, float &a0, float &a1, float &b0, float &b1) {
+        // The ring lives in FIXED registers v64 .. v79 (slot s: v[64 + 4 s .. 67 + 4 s]) that only these asm statements name (declared
+        // as clobbers): the compiler never holds a ring value in a register of its own before the wait that makes it valid, so it
+        // cannot copy or spill a register whose load is still in flight (with "=v" outputs on the loads it legally
+        // could).  take() waits and moves a slot's four values into compiler-visible registers in ONE asm statement.  Build check
+        // (tests/test_host_logic.py): the compiler's own code of this kernel stays below v64.
+#define RV_RING_FETCH(R0_, R1_, R2_, R3_)                                                                                          \
+    asm volatile("global_load_dword " R0_ ", %0, off\n\tglobal_load_dword " R1_ ", %1, off\n\tglobal_load_dword " R2_ ", %2, off\n\t" \
+                 "global_load_dword " R3_ ", %3, off" : : "v"(xl + j0), "v"(xl + j1), "v"(xr + j0), "v"(xr + j1) : "memory", R0_, R1_, R2_, R3_)
+#define RV_RING_TAKE(N_, R0_, R1_, R2_, R3_)                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #N_ ")\n\tv_mov_b32 %0, " R0_ "\n\tv_mov_b32 %1, " R1_ "\n\tv_mov_b32 %2, " R2_ "\n\tv_mov_b32 %3, " R3_ \
+                 : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1) : : "memory", R0_, R1_, R2_, R3_)
+        auto fetch = [&](int64_t t, int slot) {
             const int64_t i0 = t * RV_TT + 2 * (act ? v : 0), i1 = i0 + 1;
             const int64_t j0 = i0 < Lm1 ? i0 : Lm1, j1 = i1 < Lm1 ? i1 : Lm1;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(a0) : "v"(xl + j0) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(a1) : "v"(xl + j1) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(b0) : "v"(xr + j0) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(b1) : "v"(xr + j1) : "memory");
+            switch (slot) {   // a compile-time constant at every call site (unrolled loops)
+                case 0: RV_RING_FETCH("v64", "v65", "v66", "v67"); break;
+                case 1: RV_RING_FETCH("v68", "v69", "v70", "v71"); break;
+                case 2: RV_RING_FETCH("v72", "v73", "v74", "v75"); break;
+                default: RV_RING_FETCH("v76", "v77", "v78", "v79"); break;
+            }
+        };
+        auto take0 = [&](int slot, float &a0, float &a1, float &b0, float &b1) {    // everything issued so far has landed
+            switch (slot) {
+                case 0: RV_RING_TAKE(0, "v64", "v65", "v66", "v67"); break;
+                case 1: RV_RING_TAKE(0, "v68", "v69", "v70", "v71"); break;
+                case 2: RV_RING_TAKE(0, "v72", "v73", "v74", "v75"); break;
+                default: RV_RING_TAKE(0, "v76", "v77", "v78", "v79"); break;
+            }
+        };
+        auto take12 = [&](int slot, float &a0, float &a1, float &b0, float &b1) {   // ... all but the twelve youngest loads
+            switch (slot) {
+                case 0: RV_RING_TAKE(12, "v64", "v65", "v66", "v67"); break;
+                case 1: RV_RING_TAKE(12, "v68", "v69", "v70", "v71"); break;
+                case 2: RV_RING_TAKE(12, "v72", "v73", "v74", "v75"); break;
+                default: RV_RING_TAKE(12, "v76", "v77", "v78", "v79"); break;
+            }
         };
         auto put = [&](float a0, float a1, float b0, float b1, int64_t t, int buf3, int buf2) {
             const int64_t i0 = t * RV_TT + 2 * (act ? v : 0);
@@ -646,13 +674,13 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
                 *(f2 *)(s_in + buf2 * RV_TT + 2 * v) = (f2){(l0 + r0) * 0.015f, (l1 + r1) * 0.015f};
             }
         };
-#define RV_RING_WAIT(S_, N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" : "+v"(ra[S_]), "+v"(rb[S_]), "+v"(rc[S_]), "+v"(rd[S_])::"memory")
-        static_assert(RV_PD == 4, "the wait counts below are 4 (RV_PD - 1) = 12 loads");
-        fetch(0, ra[0], rb[0], rc[0], rd[0]);
-        RV_RING_WAIT(0, 0);
-        put(ra[0], rb[0], rc[0], rd[0], 0, 0, 0);
+        static_assert(RV_PD == 4, "the wait count of take12 is 4 (RV_PD - 1) = 12 loads; four ring slots are named");
+        float q0, q1, q2, q3;
+        fetch(0, 0);
+        take0(0, q0, q1, q2, q3);
+        put(q0, q1, q2, q3, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < RV_PD; ++j) fetch(j + 1, ra[(j + 1) % RV_PD], rb[(j + 1) % RV_PD], rc[(j + 1) % RV_PD], rd[(j + 1) % RV_PD]);
+        for (int j = 0; j < RV_PD; ++j) fetch(j + 1, (j + 1) % RV_PD);
         int m3 = 1;  // (k + 1) % 3 at k = 0
         for (int k0 = 0; k0 <= ntiles; k0 += RV_PD) {   // ntiles + 1 is a multiple of RV_PD
 #pragma unroll
@@ -660,13 +688,14 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
                 const int k = k0 + kk;
                 const int sl = (kk + 1) % RV_PD;
                 RV_BARRIER();
-                RV_RING_WAIT(sl, 12);   // tile k + 1 has landed (the three fetches behind it may still be in flight)
-                put(ra[sl], rb[sl], rc[sl], rd[sl], (int64_t)k + 1, m3, (k + 1) & 1);   // zeros past the end of the signal
-                fetch((int64_t)k + 1 + RV_PD, ra[sl], rb[sl], rc[sl], rd[sl]);
+                take12(sl, q0, q1, q2, q3);   // tile k + 1 has landed (the three fetches behind it may still be in flight)
+                put(q0, q1, q2, q3, (int64_t)k + 1, m3, (k + 1) & 1);   // zeros past the end of the signal
+                fetch((int64_t)k + 1 + RV_PD, sl);
                 m3 = m3 == 2 ? 0 : m3 + 1;
             }
         }
-#undef RV_RING_WAIT
+#undef RV_RING_FETCH
+#undef RV_RING_TAKE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the ring may land after the wave has ended
     }
 }

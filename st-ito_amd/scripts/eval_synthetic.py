@@ -56,7 +56,7 @@ def get_pb_plugins():
 def mrstft_error(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """auraloss.freq.MultiResolutionSTFTLoss()(x, y) with the library's defaults, restated (auraloss is absent: unpinned): FFT
     sizes 1024 / 2048 / 512 with hops 120 / 240 / 50 and Hann windows of 600 / 1200 / 240; per resolution the spectral
-    convergence ||Y| - |X||_F / ||Y||_F plus the mean absolute difference of the log magnitudes (magnitudes clamped at
+    convergence ||Y| - |X||_F / ||Y||_F (per (item, channel) row, then the mean over rows: auraloss 0.4.0) plus the mean absolute difference of the log magnitudes (magnitudes clamped at
     sqrt(1e-8)); the mean over the three.  x, y: (bs, chs, n) of equal shape; x is the estimate, y the reference."""
     assert x.shape == y.shape and x.dim() == 3
     xs, ys = x.reshape(-1, x.shape[-1]).to(torch.float32), y.reshape(-1, y.shape[-1]).to(torch.float32)
@@ -68,7 +68,9 @@ def mrstft_error(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
             z = torch.stft(s, n_fft, hop, win, w, return_complex=True)
             mags.append(torch.sqrt(torch.clamp(z.real ** 2 + z.imag ** 2, min=1e-8)))
         xm, ym = mags
-        sc = torch.linalg.norm((ym - xm).flatten()) / torch.linalg.norm(ym.flatten())
+        # auraloss >= 0.3 (SpectralConvergenceLoss): the Frobenius norms are taken PER ROW over (bins, frames), then averaged --
+        # for stereo pairs of unequal channel energy that is not one norm over the flattened batch
+        sc = (torch.linalg.norm(ym - xm, dim=(-2, -1)) / torch.linalg.norm(ym, dim=(-2, -1))).mean()
         lm = torch.mean(torch.abs(torch.log(xm) - torch.log(ym)))
         total = total + sc + lm
     return total / 3.0

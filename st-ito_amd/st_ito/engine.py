@@ -252,6 +252,7 @@ class PopulationEvaluator:
         # call (bench.py: inside its warm-up)
         self.capture_after = int(os.environ.get("STITO_GRAPH_AFTER", "32")) if capture_after is None else int(capture_after)
         self._graph_calls = {}
+        self._graph_evictions = 0
         self._graphs = {}      # (P, input pointer, input shape) -> (graph, W buffer, loss, mid, side, n_calls, buffers kept alive)
         self._x_padded = None
 
@@ -313,6 +314,8 @@ class PopulationEvaluator:
             self._graph_calls[key] = seen + 1
             if seen < self.capture_after:
                 return None   # not yet: the caller launches eagerly
+            if len(self._graphs) >= 4 and self._graph_evictions >= 8:
+                return None   # more than four shapes keep rotating: every call would re-capture (10 - 30 ms each); stay eager
             Wbuf = torch.empty((P, self.ndims), dtype=torch.float64, device=self.device)
             Wbuf.copy_(torch.from_numpy(Wn))
             if seen == 0:
@@ -329,19 +332,33 @@ class PopulationEvaluator:
             g = torch.cuda.CUDAGraph()
             cap_stream = torch.cuda.Stream(self.device)
             cap_stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(cap_stream):
-                g.capture_begin(capture_error_mode="relaxed")
-                try:
-                    loss, mid, side, _, keep, n_calls = self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
-                finally:
-                    g.capture_end()
+            try:
+                with torch.cuda.stream(cap_stream):
+                    g.capture_begin(capture_error_mode="relaxed")
+                    try:
+                        loss, mid, side, _, keep, n_calls = self._fused_pass(Wbuf, x, 0, P, per, 0, 0.0, False)
+                    finally:
+                        g.capture_end()
+            except Exception as e:  # noqa: BLE001 -- a capture-unsafe call on another ROCm build, an allocation failure, ...
+                # the step must not die at call capture_after + 1 of a long run: drop the partial graph, switch replay off for
+                # this evaluator and let the caller launch eagerly (the eager path is the one the first capture_after calls took)
+                import warnings
+                warnings.warn(f"st_ito: hipGraph capture of the evaluate step failed ({type(e).__name__}: {e}); continuing with eager launches")
+                self._graph_on = False
+                self._graphs.clear()
+                del g
+                torch.cuda.synchronize(self.device)
+                return None
             torch.cuda.current_stream(self.device).wait_stream(cap_stream)
             # the graph holds raw pointers: everything it touches stays referenced here -- the outputs, the render and trunk
             # workspaces as they were at capture (a later, larger call replaces those objects; the graph keeps its own)
             keep = (keep, _WS._bufs.get("render"), getattr(self.model, "_ws", None), x)
             ent = (g, Wbuf, loss, mid, side, n_calls, keep)
             if len(self._graphs) >= 4:   # a few shapes at most (find_w0 batch, population, last partial shard)
-                self._graphs.pop(next(iter(self._graphs)))
+                old = next(iter(self._graphs))
+                self._graphs.pop(old)
+                self._graph_calls.pop(old, None)   # an evicted shape starts counting again instead of re-capturing on its next call
+                self._graph_evictions += 1
             self._graphs[key] = ent
         g, Wbuf, loss, mid, side, n_calls, _ = ent
         Wbuf.copy_(torch.from_numpy(Wn))

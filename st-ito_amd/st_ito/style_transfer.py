@@ -97,12 +97,21 @@ def savepop_to_disk(iteration, fvals, output_embeds, output_audios, run_dir: str
     `fvals` is the full population's fitness; `output_audios` holds candidates [first, first + len)
     of it -- under torch.distributed every rank passes its own shard and writes only its own
     candidates' files, named by their rank in the global ordering, so the directory ends up with the
-    same files a single process writes (no audio is communicated)."""
+    same files a single process writes (no audio is communicated).
+
+    STATED DEVIATION, one switch away from parity: the reference zips (fvals, output_audios, output_embeds) and run_es hands
+    it the embedding DICT, whose iteration yields its keys -- so the reference writes only as many files as the dict has
+    entries (two for AFx-Rep: candidates 0 and 1 of the population, ranked among themselves).  The default here writes the
+    whole population, which is what the flag promises; STITO_SAVEPOP_REFERENCE=1 reproduces the reference's files exactly
+    (tests/test_host_logic.py against a fixture the reference's own function produced)."""
     from .audio_io import save_wav
 
     pop_dir = os.path.join(run_dir, f"pop_{iteration}")
     os.makedirs(pop_dir, exist_ok=True)
-    order = sorted(range(len(fvals)), key=lambda i: fvals[i])
+    members = range(len(fvals))
+    if os.environ.get("STITO_SAVEPOP_REFERENCE") == "1":
+        members = range(min(len(fvals), len(output_embeds)))   # zip() stops at the shortest: the dict's keys
+    order = sorted(members, key=lambda i: fvals[i])
     for idx, i in enumerate(order):
         if not first <= i < first + len(output_audios):
             continue

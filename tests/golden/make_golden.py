@@ -20,6 +20,7 @@ orchestration, not the front-end ("parity unpinned" ther
   G6 cnn14_trunk_*.npz    panns.py:209-281 conv stack (+ this repo's front-end)
   G6b cnn14_trunk_minmax_262144.npz  the same on a 257 x 128 map (input stored as its synth_audio recipe)
   G7 evaluate_*.npz       style_transfer.py:399-692 run_es -> evaluate losses (fake `cma`)
+  G9 savepop_reference.npz  style_transfer.py:362-396 savepop_to_disk with the embedding dict run_es hands it (two files)
   G8 features.npz         features.py:166-264 bark spectrum (3 modes, 2 FFT sizes), RMS, crest factor
                           on O.synth_audio(seed, 2, n) inputs (the fixture stores the recipe, not the audio)
 """
@@ -278,8 +279,30 @@ def g8():
     save("features.npz", **out)
 
 
+def g9():
+    """The reference's savepop_to_disk (style_transfer.py:362-396) as it IS: run_es hands it the embedding DICT, the zip over
+    (fvals, audios, dict) stops at the dict's two keys, so two files per population are written -- candidates 0 and 1, ordered by
+    their own fitness.  torchaudio.save is a recorder here (file name, tensor as handed over, rate)."""
+    import tempfile
+    rng = np.random.default_rng(9)
+    P, chs, n = 5, 2, 257
+    fvals = [float(v) for v in -rng.random(P)]
+    fvals[0] = max(fvals) + 0.125          # candidate 0 is the worst of the five, candidate 1 somewhere in the middle
+    audios = [torch.from_numpy(rng.standard_normal((1, chs, n)).astype(np.float32) * (0.2 + 0.3 * i)) for i in range(P)]
+    embeds = {"mid": torch.zeros(P, 4), "side": torch.zeros(P, 4)}
+    rec = []
+    sys.modules["torchaudio"].save = lambda path, t, sr, backend=None: rec.append((os.path.basename(path), t.clone().numpy(), sr, backend))
+    with tempfile.TemporaryDirectory() as d:
+        RS.savepop_to_disk(3, list(fvals), embeds, [a.clone() for a in audios], d, SR)
+        made = sorted(os.listdir(d))
+    assert made == ["pop_3"] and len(rec) == 2, (made, len(rec))
+    save("savepop_reference.npz", fvals=np.array(fvals), audios=np.stack([a.numpy() for a in audios]),
+         names=np.array([r[0] for r in rec]), written=np.stack([r[1] for r in rec]), rate=np.array(rec[0][2]),
+         backend=np.array(str(rec[0][3])), iteration=np.array(3))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g6b", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g6b", "g7", "g8", "g9"]
     for name in which:
-        {"g1": g1, "g2": g2, "g3": g3_g4, "g5": g5, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8}[name]()
+        {"g1": g1, "g2": g2, "g3": g3_g4, "g5": g5, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}[name]()

@@ -286,6 +286,54 @@ def test_sub_batched_passes_and_graph_replay_give_identical_fitness(dev, monkeyp
         np.testing.assert_array_equal(ee["side"].cpu().numpy(), eg["side"].cpu().numpy())
 
 
+def test_graph_capture_failure_falls_back_to_eager_and_evicted_shapes_do_not_thrash(dev):
+    """(1) an exception inside the hipGraph capture -- a capture-unsafe call on another ROCm build, a failed
+    allocation -- must not kill a long run at call capture_after + 1: the evaluator warns, switches replay off and returns the
+    eager result; (2) with more than four shapes rotating, an evicted shape starts counting again (no re-capture on every call)
+    and after eight evictions the evaluator stops capturing new shapes."""
+    import warnings
+    from st_ito import effects as E
+    from st_ito.engine import PopulationEvaluator
+    from st_ito.utils import get_param_embeds, make_synthetic_param_model
+    pm = make_synthetic_param_model(0)
+    x = O.synth_audio(41, 2, 60000)[None]
+    pp = E.make_plugins("bench5")
+    te = get_param_embeds(O.synth_audio(42, 2, 60000)[None], pm, SR)
+    W = np.random.default_rng(3).random((5, 45))
+    ref = PopulationEvaluator(x, SR, pp, pm, te, use_graph=False).evaluate(W)[0].cpu().numpy()
+    ev = PopulationEvaluator(x, SR, pp, pm, te, capture_after=1)
+    real = ev._fused_pass
+
+    def failing(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected: operation not permitted while the stream is capturing")
+        return real(*a, **k)
+    ev._fused_pass = failing
+    np.testing.assert_array_equal(ev.evaluate(W)[0].cpu().numpy(), ref)        # call 1: eager
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = ev.evaluate(W)[0].cpu().numpy()                                   # call 2: the capture fails inside
+    assert any("hipGraph capture" in str(r.message) for r in rec), [str(r.message) for r in rec]
+    np.testing.assert_array_equal(got, ref)
+    assert ev._graph_on is False and not ev._graphs
+    np.testing.assert_array_equal(ev.evaluate(W)[0].cpu().numpy(), ref)        # and the run goes on
+    # the device is still usable for a capture afterwards (the failed one was ended and dropped)
+    ev2 = PopulationEvaluator(x, SR, pp, pm, te, capture_after=0)
+    np.testing.assert_array_equal(ev2.evaluate(W)[0].cpu().numpy(), ref)
+    assert len(ev2._graphs) == 1
+    # (2) six population sizes in rotation through a cache of four
+    ev3 = PopulationEvaluator(x, SR, pp, pm, te, capture_after=0)
+    Ws = {P: np.random.default_rng(P).random((P, 45)) for P in (1, 2, 3, 4, 5, 6)}
+    for rnd in range(4):
+        for P, Wp in Ws.items():
+            ev3.evaluate(Wp)
+    assert len(ev3._graphs) <= 4 and ev3._graph_evictions == 8, (len(ev3._graphs), ev3._graph_evictions)
+    keys = set(ev3._graphs)
+    for P, Wp in Ws.items():   # no further capture, whatever comes
+        ev3.evaluate(Wp)
+    assert set(ev3._graphs) == keys
+
+
 def test_graph_replay_soak_in_fresh_processes(dev):
     """the captured evaluate step against the eager launches, bit for bit, over 50 FRESH processes x 20 replays
     with new parameters each (tools/graph_soak.py; the corruption of round 4 showed in every process from the second
@@ -738,6 +786,43 @@ def test_gather_fitness_over_rccl_in_process(dev):
         os.environ.pop("STITO_FORCE_COLLECTIVE", None)
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+_RCCL2_WORKER = """
+import os, sys
+sys.path.insert(0, os.path.join({root!r}, "st-ito_amd"))
+import torch, torch.distributed as dist
+rank = int(sys.argv[1]); port = sys.argv[2]
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + port, world_size=2, rank=rank, device_id=dev)
+from st_ito.style_transfer import gather_fitness, shard_bounds
+P = 11                                     # uneven shards: 6 + 5
+lo, hi = shard_bounds(P, rank, 2)
+full = torch.arange(P, dtype=torch.float32) * 0.5 - 2.0
+got = gather_fitness(full[lo:hi].to(dev), P)
+assert got.is_cuda and torch.equal(got.cpu(), full), (rank, got)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl2 ok", rank, torch.cuda.nccl.version())
+"""
+
+
+def test_two_rank_rccl_all_gather_between_two_gpus(dev, tmp_path):
+    """a REAL inter-rank RCCL exchange inside -m gpu -- two processes, one GPU each, `nccl` process group,
+    gather_fitness's all_gather_into_tensor of uneven shards.  Skips itself on a box with fewer than two GPUs (the build box
+    has one): the first multi-GPU box that runs the suite exercises it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (torch.cuda.device_count() < 2)")
+    import subprocess
+    script = tmp_path / "rccl2_worker.py"
+    script.write_text(_RCCL2_WORKER.format(root=ROOT))
+    port = str(36500 + os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("rccl2 ok" in o for o in outs), outs
 
 
 def test_case_study_point_against_the_oracle(dev, tmp_path):

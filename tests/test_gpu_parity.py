@@ -351,6 +351,7 @@ CONV_CASES = [  # (n, H, W, cin, cout, pool)
     # the six-sweep kernel (algo 9, cout % 512 == 0): pixel-block quads that end inside the batch, 64 .. 192 input channels (2 .. 6 channel
     # groups per sweep), pooled odd maps, more quads than one XCD round
     (5, 14, 4, 512, 512, 0), (3, 29, 8, 192, 512, 1), (9, 9, 16, 64, 1024, 0), (40, 13, 7, 128, 512, 1), (2, 58, 16, 512, 512, 1),
+    (3, 14, 4, 128, 1536, 0),   # 12 channel tiles (not a power of two)
 ]
 
 
@@ -729,7 +730,10 @@ def test_trunk_hoisted_input_transform_is_bitwise_the_in_kernel_one(dev):
 
 
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", [(5, 14, 4, 512, 512, 0), (3, 29, 8, 192, 512, 1), (9, 9, 16, 64, 1024, 0), (40, 13, 7, 128, 512, 1),
-                                                 (2, 58, 16, 512, 512, 1), (64, 14, 4, 1024, 1024, 0), (7, 14, 4, 2048, 2048, 0)])
+                                                 (2, 58, 16, 512, 512, 1), (64, 14, 4, 1024, 1024, 0), (7, 14, 4, 2048, 2048, 0),
+                                                 # cout 1536 = 12 channel tiles: not a power of two (the round-5 grid came out empty for it),
+                                                 # with few and with many pixel-block quads (xm = 8 / 4 / 2 splits of the XCDs)
+                                                 (3, 14, 4, 128, 1536, 0), (80, 14, 4, 64, 1536, 1), (300, 9, 4, 64, 1536, 0)])
 def test_conv_six_sweeps_is_bitwise_the_two_sweep_kernel(dev, n, H, W, cin, cout, pool):
     """k_conv_wino43s3 (128 x 128 tiles, six sweeps) and k_conv_wino43s2 (64 x 64, two sweeps) do the same arithmetic in the same
     order -- per position the same sequence of products over the input channels (input lo x weight hi, hi x lo, hi x hi per 16

@@ -510,8 +510,25 @@ def test_bench_self_launches_ranks_dryrun():
     assert len(lines) == 1
     d = json.loads(lines[0])
     # ... with the per-rank stage breakdown gathered the way the real run gathers it (min / max over ranks of evaluate / gather / tell)
+    cfg = d.pop("config")
     assert d == {"dryrun": True, "n_gpus": 2, "ranks_seen": [0, 1], "max_over_ranks": 2.0, "steps": 3, "warmup": 1,
                  "stages": {"evaluate_ms": {"min": 10.0, "max": 20.0}, "gather_ms": {"min": 1.0, "max": 2.0}, "tell_ms": {"min": 0.5, "max": 0.5}}}
+    assert cfg["baseline_config"] == 1 and cfg["pop_per_gpu"] == 256 and cfg["n_samples"] == 480000 and "configs[1]" in cfg["workload"]
+    # --config 3 / 4: BASELINE.json's two 8-GPU configurations as ONE command -- their defaults (30 s audio,
+    # 256 / 128 candidates per GPU, 50 iterations for configs[3], the 96 000-tap convolution reverb in configs[4]'s chain) and the
+    # workload string naming the BASELINE entry, through the same two-rank launch path
+    import json as _json
+    base_cfgs = _json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    for c, pop, steps, D, word in ((3, 256, 50, 45, "pop=2048 sharded 256/GPU"), (4, 128, 10, 66, "convolution-reverb IR=2 s")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", str(c)],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 2 and d["steps"] == steps and d["ranks_seen"] == [0, 1]
+        cfg = d["config"]
+        assert cfg["baseline_config"] == c and cfg["pop_per_gpu"] == pop and cfg["n_samples"] == 30 * 48000
+        assert word in cfg["workload"] and word in base_cfgs[c] and f"(D={D})" in cfg["workload"] and f"({2 * pop} total)" in cfg["workload"]
+        assert ("NoiseShapedReverb(96000 taps)" in cfg["chain"]) == (c == 4)
     # a rank count that disagrees with the launcher's WORLD_SIZE is refused, not silently benchmarked
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
@@ -547,6 +564,45 @@ def test_compressor_scan_ring_registers_are_out_of_the_compilers_reach(tmp_path)
             highest = max(highest, int(a or b))
     assert n_asm >= 3, "the ring's asm statements are gone: update this check"
     assert 0 <= highest < 100, f"compiler-allocated code of k_comp_blockscan reaches v{highest}: it would clobber the ring (v100+)"
+
+
+def test_reverb_staging_ring_registers_are_out_of_the_compilers_reach(tmp_path):
+    """k_reverb's staging waves keep a four-tile register ring in FIXED VGPRs v64 .. v79, loaded by inline-asm global_load_dword
+    and handed to the compiler only inside the asm statement that waits for them (with "=v" outputs on the loads the
+    compiler could legally copy a register whose load was still in flight).  The registers are only declared as clobbers, so --
+    as for the compressor scan's ring -- the build check is that everything hipcc itself emits for the kernel stays below v64,
+    that the ring's 36 loads are all inside asm statements, and that the kernel does not spill."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "st-ito_amd", "csrc", "dsp.hip")
+    out = tmp_path / "dsp.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w",
+                           "-I", os.path.join(ROOT, "include"), src, "-o", str(out)])
+    text = out.read_text()
+    m = re.search(r"^(_ZN5stito8k_reverb\w*):.*?^\s*s_endpgm", text, flags=re.S | re.M)
+    assert m, "k_reverb not found in the compiled assembly"
+    inside, highest, ring_loads, ring_regs = False, -1, 0, set()
+    for line in m.group(0).splitlines():
+        if "ASMSTART" in line:
+            inside = True
+            continue
+        if "ASMEND" in line:
+            inside = False
+            continue
+        code = line.split(";")[0]
+        if inside:
+            mm = re.search(r"global_load_dword v(\d+),", code)
+            if mm:
+                ring_loads += 1
+                ring_regs.add(int(mm.group(1)))
+            continue
+        assert "scratch_" not in code, f"k_reverb spills: {code.strip()}"
+        for a, b in re.findall(r"\bv(\d+)\b|\bv\[\d+:(\d+)\]", code):
+            highest = max(highest, int(a or b))
+    assert ring_loads == 36 and ring_regs == set(range(64, 80)), (ring_loads, sorted(ring_regs))
+    assert 0 <= highest < 64, f"compiler-allocated code of k_reverb reaches v{highest}: it would clobber the staging ring (v64 .. v79)"
 
 
 def test_cmaes_prefetch_does_not_change_the_run():
@@ -602,3 +658,31 @@ def test_case_study_cases_mirror_the_reference_table():
     a, b = C.crop_pair(x[:1], x, rng)                                       # mono source -> stereo crop; lengths and guards
     assert a.shape[0] == 2 and b.shape[0] == 2 and 262144 <= a.shape[1] < 524288 and 262144 <= b.shape[1] < 524288
     assert float(a.abs().max()) == 1.0 and float(b.abs().max()) == 1.0
+
+
+def test_savepop_reference_switch_reproduces_the_reference_files(tmp_path, monkeypatch, golden_dir):
+    """--savepop deliberately writes the whole population; the reference's savepop_to_disk
+    (style_transfer.py:362-396) zips the population with the embedding DICT run_es hands it and therefore writes two files --
+    candidates 0 and 1 ranked among themselves.  STITO_SAVEPOP_REFERENCE=1 reproduces exactly that: file names and samples
+    against a fixture the reference's own function produced (tests/golden/make_golden.py g9, torchaudio.save as a recorder)."""
+    from st_ito.audio_io import load_wav
+    from st_ito.style_transfer import savepop_to_disk
+    g = np.load(os.path.join(golden_dir, "savepop_reference.npz"))
+    fvals = [float(v) for v in g["fvals"]]
+    audios = [torch.from_numpy(a[0].copy()) for a in g["audios"]]      # (chs, n) per candidate, as evaluate hands them over
+    embeds = {"mid": torch.zeros(len(fvals), 4), "side": torch.zeros(len(fvals), 4)}
+    it = int(g["iteration"])
+    monkeypatch.setenv("STITO_SAVEPOP_REFERENCE", "1")
+    savepop_to_disk(it, fvals, embeds, audios, str(tmp_path / "ref"), int(g["rate"]))
+    names = sorted(os.listdir(tmp_path / "ref" / f"pop_{it}"))
+    assert names == sorted(str(n) for n in g["names"]) and len(names) == 2
+    for name, want in zip(g["names"], g["written"]):
+        audio, sr = load_wav(str(tmp_path / "ref" / f"pop_{it}" / str(name)))
+        assert sr == int(g["rate"])
+        np.testing.assert_array_equal(np.asarray(audio, dtype=np.float32).reshape(want.shape), want)
+    # a rank that does not hold candidates 0 / 1 writes nothing in this mode; the default writes all five
+    savepop_to_disk(it, fvals, embeds, audios[2:], str(tmp_path / "shard"), int(g["rate"]), first=2)
+    assert os.listdir(tmp_path / "shard" / f"pop_{it}") == []
+    monkeypatch.delenv("STITO_SAVEPOP_REFERENCE")
+    savepop_to_disk(it, fvals, embeds, audios, str(tmp_path / "all"), int(g["rate"]))
+    assert len(os.listdir(tmp_path / "all" / f"pop_{it}")) == 5

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "st-ito_amd")); sys.path.insert(0, os.path
 import numpy as np, torch
 import st_ito_oracle as O
 from st_ito import effects as E, engine
-from soak import KINDS, SR
+from soak import KINDS, SR   # (replays soak.py's generator with --min-fx 1)
 
 ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--case", type=int, default=0)
 a = ap.parse_args()
