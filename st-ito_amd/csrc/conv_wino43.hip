@@ -897,22 +897,35 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
 // Slab = one local row (6 positions) x 16 channels x (64 tiles | 64 couts) x (hi, lo) = 48 KB, ring of three, two wave sets
 // as in k_conv_wino43s; wave (th, nh, pp) = (tile half, channel half, position parity) owns the columns j = pp + 2 t of every
 // row: 3 blocks = 9 MFMAs per period, accumulator 3 * local row + t.  Six periods (32 channels) per loop trip.
-template <int TTW, bool POOL>
+//
+// Round 6, for SMALL batches (the reference's CLI default is a population of 32 = 64 streams: conv_block6 is 2 pixel-block pairs x 32
+// channel tiles = 64 workgroups of 768 periods, each streaming 18.9 MB of weights):
+//   * the XCDs in two dimensions (g.xcd_m, as in k_conv_wino43s3): with the pair class = b % 8 those 64 workgroups sat on TWO of
+//     the eight XCDs -- two L2s and two fabric ports pulled all 604 MB of weights (1.1 TB/s);
+//   * SWSPLIT: the two sweeps of an item as TWO workgroups (second half of the grid = sweep 1).  The sweeps never shared anything
+//     but the partial outputs, which sweep 0 leaves in the scratch area anyway: sweep 1's workgroup waits for its partner's flag
+//     (agent-scope release / acquire) just before it reads them.  Same loads, same products, same additions in the same order:
+//     IDENTICAL BITS (tested), twice the workgroups.  Sweep-0 workgroups have the lower indices, are dispatched first and wait for
+//     nobody, so the wait cannot deadlock however many workgroups are resident.
+template <int TTW, bool POOL, bool SWSPLIT>
 __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__restrict__ vsl, const char *__restrict__ usl,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 float *__restrict__ out, Wino43Geom g,
                                                                 const unsigned *__restrict__ amax, const float *__restrict__ u_inv_p,
-                                                                f32x4 *__restrict__ partial) {
+                                                                f32x4 *__restrict__ partial, unsigned *__restrict__ sweep_flags) {
     constexpr int TTH = 32 / TTW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup order: as MODE 1, over pixel-block PAIRS (g.n_mblocks = number of pairs)
-    const int n_tiles = g.Cout / 64;
-    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    // workgroup order: as MODE 1, over pixel-block PAIRS (g.n_mblocks = number of pairs); XCD = (pair class xcd % xm, channel-tile
+    // range xcd / xm), xm = 8: every XCD runs all channel tiles of its pairs
+    const int xm = g.xcd_m, n_tiles = (g.Cout / 64) / (8 / xm);   // channel tiles of this XCD's range
+    const int half_grid = SWSPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;   // a multiple of 8: b % 8 is the XCD in both halves
+    const int my_sweep = SWSPLIT ? (int)(blockIdx.x >= (unsigned)half_grid) : 0;
+    const int b = (int)blockIdx.x - my_sweep * half_grid, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
     const int a = g.ct_group, n_ctg = n_tiles / a;
-    const int ct = (gi % n_ctg) * a + (r % a);
-    const int m_pair = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+    const int ct = (xcd / xm) * n_tiles + (gi % n_ctg) * a + (r % a);
+    const int m_pair = ((gi / n_ctg) * (32 / a) + r / a) * xm + (xcd % xm);
     const int n0 = ct * 64;
     if (m_pair >= g.n_mblocks) return;
     W43_CLK_BEGIN()
@@ -923,7 +936,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
     const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
     const char *a_rd = (const char *)smem + pp * 4096 + (half * 64 + th * 32 + l31) * 16;
     const char *b_rd = (const char *)smem + S43B_PART + pp * 4096 + (half * 64 + nh * 32 + l31) * 16;
-    f32x4 *my_partial = partial + (int64_t)blockIdx.x * (2 * 16 * W43_THREADS) + tid;  // [tile half][r * 4 + c][thread]
+    f32x4 *my_partial = partial + (int64_t)b * (2 * 16 * W43_THREADS) + tid;  // [tile half][r * 4 + c][thread]
     const float u_inv = u_inv_p[0];
 
     f32x16 acc[9];
@@ -1002,6 +1015,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
 
 #pragma unroll
     for (int sweep = 0; sweep < 2; ++sweep) {
+        if (SWSPLIT && sweep != my_sweep) continue;   // (uniform) this workgroup runs one of the two
         const char *vw = vsl + ((int64_t)m_pair * 2 + sweep) * n_slabs * S43B_PART + w4 * 1024;
         const char *uw = usl + ((int64_t)ct * 2 + sweep) * n_slabs * S43B_PART + w4 * 1024;
 #pragma unroll
@@ -1019,6 +1033,12 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
         }
         if (S43_ILV && !(S43B_ABL & 5)) {  // the last slab's block 2 (n_slabs % 6 == 0: local row 2 -> accumulator 8)
             S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
+        }
+        if (SWSPLIT && sweep == 1) {   // the partner's partial outputs have to be there (and visible) before they are read
+            if (tid == 0)
+                while (__hip_atomic_load(sweep_flags + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+            W43_BARRIER()
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         // ---- this sweep's rows of Y = A^T M A, one tile half (= one 32-tile pixel block) at a time --------------------
 #pragma unroll 1
@@ -1095,6 +1115,11 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s2(const char *__res
                 }
                 if (g.amax_out != nullptr) w43_amax_out(g.amax_out, sidx, smax);
             }
+        }
+        if (SWSPLIT && sweep == 0) {   // publish: every thread's partial stores, then the flag
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            W43_BARRIER()
+            if (tid == 0) __hip_atomic_store(sweep_flags + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     W43_CLK_END()
@@ -1751,31 +1776,49 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
 }
 
 // Two-sweep variant: workspace = V slabs of the pixel-block pairs | stream maxima | per-workgroup partial outputs (256 KB each).
+// -> the grid of ONE sweep set (SWSPLIT launches twice as many); xcd_m / ct_group: the kernel's workgroup order
 template <int TTW>
-static int64_t w43_split2_grid(const ConvShape &c, bool pool, int64_t &m_pairs, int &ct_group) {
+static int64_t w43_split2_grid(const ConvShape &c, bool pool, int64_t &m_pairs, int &ct_group, int &xcd_m) {
     Wino43Geom g;
     size_t lds;
     int64_t blocks;
     if (!w43_geometry<TTW>(c, pool, g, lds, blocks)) return 0;
     const int64_t m_blocks = blocks / (c.Cout / 64);
     m_pairs = (m_blocks + 1) / 2;
-    const int n_tiles = c.Cout / 64;
-    int a = n_tiles % 8 == 0 ? 8 : 4;  // (n_tiles is a multiple of 4: wino43_split_supported)
+    const int n_tiles_all = c.Cout / 64;   // a multiple of 4 (wino43_split_supported)
+    // XCD split: the xm in {8, 4, 2, 1} with the fewest slab streams per L2, pairs / xm + tiles / (8 / xm); 8 on a tie
+    int xm = 8;
+    for (int cand = 4; cand >= 1; cand >>= 1)
+        if (n_tiles_all % (8 / cand) == 0 && (m_pairs + cand - 1) / cand + n_tiles_all / (8 / cand) < (m_pairs + xm - 1) / xm + n_tiles_all / (8 / xm)) xm = cand;
+    if (const char *e = getenv("STITO_W43S2_XM")) { const int xe = atoi(e); if ((xe == 8 || xe == 4 || xe == 2 || xe == 1) && n_tiles_all % (8 / xe) == 0) xm = xe; }  // tuning aid
+    xcd_m = xm;
+    const int n_tiles = n_tiles_all / (8 / xm);
+    int a = 8;
+    while (a > 1 && n_tiles % a != 0) a >>= 1;
     if (const char *e = getenv("STITO_W43S_CTG")) { const int ae = atoi(e); if (ae >= 1 && ae <= 32 && (ae & (ae - 1)) == 0 && n_tiles % ae == 0) a = ae; }
     if (a < 1 || a > 32 || (a & (a - 1)) != 0 || n_tiles % a != 0) return 0;
     ct_group = a;
     const int bm = 32 / a;
-    const int64_t m_groups = ((m_pairs + 7) / 8 + bm - 1) / bm;
+    const int64_t m_groups = ((m_pairs + xm - 1) / xm + bm - 1) / bm;
     return 8 * m_groups * (n_tiles / a) * 32;
 }
 
 static int64_t w43_split2_grid_any(const ConvShape &c, bool pool, int64_t &m_pairs, int &ct_group) {
+    int xm;
     switch (w43_ttw(c, pool)) {
-        case 8: return w43_split2_grid<8>(c, pool, m_pairs, ct_group);
-        case 4: return w43_split2_grid<4>(c, pool, m_pairs, ct_group);
-        case 2: return w43_split2_grid<2>(c, pool, m_pairs, ct_group);
-        default: return w43_split2_grid<1>(c, pool, m_pairs, ct_group);
+        case 8: return w43_split2_grid<8>(c, pool, m_pairs, ct_group, xm);
+        case 4: return w43_split2_grid<4>(c, pool, m_pairs, ct_group, xm);
+        case 2: return w43_split2_grid<2>(c, pool, m_pairs, ct_group, xm);
+        default: return w43_split2_grid<1>(c, pool, m_pairs, ct_group, xm);
     }
+}
+
+// the two sweeps of an item as two workgroups when that still fits one round of the device (see the kernel); STITO_W43S2_SWSPLIT=0 / 1 forces
+static bool w43_split2_sweep_split(int64_t m_pairs, int cout) {
+    if (const char *e = getenv("STITO_W43S2_SWSPLIT")) return atoi(e) != 0;   // (read per launch: the tests flip it)
+    DeviceInfo d;
+    if (device_info(d) != STITO_OK) return false;
+    return 2 * m_pairs * (cout / 64) <= d.cus;
 }
 
 // f16-pipe FLOPs the two-sweep kernel issues: pixel-block pairs (a padded half included) x channel tiles x 64 x 64 x 36 x cin x 3 products
@@ -1794,7 +1837,7 @@ size_t wino43_split2_workspace_bytes(const ConvShape &c, bool pool) {
     const int64_t grid = w43_split2_grid_any(c, pool, m_pairs, a);
     if (grid <= 0 || grid >= (1ll << 31)) return 0;
     return align_up((size_t)m_pairs * 2 * (size_t)(c.Cin / 16) * 3 * S43B_PART, 256) + align_up((size_t)c.S * sizeof(unsigned), 256) +
-           (size_t)grid * 2 * 16 * W43_THREADS * sizeof(f32x4);
+           (size_t)grid * 2 * 16 * W43_THREADS * sizeof(f32x4) + align_up((size_t)grid * sizeof(unsigned), 256);   // ... + one flag per workgroup item (SWSPLIT)
 }
 
 template <int TTW, bool POOL>
@@ -1806,9 +1849,9 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
     STITO_REQUIRE((w43_geometry<TTW>(c, POOL, g, lds, blocks)), STITO_E_UNSUPPORTED,
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     int64_t m_pairs = 0;
-    int a = 4;
-    const int64_t grid = w43_split2_grid<TTW>(c, POOL, m_pairs, a);
-    STITO_REQUIRE(grid > 0 && grid < (1ll << 31), STITO_E_UNSUPPORTED, "conv (two-sweep split-precision winograd): grid / cout %d", c.Cout);
+    int a = 4, xm = 8;
+    const int64_t grid = w43_split2_grid<TTW>(c, POOL, m_pairs, a, xm);
+    STITO_REQUIRE(grid > 0 && grid < (1ll << 30), STITO_E_UNSUPPORTED, "conv (two-sweep split-precision winograd): grid / cout %d", c.Cout);
     const size_t vbytes = align_up((size_t)m_pairs * 2 * (size_t)(c.Cin / 16) * 3 * S43B_PART, 256);
     unsigned *amax_ws = (unsigned *)(ws + vbytes);
     const unsigned *amax = amax_in != nullptr ? amax_in : amax_ws;
@@ -1836,17 +1879,28 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
-    auto kern = k_conv_wino43s2<TTW, POOL>;
+    const bool swsplit = w43_split2_sweep_split(m_pairs, c.Cout);
+    unsigned *flags = (unsigned *)((char *)partial + (size_t)grid * 2 * 16 * W43_THREADS * sizeof(f32x4));
     const size_t lds1 = (size_t)3 * S43B_SLAB;
     static_assert((size_t)12 * 32 * W43_XT * sizeof(float) <= (size_t)3 * S43B_SLAB, "epilogue exchange fits the slab ring");
-    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     g.n_mblocks = (int)m_pairs;
     g.ct_group = a;
+    g.xcd_m = xm;
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
     W43_CLK_ARM(g)
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
-                       (const unsigned *)amax, u_inv, partial);
+    if (swsplit) {
+        STITO_TRY(zero_async(flags, (size_t)grid * sizeof(unsigned), st));
+        auto kern = k_conv_wino43s2<TTW, POOL, true>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(2 * grid)), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                           (const unsigned *)amax, u_inv, partial, flags);
+    } else {
+        auto kern = k_conv_wino43s2<TTW, POOL, false>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                           (const unsigned *)amax, u_inv, partial, flags);
+    }
     STITO_LAUNCH_CHECK();
     W43_CLK_REPORT("k_conv_wino43s2 (f16 MFMA)", c, st)
     return STITO_OK;

@@ -764,6 +764,46 @@ def test_conv_six_sweeps_is_bitwise_the_two_sweep_kernel(dev, n, H, W, cin, cout
     assert torch.equal(outs[_hip.CONV_WINOGRAD_F4_SPLIT2], outs[_hip.CONV_WINOGRAD_F4_SPLIT3])
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout,pool", [(64, 8, 4, 2048, 2048, 0), (64, 16, 8, 1024, 1024, 1), (5, 14, 4, 512, 512, 0), (3, 29, 8, 192, 512, 1),
+                                                 (40, 13, 7, 128, 256, 1), (9, 9, 16, 64, 1024, 0), (2, 58, 16, 512, 768, 1)])
+def test_conv_two_sweep_kernel_sweep_split_and_xcd_order_are_bitwise_neutral(dev, n, H, W, cin, cout, pool, monkeypatch):
+    """Round 6, small batches: k_conv_wino43s2 with the two sweeps of an item as TWO workgroups (the second
+    waits for the first one's flag before it reads the partial outputs) and with the XCDs split in two dimensions must return
+    the bits of the one-workgroup, pair-class-per-XCD launch: same loads, same products, same additions in the same order.  Ten
+    launches per setting (a lost flag / an early read of the partials would show as a difference or a hang -> the suite's timeout);
+    the first two shapes are conv_block6 / conv_block5.conv2 of a population of 32 on 262 144 samples."""
+    from st_ito import _hip
+    L = _hip.lib()
+    st = _hip.stream_ptr()
+    g = torch.Generator().manual_seed(H * 10 + cin)
+    x = torch.relu(torch.randn((n, cin // 8, H, W, 8), generator=g)).to(dev)
+    x[1 % n] *= 300.0
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)).to(dev)
+    sc = (0.5 + torch.rand(cout, generator=g)).to(dev); sh = (0.1 * torch.randn(cout, generator=g)).to(dev)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    m = _hip.CONV_WINOGRAD_F4_SPLIT2
+    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, m)
+    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, m), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, m, _hip.ptr(packed), st))
+    ref = None
+    for split, xm in (("0", "8"), ("1", "8"), ("1", None), ("0", None), ("1", "2"), ("1", "1"), ("0", "4")):
+        monkeypatch.setenv("STITO_W43S2_SWSPLIT", split)
+        if xm is None:
+            monkeypatch.delenv("STITO_W43S2_XM", raising=False)
+        else:
+            monkeypatch.setenv("STITO_W43S2_XM", xm)
+        wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, m)   # the grid (and with it the scratch area) follows the XCD order
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        for rep in range(10):
+            out = torch.full((n, cout // 8, Ho, Wo, 8), float("nan"), device=dev)
+            _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), n, H, W, cin, cout, pool, m,
+                                                  _hip.ptr(ws), wsb, st))
+            if ref is None:
+                ref = out
+                assert not torch.isnan(ref).any()
+            assert torch.equal(out, ref), (split, xm, rep)
+
+
 def test_trunk_small_batches_take_the_two_sweep_packing(dev):
     """The six-sweep kernel's workgroups are four times the two-sweep kernel's: a batch that gives it fewer than 3 / 4 workgroup per
     CU (anything below ~380 streams for conv_block6) runs the two-sweep kernel from the alternative packing the model carries
