@@ -1157,12 +1157,16 @@ __device__ __forceinline__ const char *w43_uniform(const char *p) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (const char *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
-template <int TTW, bool POOL>
+// SWSPLIT (round 6, small batches): the six sweeps of an item as SIX workgroups (sixth s of the grid = position row s): rows 0 .. 4 leave
+// their Z in the scratch area as before and count themselves in (agent-scope release), the row-5 workgroup waits for the count of five
+// before it reads them back.  Same products, same additions, same order: identical bits; six times the workgroups for a batch that
+// would leave most CUs idle.  Rows 0 .. 4 have the lower workgroup indices and wait for nobody: no deadlock whatever is resident.
+template <int TTW, bool POOL, bool SWSPLIT>
 __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__restrict__ vsl, const char *__restrict__ usl,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 float *__restrict__ out, Wino43Geom g,
                                                                 const unsigned *__restrict__ amax, const float *__restrict__ u_inv_p,
-                                                                f32x4 *__restrict__ partial) {
+                                                                f32x4 *__restrict__ partial, unsigned *__restrict__ sweep_count) {
     constexpr int TTH = 32 / TTW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, oct = lane >> 5;
@@ -1173,19 +1177,23 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
     // number of bytes per quad as per tile -- so quads / xm + tiles / (8 / xm) is what the eight L2s pull over the fabric each
     // (profiles/round5_conv_ea_pmc.txt: with every XCD running all 16 channel tiles of conv_block6.conv2, 8 x 604 MB of weights)
     const int xm = g.xcd_m, n_tiles = (g.Cout / 128) / (8 / xm);   // channel tiles of this XCD's range
-    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    const int sixth = SWSPLIT ? (int)(gridDim.x / 6) : (int)gridDim.x;   // a multiple of 8: b % 8 is the XCD in every sixth
+    const int my_sweep = SWSPLIT ? (int)(blockIdx.x / (unsigned)sixth) : 0;
+    const int b = (int)blockIdx.x - my_sweep * sixth, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
     const int a = g.ct_group, n_ctg = n_tiles / a;
     const int ct = (xcd / xm) * n_tiles + (gi % n_ctg) * a + (r % a);
     const int m_quad = ((gi / n_ctg) * (32 / a) + r / a) * xm + (xcd % xm);
     if (m_quad >= g.n_mblocks) return;
     W43_CLK_BEGIN()
     const int nP = g.Cin >> 3;   // periods per sweep: two per 16 input channels
+    const int sw_lo = SWSPLIT ? my_sweep : 0, sw_hi = SWSPLIT ? my_sweep + 1 : 6;   // the sweeps this workgroup runs
+    const int sl_end = sw_hi * nP;                                                  // ... and the end of its slab stream
     const int set = wv >> 2, w4 = wv & 3, th = wv & 1, cq = wv >> 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
     const char *v_rd = (const char *)smem + (oct * 128 + th * 64 + l31) * 16;               // + jj * 8192 (+ 4096: lo) + blk * 512
     const char *u_rd = (const char *)smem + S43B_PART + (oct * 128 + cq * 32 + l31) * 16;   // + jj * 8192 (+ 4096: lo)
-    f32x4 *my_partial = partial + (int64_t)blockIdx.x * (8 * 2 * 4 * 20 * 64) + wv * (2 * 4 * 20 * 64) + lane;  // [wave][blk][quad][row 0..4][c][lane]
+    f32x4 *my_partial = partial + (int64_t)b * (8 * 2 * 4 * 20 * 64) + wv * (2 * 4 * 20 * 64) + lane;  // [wave][blk][quad][row 0..4][c][lane]
     const float u_inv = u_inv_p[0];
 
     f32x16 acc[12];   // [position j of the row][tile panel]
@@ -1199,7 +1207,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
 #define S43C_PERIOD(KK, SL, BUF_)                                                                        \
     {                                                                                                    \
         const bool mine_ = set == (KK);                                                                   \
-        if (mine_ && (SL) + 2 < 6 * nP) { const int nb_ = (BUF_) + 2 >= 3 ? (BUF_) - 1 : (BUF_) + 2; S43C_ISSUE((SL) + 2, nb_) } \
+        if (mine_ && (SL) + 2 < sl_end) { const int nb_ = (BUF_) + 2 >= 3 ? (BUF_) - 1 : (BUF_) + 2; S43C_ISSUE((SL) + 2, nb_) } \
         const char *pv_ = v_rd + (BUF_) * S43B_SLAB, *pu_ = u_rd + (BUF_) * S43B_SLAB;                    \
         _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                \
             const h8 uh_ = *(const h8 *)(pu_ + q_ * 8192), ul_ = *(const h8 *)(pu_ + q_ * 8192 + 4096);    \
@@ -1233,12 +1241,12 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
     // (the 64-bit products are VALU work: back into scalar registers by hand -- hipcc hands an "s" asm operand a VGPR pair otherwise)
     const char *vw = w43_uniform(vsl + (int64_t)m_quad * 6 * nP * S43B_PART + w4 * 1024);
     const char *uw = w43_uniform(usl + (int64_t)ct * 6 * nP * S43B_PART + w4 * 1024);
-    if (set == 0) { S43C_ISSUE(0, 0) } else { S43C_ISSUE(1, 1) }
+    if (set == 0) { S43C_ISSUE(sw_lo * nP, 0) } else { S43C_ISSUE(sw_lo * nP + 1, 1) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
     int buf = 0;
 #pragma unroll 1
-    for (int sweep = 0; sweep < 6; ++sweep) {
+    for (int sweep = sw_lo; sweep < sw_hi; ++sweep) {
 #pragma unroll
         for (int q = 0; q < 12; ++q)
 #pragma unroll
@@ -1285,7 +1293,18 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s3(const char *__res
                     else pt[(sweep * 4 + c) * 64] = Z[c];
                 }
             }
+            if (SWSPLIT) {   // publish this row: every thread's stores, then the count
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                W43_BARRIER()
+                if (tid == 0) __hip_atomic_fetch_add(sweep_count + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
+            if (SWSPLIT) {   // the other five rows have to be there (and visible) before they are read back
+                if (tid == 0)
+                    while (__hip_atomic_load(sweep_count + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 5u) __builtin_amdgcn_s_sleep(8);
+                W43_BARRIER()
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
             // the last row: all eight Z sets first (the accumulators are dead behind them: 128 registers for the loads that follow --
             // a (panel, quad)'s twenty stored values in flight at once; five at a time was 32 dependent round trips to HBM per workgroup)
             f32x4 Zl[8][4];
@@ -1814,11 +1833,14 @@ static int64_t w43_split2_grid_any(const ConvShape &c, bool pool, int64_t &m_pai
 }
 
 // the two sweeps of an item as two workgroups when that still fits one round of the device (see the kernel); STITO_W43S2_SWSPLIT=0 / 1 forces
-static bool w43_split2_sweep_split(int64_t m_pairs, int cout) {
+// Measured (tools/small_conv_ab.sh, 64 / 128 streams x 257 frames): 1024 -> 1024 0.348 -> 0.293 ms, 1024 -> 2048 0.346 -> 0.231, 2048 -> 2048
+// 0.640 -> 0.388; with 512 input channels the halves are too short to carry the second workgroup's prologue and its wait
+// (512 -> 1024: 0.201 -> 0.236), hence the channel threshold.
+static bool w43_split2_sweep_split(int64_t m_pairs, int cout, int cin) {
     if (const char *e = getenv("STITO_W43S2_SWSPLIT")) return atoi(e) != 0;   // (read per launch: the tests flip it)
     DeviceInfo d;
     if (device_info(d) != STITO_OK) return false;
-    return 2 * m_pairs * (cout / 64) <= d.cus;
+    return cin >= 1024 && 2 * m_pairs * (cout / 64) <= d.cus;
 }
 
 // f16-pipe FLOPs the two-sweep kernel issues: pixel-block pairs (a padded half included) x channel tiles x 64 x 64 x 36 x cin x 3 products
@@ -1879,7 +1901,7 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
-    const bool swsplit = w43_split2_sweep_split(m_pairs, c.Cout);
+    const bool swsplit = w43_split2_sweep_split(m_pairs, c.Cout, c.Cin);
     unsigned *flags = (unsigned *)((char *)partial + (size_t)grid * 2 * 16 * W43_THREADS * sizeof(f32x4));
     const size_t lds1 = (size_t)3 * S43B_SLAB;
     static_assert((size_t)12 * 32 * W43_XT * sizeof(float) <= (size_t)3 * S43B_SLAB, "epilogue exchange fits the slab ring");
@@ -1997,7 +2019,17 @@ size_t wino43_split3_workspace_bytes(const ConvShape &c, bool pool) {
     int a;
     const int64_t grid = w43_split3_grid_any(c, pool, m_quads, a);
     if (grid <= 0 || grid >= (1ll << 31)) return 0;
-    return w43_split3_vbytes(c, m_quads) + align_up((size_t)c.S * sizeof(unsigned), 256) + (size_t)grid * (8 * 2 * 4 * 20 * 64) * sizeof(f32x4);
+    return w43_split3_vbytes(c, m_quads) + align_up((size_t)c.S * sizeof(unsigned), 256) + (size_t)grid * (8 * 2 * 4 * 20 * 64) * sizeof(f32x4) +
+           align_up((size_t)grid * sizeof(unsigned), 256);   // ... + one row count per workgroup item (SWSPLIT)
+}
+
+// the six sweeps of an item as six workgroups: OFF unless STITO_W43S3_SWSPLIT=1.  Built and measured in round 6 for the small batches
+// whose items alone leave CUs idle (tools/small_conv_ab.sh, profiles/round6_small_conv_ab.txt): it takes 64-stream conv_block6.conv2 from
+// 1.53 to 0.51 ms -- but the two-sweep kernel with ITS sweeps split does the same layer in 0.39 (the six-sweep kernel's transform pass and
+// its 1 MB of partial outputs per item do not shrink with the batch), and that is what stito_cnn14_forward takes for small batches.
+static bool w43_split3_sweep_split(int64_t, int) {
+    if (const char *e = getenv("STITO_W43S3_SWSPLIT")) return atoi(e) != 0;   // (read per launch: the tests flip it)
+    return false;
 }
 
 template <int TTW, bool POOL>
@@ -2039,17 +2071,26 @@ static int launch_w43_split3(const float *in, const float *upk, const float *sca
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
-    auto kern = k_conv_wino43s3<TTW, POOL>;
     const size_t lds1 = (size_t)3 * S43B_SLAB;
-    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     g.n_mblocks = (int)m_quads;
     g.ct_group = a;
     g.xcd_m = xm;
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    unsigned *counts = (unsigned *)((char *)partial + (size_t)grid * (8 * 2 * 4 * 20 * 64) * sizeof(f32x4));
     W43_CLK_ARM(g)
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
-                       (const unsigned *)amax, u_inv, partial);
+    if (w43_split3_sweep_split(m_quads, c.Cout) && 6 * grid < (1ll << 31)) {
+        STITO_TRY(zero_async(counts, (size_t)grid * sizeof(unsigned), st));
+        auto kern = k_conv_wino43s3<TTW, POOL, true>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(6 * grid)), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                           (const unsigned *)amax, u_inv, partial, counts);
+    } else {
+        auto kern = k_conv_wino43s3<TTW, POOL, false>;
+        STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
+                           (const unsigned *)amax, u_inv, partial, counts);
+    }
     STITO_LAUNCH_CHECK();
     W43_CLK_REPORT("k_conv_wino43s3 (f16 MFMA)", c, st)
     return STITO_OK;

@@ -460,12 +460,26 @@ __device__ __forceinline__ float rv_dpp(float v) {
 // (An LDS-only barrier -- s_waitcnt lgkmcnt(0); s_barrier, without __syncthreads()'s vmcnt(0) -- was measured too: 2.16
 // against 2.06 ms on the same box; hipcc then drains vmcnt in front of the LDS writes instead.)
 #define RV_BARRIER() __syncthreads()
+// wet / dry mix of juce::Reverb::processStereo with its two fused multiply-adds spelled out: the one-workgroup kernel and the
+// per-channel form (k_reverb<true> + k_reverb_mix) must round alike -- a candidate's audio may not depend on which of them its
+// batch size selects
+__device__ __forceinline__ float rv_mix(float wet_own, float wet_other, float x, float wet1, float wet2, float dry) {
+    return fmaf(wet_own, wet1, fmaf(wet_other, wet2, x * dry));
+}
 #ifndef RV_ABL
 #define RV_ABL 0   // timing builds only (tools/reverb_ablate.sh): 1 = comb role idle, 2 = all-pass role idle
 #endif
 
+// HALF (round 6, small populations: a population of 32 puts 32 of these workgroups on 256 CUs): one workgroup per (candidate, CHANNEL)
+// -- the channel's eight combs on two waves, its all-pass chain on three, the same staging (the comb input is the sum of both
+// channels) -- writing the channel's WET signal to a scratch buffer; k_reverb_mix then forms wet_c wet1 + wet_other wet2 + x_c dry
+// with the same two fused multiply-adds.  Same LDS geometry, same arithmetic per comb / all-pass: identical bits (tested), half the
+// instructions per SIMD and tile.
+template <bool HALF>
 __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restrict__ out, int64_t cand_stride,
                                                         int64_t L, const double *__restrict__ coef, ReverbGeom g) {
+    constexpr int NCW = HALF ? RV_COMB_WAVES / 2 : RV_COMB_WAVES, NAW = HALF ? RV_AP_WAVES / 2 : RV_AP_WAVES;
+    constexpr int NTHREADS = (NCW + NAW + RV_STAGE_WAVES) * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *state = smem;                          // comb + all-pass delay lines
     float *s_in = smem + g.state_floats;          // [2 buffers][RV_TT] (L+R)*gain
@@ -474,27 +488,27 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
     float *s_x = s_in + 2 * RV_TT;                // [3 buffers][2][RV_TT (+ RV_PAD for channel 1)] dry input
     float *s_comb = s_x + 3 * RV_XB;              // [2 buffers][16][RV_TT] (+ RV_PAD in front of combs 8..15) comb outputs
 
-    const int cand = blockIdx.x;
+    const int cand = HALF ? blockIdx.x >> 1 : blockIdx.x, my_ch = HALF ? blockIdx.x & 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *cf = coef + (int64_t)cand * COEF_STRIDE;
     const float damp = (float)cf[0], fbk = (float)cf[1], wet1 = (float)cf[2], wet2 = (float)cf[3], dry = (float)cf[4];
     const float omd = 1.0f - damp;
     const float *xl = in_ptr(in, cand, 0), *xr = in_ptr(in, cand, 1);
-    float *yl = out + (int64_t)cand * cand_stride, *yr = yl + L;
+    float *yl = out + (int64_t)cand * cand_stride, *yr = yl + L;   // (HALF: out = the wet scratch buffer, (pop, 2, L))
 
-    for (int i = tid; i < g.state_floats; i += RV_THREADS) state[i] = 0.0f;
+    for (int i = tid; i < g.state_floats; i += NTHREADS) state[i] = 0.0f;
     // tiles, rounded up to whole turns of the staging ring: every role runs ntiles + 1 barrier steps, and the staging loop has no
     // early exit inside its unrolled turn (with one, hipcc gives up counting its loads and drains vmcnt(0) every turn); the tiles
     // past the end of the signal are zeros in, nothing out
     const int ntiles = (int)((L + RV_TT - 1) / RV_TT + RV_PD - 1) / RV_PD * RV_PD + (RV_PD - 1);
 
-    if (wv < RV_COMB_WAVES) {
-        // ---- comb role: the four 16-lane rows of wave w are combs 4 w .. 4 w + 3; lane l of a row owns samples 12 l .. 12 l + 11.
+    if (wv < NCW) {
+        // ---- comb role: the four 16-lane rows of wave w are combs 4 w .. 4 w + 3 (HALF: of this workgroup's channel); lane l of a row owns samples 12 l .. 12 l + 11.
         // The kernel is bound by the instructions its waves issue between two barriers, summed per SIMD (tools/reverb_ablate.sh: the
         // roles' times ADD -- barriers only 0.4 ms, + all-pass 0.4, + comb 0.7 at 256 candidates -- at ~4.8 cycles per instruction and
         // SIMD): with two combs of 32 lanes x 6 samples per wave (rounds 2 - 4) the eight comb waves issued 8 x 92 instructions per
         // tile; a row per comb halves the waves for ~100 each, and the scan needs no step across rows.
-        const int cidx = 4 * wv + (lane >> 4), cl = lane & 15;
+        const int cidx = (HALF ? 8 * my_ch : 0) + 4 * wv + (lane >> 4), cl = lane & 15;
         const int csz = g.comb_size[cidx];
         float *cbuf = state + g.comb_off[cidx];
         int cpos = 0;
@@ -569,10 +583,10 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
 #pragma unroll
             for (int i = 0; i < RV_RUN; ++i) o[i] = cbuf[base + i];   // (runs into the mirror behind the line's end)
         }
-    } else if (wv < RV_COMB_WAVES + RV_AP_WAVES) {
+    } else if (wv < NCW + NAW) {
         // ---- all-pass role: thread u = (channel u & 1, sample u >> 1) of tile k - 1: comb sum, 4 series all-passes, width mix
-        // (the other channel of the sample is the neighbouring lane), wet/dry, store
-        const int u = tid - RV_COMB_WAVES * 64, c2 = u & 1, t2 = u >> 1;
+        // (the other channel of the sample is the neighbouring lane), wet/dry, store.  HALF: thread u = sample u of the one channel
+        const int u = tid - NCW * 64, c2 = HALF ? my_ch : (u & 1), t2 = HALF ? u : (u >> 1);
         float *yc_g = c2 == 0 ? yl : yr;
         int appos[4] = {0, 0, 0, 0}, apsz[4], apoff[4];  // geometry copied out of the kernel-argument struct once
 #pragma unroll
@@ -599,7 +613,7 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
                     appos[j] += RV_TT;
                     appos[j] = appos[j] >= apsz[j] ? appos[j] - apsz[j] : appos[j];
                 }
-                const float xd = s_x[m3 * RV_XB + c2 * (RV_TT + RV_PAD) + t2];
+                const float xd = HALF ? 0.0f : s_x[m3 * RV_XB + c2 * (RV_TT + RV_PAD) + t2];
                 float acc = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc += cs[j];
@@ -608,8 +622,12 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
                     *abp[j] = acc + (bv[j] * 0.5f);
                     acc = bv[j] - acc;
                 }
-                const float other = rv_dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the other channel of this sample
-                if (t_out < L) yc_g[t_out] = acc * wet1 + other * wet2 + xd * dry;
+                if (HALF) {
+                    if (t_out < L) yc_g[t_out] = acc;   // the channel's wet signal; mixed by k_reverb_mix
+                } else {
+                    const float other = rv_dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the other channel of this sample
+                    if (t_out < L) yc_g[t_out] = rv_mix(acc, other, xd, wet1, wet2, dry);
+                }
             }
             m3 = m3 == 2 ? 0 : m3 + 1;
             t_out += RV_TT;
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
     } else {
         // ---- staging role: thread v < RV_TT / 2 owns samples 2 v, 2 v + 1 of both channels.  Tile k + 1 is written to LDS in
         // step k out of the ring slot filled RV_PD steps earlier; loads are clamped, not branched around.
-        const int v = tid - (RV_COMB_WAVES + RV_AP_WAVES) * 64;
+        const int v = tid - (NCW + NAW) * 64;
         const bool act = v < RV_TT / 2;
         const int64_t Lm1 = L - 1;
         // Register ring of RV_PD tiles, loaded by inline-asm global_load_dword and waited for by hand: (l0, l1, r0, r1) of tile t
@@ -697,6 +715,22 @@ __global__ __launch_bounds__(RV_THREADS) void k_reverb(InView in, float *__restr
 #undef RV_RING_FETCH
 #undef RV_RING_TAKE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the ring may land after the wave has ended
+    }
+}
+
+// per-channel form: wet (pop, 2, L) from k_reverb<true> + the stage's input -> out (in place over the input is fine: pointwise)
+__global__ __launch_bounds__(256) void k_reverb_mix(InView in, const float *__restrict__ wet, float *__restrict__ out, int64_t cand_stride,
+                                                     int64_t L, const double *__restrict__ coef) {
+    const int cand = blockIdx.y;
+    const double *cf = coef + (int64_t)cand * COEF_STRIDE;
+    const float wet1 = (float)cf[2], wet2 = (float)cf[3], dry = (float)cf[4];
+    const float *xl = in_ptr(in, cand, 0), *xr = in_ptr(in, cand, 1);
+    const float *wl = wet + (int64_t)cand * 2 * L, *wr = wl + L;
+    float *yl = out + (int64_t)cand * cand_stride, *yr = yl + L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = wl[i], b = wr[i], x0 = xl[i], x1 = xr[i];
+        yl[i] = rv_mix(a, b, x0, wet1, wet2, dry);
+        yr[i] = rv_mix(b, a, x1, wet1, wet2, dry);
     }
 }
 
@@ -810,6 +844,31 @@ extern "C" int stito_chain_num_dims(const stito_fx_desc *chain, int n_fx) {
     return d;
 }
 
+// convolution reverb: spectra of the input blocks and of every candidate's IR partitions
+static size_t conv_reverb_bytes(const stito_fx_desc *chain, int n_fx, int64_t n_samples, int pop) {
+    size_t cr = 0;
+    for (int i = 0; i < n_fx; ++i)
+        if (chain[i].kind == STITO_FX_NOISE_REVERB) {
+            const size_t need = conv_reverb_workspace_bytes(pop * 2, n_samples, chain[i].aux_len > 0 ? chain[i].aux_len : 1);
+            cr = need > cr ? need : cr;
+        }
+    return cr;
+}
+
+// Freeverb as two workgroups per candidate (k_reverb<true> + k_reverb_mix) while that still leaves every workgroup its own CU:
+// a population of 32 runs 64 half-size workgroups instead of 32 (0.81 -> see profiles/round6_small_pop.txt).  STITO_REVERB_SPLIT=0 / 1 forces.
+static bool reverb_split(int pop) {
+    if (const char *e = getenv("STITO_REVERB_SPLIT")) return atoi(e) != 0;   // (read per call: the tests flip it)
+    DeviceInfo d;
+    if (device_info(d) != STITO_OK) return false;
+    return 2 * pop <= d.cus;
+}
+static size_t reverb_split_bytes(const stito_fx_desc *chain, int n_fx, int64_t n_samples, int pop) {   // the wet signals (pop, 2, L)
+    bool has = false;
+    for (int i = 0; i < n_fx; ++i) has |= chain[i].kind == STITO_FX_REVERB;
+    return has && reverb_split(pop) ? align_up((size_t)pop * 2 * n_samples * sizeof(float), 256) : 0;
+}
+
 extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n_fx, int in_channels,
                                                int64_t n_samples, int pop) {
     (void)in_channels;  // the compressor's share is sized for two channels per candidate whatever the chain does
@@ -817,13 +876,8 @@ extern "C" size_t stito_render_workspace_bytes(const stito_fx_desc *chain, int n
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
     size_t env = has_comp ? compressor_workspace_bytes(pop * 2, n_samples) : 0;  // block functions + boundary states
-    size_t cr = 0;  // convolution reverb: spectra of the input blocks and of every candidate's IR partitions
-    for (int i = 0; i < n_fx; ++i)
-        if (chain[i].kind == STITO_FX_NOISE_REVERB) {
-            const size_t need = conv_reverb_workspace_bytes(pop * 2, n_samples, chain[i].aux_len > 0 ? chain[i].aux_len : 1);
-            cr = need > cr ? need : cr;
-        }
-    return coef + env + cr + align_up((size_t)pop * sizeof(float), 256) + 256;
+    return coef + env + conv_reverb_bytes(chain, n_fx, n_samples, pop) + reverb_split_bytes(chain, n_fx, n_samples, pop) +
+           align_up((size_t)pop * sizeof(float), 256) + 256;
 }
 
 static int peak_strided(const float *audio_dev, int pop, int64_t per, int64_t stride, float *peaks_dev, hipStream_t st) {
@@ -892,6 +946,8 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
     bool has_comp = false;
     for (int i = 0; i < n_fx; ++i) has_comp |= chain[i].kind == STITO_FX_COMPRESSOR;
     char *crbuf = (char *)envbuf + (has_comp ? compressor_workspace_bytes(pop * 2, n_samples) : 0);
+    float *rvbuf = (float *)(crbuf + conv_reverb_bytes(chain, n_fx, n_samples, pop));   // wet signals of the per-channel Freeverb
+    const bool rv_split = reverb_split_bytes(chain, n_fx, n_samples, pop) > 0;
     // per-stage peaks (normalize_stages) live in the last pop floats of the workspace
     float *stage_peaks = (float *)(ws + (need - 256 - align_up((size_t)pop * sizeof(float), 256)));
 
@@ -971,8 +1027,16 @@ extern "C" int stito_render_population_multi(const stito_fx_desc *chain, int n_f
                 for (int k = 0; k < 16; ++k) minc = g.comb_size[k] < minc ? g.comb_size[k] : minc;
                 STITO_REQUIRE(mins >= RV_TT && minc >= 2 * RV_TT + RV_RUN && lds <= 160 * 1024, STITO_E_UNSUPPORTED,
                               "Reverb: sample rate %.0f needs delay lines outside the LDS-resident design", sample_rate);
-                STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_reverb, dim3(pop), dim3(RV_THREADS), lds, st, in, audio_dev, cand_stride, L, cf, g);
+                if (rv_split) {
+                    constexpr int NT = (RV_COMB_WAVES / 2 + RV_AP_WAVES / 2 + RV_STAGE_WAVES) * 64;
+                    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_reverb<true>, dim3(2 * pop), dim3(NT), lds, st, in, rvbuf, (int64_t)2 * L, L, cf, g);
+                    STITO_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(k_reverb_mix, dim3(grid_x_for(L, pop), pop), dim3(256), 0, st, in, rvbuf, audio_dev, cand_stride, L, cf);
+                } else {
+                    STITO_HIP_CHECK(hipFuncSetAttribute((const void *)k_reverb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_reverb<false>, dim3(pop), dim3(RV_THREADS), lds, st, in, audio_dev, cand_stride, L, cf, g);
+                }
                 break;
             }
             case STITO_FX_CHORUS: {

@@ -321,13 +321,16 @@ def test_resample_front_door_vs_oracle(dev, pm):
         assert (e[k] - e_ref[k]).abs().max() / e_ref[k].abs().max() < 1e-4
 
 
-def test_freeverb_tile_and_ring_edges_vs_oracle(dev):
-    """k_reverb's round-5 structure at its seams: signal lengths around the 192-sample tile and the four-tile staging ring (the tile
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_freeverb_tile_and_ring_edges_vs_oracle(dev, split, monkeypatch):
+    """(Both forms of the kernel: one workgroup per candidate, STITO_REVERB_SPLIT=0, and one per (candidate, channel) + the mix pass,
+    = 1, which small populations take by default.)  k_reverb's round-5 structure at its seams: signal lengths around the 192-sample tile and the four-tile staging ring (the tile
     count is padded to whole turns of the ring; the ring is loaded by inline-asm loads with hand-counted waits; samples past the
     end are zeroed where the ring is consumed), comb lines whose runs cross the end of the circular buffer (junk / mirror padding:
     room size 1 keeps every comb busy for the whole signal), both delay-line geometries (48 kHz and 44.1 kHz), mono and stereo
     input: every render within the reverb's 2e-5 bar of the oracle (measured 3e-7)."""
     from st_ito import effects as E, engine
+    monkeypatch.setenv("STITO_REVERB_SPLIT", split)
     rng = np.random.default_rng(0)
     worst = 0.0
     for sr in (48000, 44100):
@@ -346,3 +349,30 @@ def test_freeverb_tile_and_ring_edges_vs_oracle(dev):
                     worst = max(worst, err)
                     assert err < 2e-5, (sr, n, chs, p, err)
     print(f"reverb edge sweep: worst |err| {worst:.2e} of peak")
+
+
+def test_freeverb_per_channel_workgroups_are_bitwise_the_one_workgroup_kernel(dev, monkeypatch):
+    """Round 6 (VERDICT r5 next #4b): a small population runs Freeverb as TWO workgroups per candidate -- each channel's eight combs
+    and all-pass chain on its own CU, the wet / dry mix in a pointwise pass with the same two fused multiply-adds -- and must get the
+    bits of the one-workgroup kernel a large population runs: a candidate's audio (and fitness) may not depend on the batch it is
+    evaluated in.  Reverb first in the chain (shared input), behind a mono stage (up-mixed input, in place), mono and stereo input,
+    lengths around the tile / ring seams, 48 kHz and 44.1 kHz geometries."""
+    from st_ito import effects as E, engine
+    rng = np.random.default_rng(3)
+    chains = {"reverb": [("Reverb", E.BasicReverb, 2)],
+              "comp+reverb+gain": [("Compressor", E.BasicCompressor, 1), ("Reverb", E.BasicReverb, 2), ("Gain", E.BasicGain, 1)],
+              "bench5": "bench5"}
+    for name, spec in chains.items():
+        for sr in (48000, 44100):
+            for n, chs in ((1, 1), (193, 2), (769, 1), (4099, 2), (100003, 2)):
+                x = torch.from_numpy((0.5 * rng.standard_normal((chs, n))).astype(np.float32)).to(dev)
+                pp = E.make_plugins(spec)
+                D = sum(p["num_params"] for p in pp.values())
+                W = torch.from_numpy(rng.random((5, D))).to(dev)
+                outs = {}
+                for split in ("0", "1"):
+                    monkeypatch.setenv("STITO_REVERB_SPLIT", split)
+                    audio, peaks = engine.render_population(pp, x, W, sr)
+                    outs[split] = (audio.clone(), peaks.clone())
+                assert torch.isfinite(outs["0"][0]).all()
+                assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1]), (name, sr, n, chs)

@@ -766,12 +766,13 @@ def test_conv_six_sweeps_is_bitwise_the_two_sweep_kernel(dev, n, H, W, cin, cout
 
 @pytest.mark.parametrize("n,H,W,cin,cout,pool", [(64, 8, 4, 2048, 2048, 0), (64, 16, 8, 1024, 1024, 1), (5, 14, 4, 512, 512, 0), (3, 29, 8, 192, 512, 1),
                                                  (40, 13, 7, 128, 256, 1), (9, 9, 16, 64, 1024, 0), (2, 58, 16, 512, 768, 1)])
-def test_conv_two_sweep_kernel_sweep_split_and_xcd_order_are_bitwise_neutral(dev, n, H, W, cin, cout, pool, monkeypatch):
-    """Round 6, small batches: k_conv_wino43s2 with the two sweeps of an item as TWO workgroups (the second
-    waits for the first one's flag before it reads the partial outputs) and with the XCDs split in two dimensions must return
-    the bits of the one-workgroup, pair-class-per-XCD launch: same loads, same products, same additions in the same order.  Ten
-    launches per setting (a lost flag / an early read of the partials would show as a difference or a hang -> the suite's timeout);
-    the first two shapes are conv_block6 / conv_block5.conv2 of a population of 32 on 262 144 samples."""
+def test_conv_sweep_split_and_xcd_order_are_bitwise_neutral(dev, n, H, W, cin, cout, pool, monkeypatch):
+    """Round 6, small batches: the streaming kernels with the sweeps of an item as SEPARATE workgroups --
+    k_conv_wino43s2: two (the second waits for the first one's flag before it reads the partial outputs), k_conv_wino43s3: six
+    (the row-5 workgroup waits for a count of five) -- and k_conv_wino43s2 with the XCDs split in two dimensions must return the
+    bits of the one-workgroup launches: same loads, same products, same additions in the same order.  Ten launches per setting (a
+    lost flag / an early read of the partials would show as a difference, or as a hang -> run under `timeout`); the first two shapes
+    are conv_block6 / conv_block5.conv2 of a population of 32 on 262 144 samples.  The two kernels also agree with each other."""
     from st_ito import _hip
     L = _hip.lib()
     st = _hip.stream_ptr()
@@ -781,17 +782,20 @@ def test_conv_two_sweep_kernel_sweep_split_and_xcd_order_are_bitwise_neutral(dev
     w = (torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)).to(dev)
     sc = (0.5 + torch.rand(cout, generator=g)).to(dev); sh = (0.1 * torch.randn(cout, generator=g)).to(dev)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-    m = _hip.CONV_WINOGRAD_F4_SPLIT2
-    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, m)
-    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, m), device=dev)
-    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, m, _hip.ptr(packed), st))
     ref = None
-    for split, xm in (("0", "8"), ("1", "8"), ("1", None), ("0", None), ("1", "2"), ("1", "1"), ("0", "4")):
-        monkeypatch.setenv("STITO_W43S2_SWSPLIT", split)
-        if xm is None:
-            monkeypatch.delenv("STITO_W43S2_XM", raising=False)
-        else:
-            monkeypatch.setenv("STITO_W43S2_XM", xm)
+    settings = [(_hip.CONV_WINOGRAD_F4_SPLIT2, {"STITO_W43S2_SWSPLIT": sp, "STITO_W43S2_XM": xm})
+                for sp, xm in (("0", "8"), ("1", "8"), ("1", None), ("0", None), ("1", "2"), ("1", "1"), ("0", "4"))]
+    if cout % 512 == 0:
+        settings += [(_hip.CONV_WINOGRAD_F4_SPLIT3, {"STITO_W43S3_SWSPLIT": sp}) for sp in ("0", "1", None)]
+    for m, env in settings:
+        for k in ("STITO_W43S2_SWSPLIT", "STITO_W43S2_XM", "STITO_W43S3_SWSPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            if v is not None:
+                monkeypatch.setenv(k, v)
+        assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, m)
+        packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, m), device=dev)
+        _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, m, _hip.ptr(packed), st))
         wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, m)   # the grid (and with it the scratch area) follows the XCD order
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         for rep in range(10):
@@ -801,7 +805,7 @@ def test_conv_two_sweep_kernel_sweep_split_and_xcd_order_are_bitwise_neutral(dev
             if ref is None:
                 ref = out
                 assert not torch.isnan(ref).any()
-            assert torch.equal(out, ref), (split, xm, rep)
+            assert torch.equal(out, ref), (m, env, rep)
 
 
 def test_trunk_small_batches_take_the_two_sweep_packing(dev):

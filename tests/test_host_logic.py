@@ -581,27 +581,29 @@ def test_reverb_staging_ring_registers_are_out_of_the_compilers_reach(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w",
                            "-I", os.path.join(ROOT, "include"), src, "-o", str(out)])
     text = out.read_text()
-    m = re.search(r"^(_ZN5stito8k_reverb\w*):.*?^\s*s_endpgm", text, flags=re.S | re.M)
-    assert m, "k_reverb not found in the compiled assembly"
-    inside, highest, ring_loads, ring_regs = False, -1, 0, set()
-    for line in m.group(0).splitlines():
-        if "ASMSTART" in line:
-            inside = True
-            continue
-        if "ASMEND" in line:
-            inside = False
-            continue
-        code = line.split(";")[0]
-        if inside:
-            mm = re.search(r"global_load_dword v(\d+),", code)
-            if mm:
-                ring_loads += 1
-                ring_regs.add(int(mm.group(1)))
-            continue
-        assert "scratch_" not in code, f"k_reverb spills: {code.strip()}"
-        for a, b in re.findall(r"\bv(\d+)\b|\bv\[\d+:(\d+)\]", code):
-            highest = max(highest, int(a or b))
-    assert ring_loads == 36 and ring_regs == set(range(64, 80)), (ring_loads, sorted(ring_regs))
+    bodies = [m.group(0) for m in re.finditer(r"^(_ZN5stito8k_reverb\w*):.*?^\s*s_endpgm", text, flags=re.S | re.M)]
+    assert len(bodies) == 2, "k_reverb<false> and k_reverb<true> (one workgroup per candidate / per channel) expected in the compiled assembly"
+    highest = -1
+    for body in bodies:
+        inside, ring_loads, ring_regs = False, 0, set()
+        for line in body.splitlines():
+            if "ASMSTART" in line:
+                inside = True
+                continue
+            if "ASMEND" in line:
+                inside = False
+                continue
+            code = line.split(";")[0]
+            if inside:
+                mm = re.search(r"global_load_dword v(\d+),", code)
+                if mm:
+                    ring_loads += 1
+                    ring_regs.add(int(mm.group(1)))
+                continue
+            assert "scratch_" not in code, f"k_reverb spills: {code.strip()}"
+            for a, b in re.findall(r"\bv(\d+)\b|\bv\[\d+:(\d+)\]", code):
+                highest = max(highest, int(a or b))
+        assert ring_loads == 36 and ring_regs == set(range(64, 80)), (ring_loads, sorted(ring_regs))
     assert 0 <= highest < 64, f"compiler-allocated code of k_reverb reaches v{highest}: it would clobber the staging ring (v64 .. v79)"
 
 
