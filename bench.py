@@ -35,7 +35,7 @@ The JSON line also carries
   roofline_dsp : render + log-mel against HBM: SURVEY 8(d)'s algorithmic bytes (8.16 MB per 10 s stereo candidate: shared input
                  read, rendered audio written, log-mel written) / the time of those kernels (HIP events around the two stages
                  of a separate, untimed pass) against 8 TB/s; traffic = FETCH_SIZE x2 + WRITE_SIZE of those kernels per step from the
-                 committed PMC passes (profiles/round5_dsp_pmc_traffic.json), quoted only for the sources and workload they were taken on;
+                 committed PMC passes (profiles/round6_dsp_pmc_traffic.json), quoted only for the sources and workload they were taken on;
   launch_mode  : whether the timed steps replayed the evaluate step's hipGraph, and the step time of the eager region behind them;
   last_fitness_sha16 : sha256 of the last timed step's fitness vector (runs of the same tree are comparable bit for bit);
   stages       : per-rank (evaluate, gather, tell) milliseconds per step, min / max over ranks (diagnosis of a first multi-GPU run);
@@ -96,7 +96,7 @@ def conv_layer_table(T, M=128):
     return rows
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round5_conv_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round6_conv_pmc_traffic.json")
 
 
 def kernel_source_hash():
@@ -128,7 +128,7 @@ def pmc_traffic_per_launch(n_streams):
     return float(d["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(PMC_TRAFFIC_JSON)}"
 
 
-PMC_DSP_JSON = os.path.join(ROOT, "profiles", "round5_dsp_pmc_traffic.json")
+PMC_DSP_JSON = os.path.join(ROOT, "profiles", "round6_dsp_pmc_traffic.json")
 
 
 def dsp_source_hash():

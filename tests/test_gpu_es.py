@@ -837,7 +837,11 @@ def test_case_study_point_against_the_oracle(dev, tmp_path):
     om = O.make_synthetic_model(0)
     pm = _product_model(dev, om)
     src = [O.synth_audio(801, 2, C.MIN_LEN + 30000), O.synth_audio(802, 1, C.MIN_LEN + 50000)]
-    for plugin_name, kind, value in (("pb_Compressor", "Compressor", 0.3), ("pb_Reverb", "Reverb", 0.7)):
+    # (the compressor point is degenerate by construction: a threshold below the signal's level only scales the output, which the peak
+    # normalisation takes back out, so five of six candidates TIE -- exactly on the CPU, to an ulp on the GPU -- and which of them a
+    # side selects is decided by that ulp (round 6: tools/case_study_debug.py).  Its selected VALUE is therefore compared, not its
+    # vector; the EQ and reverb points have no ties and must select bit-identical vectors.)
+    for plugin_name, kind, value in (("pb_ParametricEQ", "ParametricEQ", 0.3), ("pb_Compressor", "Compressor", 0.3), ("pb_Reverb", "Reverb", 0.7)):
         spec, param, lo, hi = C.get_case(plugin_name)
         got = C.study_point(spec, plugin_name, param, value, lambda r: (src[0], src[1]), pm, np.random.RandomState(11), max_iters=2, popsize=6, seed=4)
         op = O.make_plugins([kind], with_bypass=True)
@@ -845,10 +849,12 @@ def test_case_study_point_against_the_oracle(dev, tmp_path):
         op[plugin_name]["fixed_parameters"] = dict(spec[plugin_name]["fixed_parameters"])
         est, fopt, target_value, wopt = O.case_study_point(op, plugin_name, param, value, src[0], src[1], om, cmaes.CMAEvolutionStrategy,
                                                            np.random.RandomState(11), max_iters=2, popsize=6, seed=4)
-        np.testing.assert_array_equal(got["wopt"], wopt, err_msg=plugin_name)
-        assert got["estimated_param"] == est and abs(got["fopt"] - fopt) < 1e-4
+        if plugin_name != "pb_Compressor":
+            np.testing.assert_array_equal(got["wopt"], wopt, err_msg=plugin_name)
+            assert got["estimated_param"] == est
+        assert abs(got["fopt"] - fopt) < (1e-6 if plugin_name == "pb_Compressor" else 1e-4)
         assert got["target_value"] == pytest.approx(target_value, abs=1e-12)
-        prm_lo, prm_hi = {"pb_Compressor": (-80.0, 0.0), "pb_Reverb": (0.0, 1.0)}[plugin_name]
+        prm_lo, prm_hi = {"pb_Compressor": (-80.0, 0.0), "pb_Reverb": (0.0, 1.0), "pb_ParametricEQ": (-24.0, 24.0)}[plugin_name]
         assert got["target_value"] == pytest.approx(prm_lo + value * (prm_hi - prm_lo))
     res = C.run_case_study(["pb_Distortion"], src, pm, str(tmp_path), num_runs=1, num_steps=2, max_iters=1, popsize=4, seed=2, save_audio=True)
     runs = res["pb_Distortion"]["different"]["param-panns"]["drive_db"]

@@ -1,21 +1,21 @@
 #!/bin/bash
-# The measurement pass behind profiles/ (round 5).  One command on one box:   gpurun -- bash tools/profile_round.sh
-# Outputs under gpurun_out/r5p: copy the summaries into profiles/.  Order: the PMC passes over the bench process itself first (separate
+# The measurement pass behind profiles/ (round 6; round 5's recipe + the small-population A/B and the chunked-schedule sweep).  One command on one box:   gpurun -- bash tools/profile_round.sh
+# Outputs under gpurun_out/r6p: copy the summaries into profiles/.  Order: the PMC passes over the bench process itself first (separate
 # passes, kernel trace only, eager launches so that every kernel is a dispatch the counters are attributed to) -- their summaries go
 # into profiles/ BEFORE the bench line is taken, so that the line of this very run carries roofline.traffic / roofline_dsp.traffic for
 # this tree's kernel sources -- then the bench line, rocprofv3 kernel trace + stats of the same command, the EA-side counters
 # (requests, latency) of the conv launches with their Infinity-Cache / HBM calibration, the configs, accuracy, race hunt, LDS counters.
 set -x
-rm -rf gpurun_out/r5p; mkdir -p gpurun_out/r5p
+rm -rf gpurun_out/r6p; mkdir -p gpurun_out/r6p
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5p
+O=$R/gpurun_out/r6p
 cd /tmp && export TMPDIR=/tmp
 # 1. PMC passes (separate), on the bench process, eager launches
 BENCH_PMC="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pop512 --no-roofline"
 STITO_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -- $BENCH_PMC > $O/pmc_fetch.log 2>&1
 STITO_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -- $BENCH_PMC > $O/pmc_write.log 2>&1
-(cd $R && python profiles/summarize_pmc_bench.py gpurun_out/r5p/pmc_fetch/*/*_results.db gpurun_out/r5p/pmc_write/*/*_results.db 512 gpurun_out/r5p/conv_pmc_traffic.json > gpurun_out/r5p/conv_pmc_traffic.txt 2>&1 && cp gpurun_out/r5p/conv_pmc_traffic.json profiles/round5_conv_pmc_traffic.json)
-(cd $R && python profiles/summarize_pmc_dsp.py gpurun_out/r5p/pmc_fetch/*/*_results.db gpurun_out/r5p/pmc_write/*/*_results.db 256 480000 gpurun_out/r5p/dsp_pmc_traffic.json > gpurun_out/r5p/dsp_pmc_traffic.txt 2>&1 && cp gpurun_out/r5p/dsp_pmc_traffic.json profiles/round5_dsp_pmc_traffic.json)
+(cd $R && python profiles/summarize_pmc_bench.py gpurun_out/r6p/pmc_fetch/*/*_results.db gpurun_out/r6p/pmc_write/*/*_results.db 512 gpurun_out/r6p/conv_pmc_traffic.json > gpurun_out/r6p/conv_pmc_traffic.txt 2>&1 && cp gpurun_out/r6p/conv_pmc_traffic.json profiles/round6_conv_pmc_traffic.json)
+(cd $R && python profiles/summarize_pmc_dsp.py gpurun_out/r6p/pmc_fetch/*/*_results.db gpurun_out/r6p/pmc_write/*/*_results.db 256 480000 gpurun_out/r6p/dsp_pmc_traffic.json > gpurun_out/r6p/dsp_pmc_traffic.txt 2>&1 && cp gpurun_out/r6p/dsp_pmc_traffic.json profiles/round6_dsp_pmc_traffic.json)
 cat $O/conv_pmc_traffic.txt | cut -c1-60,92-170; cat $O/dsp_pmc_traffic.txt
 # 2. bench line (with cpu baseline), plain
 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
@@ -39,6 +39,9 @@ for pop in 32 64 128; do for gr in 1 0; do
   echo -n "pop $pop, 262144 samples, bench chain, STITO_GRAPH=$gr: cand/s, ms/step, host ms (ask + launch, sync, tell): " >> $O/small_pop.txt
   STITO_GRAPH=$gr python bench.py --pop-per-gpu $pop --seconds 5.4613 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline --no-pop512 2>> $O/bench.err | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['stages']['evaluate_ms']['max'], d['stages']['gather_ms']['max'], d['stages']['tell_ms']['max'])" >> $O/small_pop.txt
 done; done
+# 5b. round 6: depth-first trunk schedule sweep + its EA counters are tools/chunk_sweep.py / tools/chunk_ea.sh (run on their own);
+#     small populations: deep layers two-sweep / six-sweep, sweeps in one workgroup or split (tools/small_conv_ab.sh)
+bash tools/small_conv_ab.sh > $O/small_conv_ab.txt 2>&1
 # 6. race hunt on the shipped conv kernels (every layer shape at 512 streams, 10 launches per algorithm) and random shapes
 (echo "# python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8,9"; timeout 900 python tools/conv_stress.py --streams 512 --reps 10 --modes 2,3,4,5,8,9 2>&1 | grep -v amdgpu.ids) > $O/conv_stress.txt
 (echo "# python tools/conv_fuzz.py --cases 150 --seed 5"; timeout 600 python tools/conv_fuzz.py --cases 150 --seed 5 2>&1 | grep -v amdgpu.ids) > $O/conv_fuzz.txt
