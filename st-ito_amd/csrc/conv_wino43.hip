@@ -95,6 +95,7 @@ struct Wino43Geom {
     int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
     int n_mblocks;     // pixel blocks (MODE 1: the grid is padded to whole XCD rounds)
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
+    int n_items;       // k_conv_wino43s, persistent form: items of the grid-stride loop (0: one item per workgroup = blockIdx.x)
     int xcd_m;         // k_conv_wino43s3: the 8 XCDs as xcd_m pixel-block classes x 8 / xcd_m channel-tile ranges (8 = the other kernels' order)
     FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
@@ -325,9 +326,16 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
+    // MODE 0, persistent form (round 6, g.n_items > 0; see k_conv_wino43s): the grid is one workgroup per CU and every workgroup walks
+    // the items bidx, bidx + gridDim.x, ... -- what the dispatcher would have handed that CU anyway, without the idle hand-over
+    const int n_items = (MODE == 0 && g.n_items > 0) ? g.n_items : (int)gridDim.x;
+    bool first_item = true;
+    for (int bidx = blockIdx.x; bidx < n_items; bidx += (int)gridDim.x) {
+    if (!first_item) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass before LDS is refilled
+    first_item = false;
     int ct_;
-    int m_blk = VOUT ? (int)blockIdx.x / n_tiles : fdiv((int)blockIdx.x, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    if (VOUT) ct_ = (int)blockIdx.x % n_tiles;
+    int m_blk = VOUT ? bidx / n_tiles : fdiv(bidx, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    if (VOUT) ct_ = bidx % n_tiles;
     int n0 = VOUT ? 0 : ct_ * 64;
     if constexpr (PREV) {
         // MODE 1 streams 18 KB of V and 36 KB of U per period through L2, and workgroup b runs on XCD b % 8 (own L2 each).
@@ -335,12 +343,12 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         // (PMC: 22.8 GB for conv_block4.conv2 against 9.2 GB for MODE 0).  Here the 32 workgroups an XCD runs at a time are
         // 8 pixel blocks x 4 channel tiles: 8 V streams + 4 U streams = 288 KB per period per XCD, the minimum of 18 a + 36 b
         // over a b = 32 (612 KB before).  Pixel blocks are dealt round-robin to the XCDs; padding workgroups leave at once.
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3, r = j & 31, gi = j >> 5;
+        const int b = bidx, xcd = b & 7, j = b >> 3, r = j & 31, gi = j >> 5;
         const int a = g.ct_group, n_ctg = n_tiles / a;          // a channel tiles x 32 / a pixel blocks per XCD round
         const int ct = (gi % n_ctg) * a + (r % a);
         m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
         n0 = ct * 64;
-        if (m_blk >= g.n_mblocks) return;
+        if (m_blk >= g.n_mblocks) return;   // (MODE 1 is never persistent: one item per workgroup)
     }
     int cb;
     const int rb = fdiv(m_blk, g.fNCB, cb);
@@ -725,8 +733,9 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     W43_STAMP(2)
 
     w43_epilogue<TTW, POOL, false>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, 1.0f, nullptr);
-    W43_CLK_END()
     W43_STAMP(3)
+    }   // items
+    W43_CLK_END()
 }
 
 // Winograd F(4x4,3x3) weight transform U = G g G^T (float64, rounded once), packed [cin/4][36][channel pair][cout][2].
@@ -782,14 +791,24 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup order: as MODE 1 (XCD b % 8 runs ct_group channel tiles x 32 / ct_group pixel blocks at a time)
+    // PERSISTENT form (round 6, g.n_items > 0): the grid is ONE round of workgroups (8 XCDs x 32) and every workgroup walks the items
+    // b, b + gridDim.x, ... -- the items the dispatcher would have handed its CU anyway (same XCD, same slot of the round), without
+    // the hand-over: one workgroup fits a CU (144 KB of LDS), so the CU sat idle from a workgroup's last store until the next one had
+    // been dispatched and had issued its first copies -- 3 - 13 us per ~40 - 50 us item (W43_CLK builds: 60 items x 49.6 us = 2.98 ms
+    // of a 3.54 ms launch of conv_block3.conv2).
     const int n_tiles = g.Cout / 64;
-    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    const int n_items = g.n_items > 0 ? g.n_items : (int)gridDim.x;
+    W43_CLK_BEGIN()
+    bool first_item = true;
+    for (int b = blockIdx.x; b < n_items; b += (int)gridDim.x) {
+    const int xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
     const int a = g.ct_group, n_ctg = n_tiles / a;
     const int ct = (gi % n_ctg) * a + (r % a);
     const int m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
     const int n0 = ct * 64;
-    if (m_blk >= g.n_mblocks) return;
-    W43_CLK_BEGIN()
+    if (m_blk >= g.n_mblocks) continue;
+    if (!first_item) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass: the ring may be refilled
+    first_item = false;
     int cb;
     const int rb = fdiv(m_blk, g.fNCB, cb);
     const int vtr0 = rb * TTH, tc0 = cb * TTW;
@@ -882,6 +901,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
     }
     w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
+    }   // items
     W43_CLK_END()
 }
 
@@ -1516,6 +1536,8 @@ static int w43_ttw(const ConvShape &c, bool pool) {
 
 template <int TTW>
 static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &lds, int64_t &blocks) {
+    g.n_items = 0;   // one item per workgroup unless a launcher sets up the persistent form
+
     constexpr int TTH = 32 / TTW;
     g = Wino43Geom{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
@@ -1629,6 +1651,14 @@ static int launch_w43(const float *in, const float *upk, const float *scale, con
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     g.trace = trace;
     g.amax_out = amax_out;
+    if (trace == nullptr) {   // persistent form: one workgroup per CU walks the items (see the kernel); STITO_W43_PERSIST=0 = one workgroup per item
+        static const bool persist = [] { const char *e = getenv("STITO_W43_PERSIST"); return e ? atoi(e) != 0 : true; }();
+        DeviceInfo d;
+        if (persist && device_info(d) == STITO_OK && d.cus >= 8 && d.cus % 8 == 0 && d.cus % (c.Cout / 64) == 0 && blocks > d.cus && blocks < (1ll << 31)) {
+            g.n_items = (int)blocks;
+            blocks = d.cus;   // (a multiple of 8 and of the channel tiles: item b stays on XCD b % 8 and next to its patch's other tiles)
+        }
+    }
     W43_CLK_ARM(g)
     auto kern = trace ? k_conv_wino43<TTW, POOL, true> : k_conv_wino43<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1786,6 +1816,15 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv (split-precision winograd): grid");
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
+    {   // persistent form: one round of workgroups walks the items (see the kernel); STITO_W43S_PERSIST=0 = one workgroup per item
+        static const bool persist = [] { const char *e = getenv("STITO_W43S_PERSIST"); return e ? atoi(e) != 0 : true; }();
+        DeviceInfo d;
+        g.n_items = 0;
+        if (persist && device_info(d) == STITO_OK && d.cus >= 256 && blocks > 256) {
+            g.n_items = (int)blocks;
+            blocks = 256;   // 8 XCDs x 32: the round the workgroup order is built on
+        }
+    }
     W43_CLK_ARM(g)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
                        (const unsigned *)amax, u_inv);
