@@ -188,11 +188,10 @@ __device__ __forceinline__ unsigned w43_max4(f32x4 v) {
 // SPLIT: the accumulators carry the power-of-two operand scales of the split-precision kernel: 1 / (u_scale * v_scale(stream))
 // is folded into the BN scale (exact: powers of two).
 #define W43_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-template <int TTW, bool POOL, bool SPLIT>
-__device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh,
-                                             const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
-                                             const float *__restrict__ scale, const float *__restrict__ shift,
-                                             float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
+// Two halves: the exchange (three passes through LDS -> the thread's 4 x 4 outputs Yo) and the finish (BN, ReLU, pool, stores: registers
+// only -- a persistent workgroup issues its next item's first copies between the two, once a barrier has seen every wave's last
+// exchange read).
+__device__ __forceinline__ void w43_epilogue_exchange(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh, f32x4 (&Yo)[4][4]) {
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
 #define A4(a, b) __builtin_shufflevector(pk_add(P2(a, 0), P2(b, 0)), pk_add(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
 #define S4(a, b) __builtin_shufflevector(pk_sub(P2(a, 0), P2(b, 0)), pk_sub(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
@@ -201,7 +200,6 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
     constexpr int XP = 32 * W43_XT;
     const int e_quad = tid & 15, e_tile = tid >> 4;
     const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
-    f32x4 Yo[4][4];
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         W43_BARRIER()  // the main loop's (or the previous pass's) LDS reads are done
@@ -251,6 +249,13 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
 #undef A4
 #undef S4
 #undef F4
+}
+
+template <int TTW, bool POOL, bool SPLIT>
+__device__ __forceinline__ void w43_epilogue_store(f32x4 (&Yo)[4][4], const int tid, const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
+    const int e_quad = tid & 15, e_tile = tid >> 4;
     // BN + ReLU (+ 2x2 average pool), 16-byte stores (4 channels) into NC8HW8
     {
         const int co = n0 + e_quad * 4;
@@ -299,6 +304,16 @@ __device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], cons
         // (outside the branch: the DPP reduction reads all 16 lanes of the tile's row; a tile is valid or not as a whole)
         if (g.amax_out != nullptr) w43_amax_out(g.amax_out, sidx, smax);
     }
+}
+
+template <int TTW, bool POOL, bool SPLIT>
+__device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh,
+                                             const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
+                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                             float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
+    f32x4 Yo[4][4];
+    w43_epilogue_exchange(smem, acc, tid, pg, nh, Yo);
+    w43_epilogue_store<TTW, POOL, SPLIT>(Yo, tid, g, n0, vtr0, tc0, scale, shift, out, u_inv, amax);
 }
 
 // MODE 0: the whole convolution (patch -> V in the workgroup).  The workgroups of one pixel block that differ only in their
@@ -800,22 +815,28 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     const int n_items = g.n_items > 0 ? g.n_items : (int)gridDim.x;
     W43_CLK_BEGIN()
     bool first_item = true;
-    for (int b = blockIdx.x; b < n_items; b += (int)gridDim.x) {
-    const int xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    bool prefetched = false;   // this item's slabs 0 and 1 were issued from inside the previous item's epilogue
     const int a = g.ct_group, n_ctg = n_tiles / a;
-    const int ct = (gi % n_ctg) * a + (r % a);
-    const int m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+    const int n_slabs = (g.Cin >> 5) * 9;
+    const int set = wv >> 2, w4 = wv & 3, pg = wv >> 1, nh = wv & 1;
+    // item b -> (pixel block, channel tile); false: a padding item of the last round
+    auto item_of = [&](int b_, int &m_blk_, int &ct_) {
+        const int xcd = b_ & 7, jb = b_ >> 3, r = jb & 31, gi = jb >> 5;
+        ct_ = (gi % n_ctg) * a + (r % a);
+        m_blk_ = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
+        return m_blk_ < g.n_mblocks;
+    };
+    for (int b = blockIdx.x; b < n_items; b += (int)gridDim.x) {
+    int m_blk, ct;
+    if (!item_of(b, m_blk, ct)) continue;
     const int n0 = ct * 64;
-    if (m_blk >= g.n_mblocks) continue;
-    if (!first_item) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass: the ring may be refilled
+    if (!first_item && !prefetched) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass: the ring may be refilled
     first_item = false;
     int cb;
     const int rb = fdiv(m_blk, g.fNCB, cb);
     const int vtr0 = rb * TTH, tc0 = cb * TTW;
-    const int n_slabs = (g.Cin >> 5) * 9;
     const char *vbase = vsl + (int64_t)m_blk * n_slabs * S43_VPART;
     const char *ubase = usl + (int64_t)ct * n_slabs * S43_UPART;
-    const int set = wv >> 2, w4 = wv & 3, pg = wv >> 1, nh = wv & 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     const char *vw = vbase + w4 * 1024, *uw = ubase + w4 * 1024;
     const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
@@ -843,6 +864,13 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
 // 13.07 -> 12.64 ms, profiles/README.md.
 #ifndef S43_ILV
 #define S43_ILV 1
+#endif
+#ifndef S43_PREFETCH_NEXT
+#define S43_PREFETCH_NEXT 0   // persistent k_conv_wino43s: the next item's first slabs issued in front of the epilogue's store phase.  Built and
+                              // measured in round 6 (tools/prefetch_ab.sh, profiles/round6_persist_ab.txt): NEUTRAL -- 3.36 / 5.49 / 2.51 ms against
+                              // 3.39 / 5.51 / 2.45 for conv_block3.conv1 / conv2 / conv_block4.conv1, bench step 45.68 against 45.69 ms on that box:
+                              // once the workgroup is persistent its first slabs are L2 hits that land while vmcnt(0) still waits for the previous
+                              // item's stores.  Off (1: -DS43_PREFETCH_NEXT=1 builds; parity / race / stress green with it on)
 #endif
 #define S43_MFMA_P(Q, A_, B_) asm volatile("" : "+v"(acc[Q])); S43_MFMA(Q, A_, B_) asm volatile("" : "+v"(acc[Q]));
 #define S43_GAP() __builtin_amdgcn_sched_barrier(0);
@@ -888,8 +916,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         W43_BARRIER()                                                                                     \
     }
 
-    if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!prefetched) { if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) } }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a prefetched item: also the previous item's output stores)
     W43_BARRIER()
     h8 ahP, alP, bhP, blP;  // S43_ILV: operands of the previous period's second block
     for (int sl = 0; sl < ((S43B_ABL & 1) ? 0 : n_slabs); sl += 18) {  // Cin % 64 == 0
@@ -900,7 +928,26 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     if (S43_ILV && !(S43B_ABL & 5)) {  // the last period's second block (n_slabs % 18 == 0: accumulator 8)
         S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
     }
-    w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
+    {
+        f32x4 Yo[4][4];
+        w43_epilogue_exchange(smem, acc, tid, pg, nh, Yo);
+        // The finish (BN, ReLU, pool, 4 - 16 stores per thread: 2 300 - 9 500 cycles) runs on registers only: once a barrier has seen
+        // every wave's last exchange read, the NEXT item's slabs 0 and 1 go out in front of it -- their latency (the ~3 000 - 4 000
+        // cycles every item used to start with) passes under the stores.  (VERDICT r5 next #2.)
+        prefetched = false;
+        int m_next, ct_next;
+        const int b_next = b + (int)gridDim.x;
+        if (S43_PREFETCH_NEXT && b_next < n_items && item_of(b_next, m_next, ct_next)) {
+            W43_BARRIER()
+            const char *vw_keep = vw, *uw_keep = uw;
+            vw = vsl + (int64_t)m_next * n_slabs * S43_VPART + w4 * 1024;
+            uw = usl + (int64_t)ct_next * n_slabs * S43_UPART + w4 * 1024;
+            if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
+            vw = vw_keep; uw = uw_keep;
+            prefetched = true;
+        }
+        w43_epilogue_store<TTW, POOL, true>(Yo, tid, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
+    }
     }   // items
     W43_CLK_END()
 }
