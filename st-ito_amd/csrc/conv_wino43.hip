@@ -343,7 +343,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
     // MODE 0, persistent form (round 6, g.n_items > 0; see k_conv_wino43s): the grid is one workgroup per CU and every workgroup walks
     // the items bidx, bidx + gridDim.x, ... -- what the dispatcher would have handed that CU anyway, without the idle hand-over
-    const int n_items = (MODE == 0 && g.n_items > 0) ? g.n_items : (int)gridDim.x;
+    const int n_items = (MODE != 1 && g.n_items > 0) ? g.n_items : (int)gridDim.x;   // (the transform passes, MODE >= 2: two workgroups per CU)
     bool first_item = true;
     for (int bidx = blockIdx.x; bidx < n_items; bidx += (int)gridDim.x) {
     if (!first_item) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass before LDS is refilled
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
                 --k;
             }
             W43_PERIOD(y, x, false, false)  // k = n_chunks - 1
-            if constexpr (VOUT) return;  // every V slab is in HBM
+            if constexpr (VOUT) continue;  // every V slab is in HBM: the next item (persistent form) or the end
             W43_MFMA(x, 2, 0, 0) W43_MFMA(x, 2, 1, 0) W43_MFMA(x, 2, 2, 0)
             W43_MFMA(x, 2, 0, 1) W43_MFMA(x, 2, 1, 1) W43_MFMA(x, 2, 2, 1)
         }
@@ -1802,6 +1802,18 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
     }
 }
 
+// Transform passes (MODE 3 / 4 / 5) in the persistent form: two workgroups per CU walk the (pixel block, chunk group) items.  OFF unless
+// STITO_W43T_PERSIST=1: measured neutral (tools/persist_ab.sh: eleven layers 41.08 -> 41.06 ms, bench step 45.93 -> 46.03) -- with two
+// workgroups resident per CU the other one covers a hand-over, and the passes run at the HBM roofline anyway.  -> the grid to launch
+static int64_t w43_transform_grid(Wino43Geom &gv, int64_t items) {
+    static const bool persist = [] { const char *e = getenv("STITO_W43T_PERSIST"); return e ? atoi(e) != 0 : false; }();
+    DeviceInfo d;
+    gv.n_items = 0;
+    if (!persist || device_info(d) != STITO_OK || items <= 2 * (int64_t)d.cus || items >= (1ll << 31)) return items;
+    gv.n_items = (int)items;
+    return 2 * (int64_t)d.cus;
+}
+
 // Split-precision variant of the hoisted path: stream maxima -> MODE 3 (V slabs as scaled f16 halves) -> k_conv_wino43s.
 // Workspace: the V slabs (the same bytes as MODE 2's) followed by one unsigned per stream.
 bool wino43_split_supported(const ConvShape &c, bool pool) {
@@ -1843,7 +1855,8 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
         auto kern = k_conv_wino43<TTW, POOL, false, 3>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+        const int64_t tgrid = w43_transform_grid(gv, m_blocks * ncg);   // (sets gv.n_items: before gv is copied into the launch)
+        hipLaunchKernelGGL(kern, dim3((unsigned)tgrid), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
@@ -1983,7 +1996,8 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
         auto kern = k_conv_wino43<TTW, POOL, false, 4>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks2 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+        const int64_t tgrid = w43_transform_grid(gv, m_blocks2 * ncg);   // (sets gv.n_items: before gv is copied into the launch)
+        hipLaunchKernelGGL(kern, dim3((unsigned)tgrid), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
@@ -2153,7 +2167,8 @@ static int launch_w43_split3(const float *in, const float *upk, const float *sca
         auto kern = k_conv_wino43<TTW, POOL, false, 5>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks4 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+        const int64_t tgrid = w43_transform_grid(gv, m_blocks4 * ncg);   // (sets gv.n_items: before gv is copied into the launch)
+        hipLaunchKernelGGL(kern, dim3((unsigned)tgrid), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
