@@ -95,7 +95,6 @@ struct Wino43Geom {
     int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
     int n_mblocks;     // pixel blocks (MODE 1: the grid is padded to whole XCD rounds)
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
-    int n_items;       // k_conv_wino43s, persistent form: items of the grid-stride loop (0: one item per workgroup = blockIdx.x)
     int xcd_m;         // k_conv_wino43s3: the 8 XCDs as xcd_m pixel-block classes x 8 / xcd_m channel-tile ranges (8 = the other kernels' order)
     FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
@@ -188,10 +187,11 @@ __device__ __forceinline__ unsigned w43_max4(f32x4 v) {
 // SPLIT: the accumulators carry the power-of-two operand scales of the split-precision kernel: 1 / (u_scale * v_scale(stream))
 // is folded into the BN scale (exact: powers of two).
 #define W43_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-// Two halves: the exchange (three passes through LDS -> the thread's 4 x 4 outputs Yo) and the finish (BN, ReLU, pool, stores: registers
-// only -- a persistent workgroup issues its next item's first copies between the two, once a barrier has seen every wave's last
-// exchange read).
-__device__ __forceinline__ void w43_epilogue_exchange(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh, f32x4 (&Yo)[4][4]) {
+template <int TTW, bool POOL, bool SPLIT>
+__device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh,
+                                             const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
+                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                             float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
 #define A4(a, b) __builtin_shufflevector(pk_add(P2(a, 0), P2(b, 0)), pk_add(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
 #define S4(a, b) __builtin_shufflevector(pk_sub(P2(a, 0), P2(b, 0)), pk_sub(P2(a, 1), P2(b, 1)), 0, 1, 2, 3)
@@ -200,6 +200,7 @@ __device__ __forceinline__ void w43_epilogue_exchange(float *smem, f32x16 (&acc)
     constexpr int XP = 32 * W43_XT;
     const int e_quad = tid & 15, e_tile = tid >> 4;
     const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
+    f32x4 Yo[4][4];
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         W43_BARRIER()  // the main loop's (or the previous pass's) LDS reads are done
@@ -249,13 +250,6 @@ __device__ __forceinline__ void w43_epilogue_exchange(float *smem, f32x16 (&acc)
 #undef A4
 #undef S4
 #undef F4
-}
-
-template <int TTW, bool POOL, bool SPLIT>
-__device__ __forceinline__ void w43_epilogue_store(f32x4 (&Yo)[4][4], const int tid, const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
-                                                   const float *__restrict__ scale, const float *__restrict__ shift,
-                                                   float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
-    const int e_quad = tid & 15, e_tile = tid >> 4;
     // BN + ReLU (+ 2x2 average pool), 16-byte stores (4 channels) into NC8HW8
     {
         const int co = n0 + e_quad * 4;
@@ -306,16 +300,6 @@ __device__ __forceinline__ void w43_epilogue_store(f32x4 (&Yo)[4][4], const int 
     }
 }
 
-template <int TTW, bool POOL, bool SPLIT>
-__device__ __forceinline__ void w43_epilogue(float *smem, f32x16 (&acc)[9], const int tid, const int pg, const int nh,
-                                             const Wino43Geom &g, const int n0, const int vtr0, const int tc0,
-                                             const float *__restrict__ scale, const float *__restrict__ shift,
-                                             float *__restrict__ out, const float u_inv, const unsigned *__restrict__ amax) {
-    f32x4 Yo[4][4];
-    w43_epilogue_exchange(smem, acc, tid, pg, nh, Yo);
-    w43_epilogue_store<TTW, POOL, SPLIT>(Yo, tid, g, n0, vtr0, tc0, scale, shift, out, u_inv, amax);
-}
-
 // MODE 0: the whole convolution (patch -> V in the workgroup).  The workgroups of one pixel block that differ only in their
 // 64 output channels all repeat the same input transform (8 .. 32 times for Cout >= 512), and it is paid in the same
 // ALUs the f32 MFMAs run on; for those layers the transform is hoisted: MODE 2 runs the production pipeline alone (one
@@ -341,16 +325,9 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
-    // MODE 0, persistent form (round 6, g.n_items > 0; see k_conv_wino43s): the grid is one workgroup per CU and every workgroup walks
-    // the items bidx, bidx + gridDim.x, ... -- what the dispatcher would have handed that CU anyway, without the idle hand-over
-    const int n_items = (MODE != 1 && g.n_items > 0) ? g.n_items : (int)gridDim.x;   // (the transform passes, MODE >= 2: two workgroups per CU)
-    bool first_item = true;
-    for (int bidx = blockIdx.x; bidx < n_items; bidx += (int)gridDim.x) {
-    if (!first_item) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass before LDS is refilled
-    first_item = false;
     int ct_;
-    int m_blk = VOUT ? bidx / n_tiles : fdiv(bidx, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    if (VOUT) ct_ = bidx % n_tiles;
+    int m_blk = VOUT ? (int)blockIdx.x / n_tiles : fdiv((int)blockIdx.x, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    if (VOUT) ct_ = (int)blockIdx.x % n_tiles;
     int n0 = VOUT ? 0 : ct_ * 64;
     if constexpr (PREV) {
         // MODE 1 streams 18 KB of V and 36 KB of U per period through L2, and workgroup b runs on XCD b % 8 (own L2 each).
@@ -358,12 +335,12 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
         // (PMC: 22.8 GB for conv_block4.conv2 against 9.2 GB for MODE 0).  Here the 32 workgroups an XCD runs at a time are
         // 8 pixel blocks x 4 channel tiles: 8 V streams + 4 U streams = 288 KB per period per XCD, the minimum of 18 a + 36 b
         // over a b = 32 (612 KB before).  Pixel blocks are dealt round-robin to the XCDs; padding workgroups leave at once.
-        const int b = bidx, xcd = b & 7, j = b >> 3, r = j & 31, gi = j >> 5;
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3, r = j & 31, gi = j >> 5;
         const int a = g.ct_group, n_ctg = n_tiles / a;          // a channel tiles x 32 / a pixel blocks per XCD round
         const int ct = (gi % n_ctg) * a + (r % a);
         m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
         n0 = ct * 64;
-        if (m_blk >= g.n_mblocks) return;   // (MODE 1 is never persistent: one item per workgroup)
+        if (m_blk >= g.n_mblocks) return;
     }
     int cb;
     const int rb = fdiv(m_blk, g.fNCB, cb);
@@ -740,7 +717,7 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
                 --k;
             }
             W43_PERIOD(y, x, false, false)  // k = n_chunks - 1
-            if constexpr (VOUT) continue;  // every V slab is in HBM: the next item (persistent form) or the end
+            if constexpr (VOUT) return;  // every V slab is in HBM
             W43_MFMA(x, 2, 0, 0) W43_MFMA(x, 2, 1, 0) W43_MFMA(x, 2, 2, 0)
             W43_MFMA(x, 2, 0, 1) W43_MFMA(x, 2, 1, 1) W43_MFMA(x, 2, 2, 1)
         }
@@ -748,9 +725,8 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     W43_STAMP(2)
 
     w43_epilogue<TTW, POOL, false>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, 1.0f, nullptr);
-    W43_STAMP(3)
-    }   // items
     W43_CLK_END()
+    W43_STAMP(3)
 }
 
 // Winograd F(4x4,3x3) weight transform U = G g G^T (float64, rounded once), packed [cin/4][36][channel pair][cout][2].
@@ -806,37 +782,21 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup order: as MODE 1 (XCD b % 8 runs ct_group channel tiles x 32 / ct_group pixel blocks at a time)
-    // PERSISTENT form (round 6, g.n_items > 0): the grid is ONE round of workgroups (8 XCDs x 32) and every workgroup walks the items
-    // b, b + gridDim.x, ... -- the items the dispatcher would have handed its CU anyway (same XCD, same slot of the round), without
-    // the hand-over: one workgroup fits a CU (144 KB of LDS), so the CU sat idle from a workgroup's last store until the next one had
-    // been dispatched and had issued its first copies -- 3 - 13 us per ~40 - 50 us item (W43_CLK builds: 60 items x 49.6 us = 2.98 ms
-    // of a 3.54 ms launch of conv_block3.conv2).
     const int n_tiles = g.Cout / 64;
-    const int n_items = g.n_items > 0 ? g.n_items : (int)gridDim.x;
-    W43_CLK_BEGIN()
-    bool first_item = true;
-    bool prefetched = false;   // this item's slabs 0 and 1 were issued from inside the previous item's epilogue
+    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
     const int a = g.ct_group, n_ctg = n_tiles / a;
-    const int n_slabs = (g.Cin >> 5) * 9;
-    const int set = wv >> 2, w4 = wv & 3, pg = wv >> 1, nh = wv & 1;
-    // item b -> (pixel block, channel tile); false: a padding item of the last round
-    auto item_of = [&](int b_, int &m_blk_, int &ct_) {
-        const int xcd = b_ & 7, jb = b_ >> 3, r = jb & 31, gi = jb >> 5;
-        ct_ = (gi % n_ctg) * a + (r % a);
-        m_blk_ = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
-        return m_blk_ < g.n_mblocks;
-    };
-    for (int b = blockIdx.x; b < n_items; b += (int)gridDim.x) {
-    int m_blk, ct;
-    if (!item_of(b, m_blk, ct)) continue;
+    const int ct = (gi % n_ctg) * a + (r % a);
+    const int m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
     const int n0 = ct * 64;
-    if (!first_item && !prefetched) { W43_BARRIER() }   // every wave has read the previous item's last exchange pass: the ring may be refilled
-    first_item = false;
+    if (m_blk >= g.n_mblocks) return;
+    W43_CLK_BEGIN()
     int cb;
     const int rb = fdiv(m_blk, g.fNCB, cb);
     const int vtr0 = rb * TTH, tc0 = cb * TTW;
+    const int n_slabs = (g.Cin >> 5) * 9;
     const char *vbase = vsl + (int64_t)m_blk * n_slabs * S43_VPART;
     const char *ubase = usl + (int64_t)ct * n_slabs * S43_UPART;
+    const int set = wv >> 2, w4 = wv & 3, pg = wv >> 1, nh = wv & 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     const char *vw = vbase + w4 * 1024, *uw = ubase + w4 * 1024;
     const unsigned ldsw = lds0 + (unsigned)w4 * 1024u;
@@ -864,13 +824,6 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
 // 13.07 -> 12.64 ms, profiles/README.md.
 #ifndef S43_ILV
 #define S43_ILV 1
-#endif
-#ifndef S43_PREFETCH_NEXT
-#define S43_PREFETCH_NEXT 0   // persistent k_conv_wino43s: the next item's first slabs issued in front of the epilogue's store phase.  Built and
-                              // measured in round 6 (tools/prefetch_ab.sh, profiles/round6_persist_ab.txt): NEUTRAL -- 3.36 / 5.49 / 2.51 ms against
-                              // 3.39 / 5.51 / 2.45 for conv_block3.conv1 / conv2 / conv_block4.conv1, bench step 45.68 against 45.69 ms on that box:
-                              // once the workgroup is persistent its first slabs are L2 hits that land while vmcnt(0) still waits for the previous
-                              // item's stores.  Off (1: -DS43_PREFETCH_NEXT=1 builds; parity / race / stress green with it on)
 #endif
 #define S43_MFMA_P(Q, A_, B_) asm volatile("" : "+v"(acc[Q])); S43_MFMA(Q, A_, B_) asm volatile("" : "+v"(acc[Q]));
 #define S43_GAP() __builtin_amdgcn_sched_barrier(0);
@@ -916,8 +869,8 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
         W43_BARRIER()                                                                                     \
     }
 
-    if (!prefetched) { if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) } }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a prefetched item: also the previous item's output stores)
+    if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W43_BARRIER()
     h8 ahP, alP, bhP, blP;  // S43_ILV: operands of the previous period's second block
     for (int sl = 0; sl < ((S43B_ABL & 1) ? 0 : n_slabs); sl += 18) {  // Cin % 64 == 0
@@ -928,27 +881,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     if (S43_ILV && !(S43B_ABL & 5)) {  // the last period's second block (n_slabs % 18 == 0: accumulator 8)
         S43_MFMA_P(8, alP, bhP) S43_MFMA_P(8, ahP, blP) S43_MFMA_P(8, ahP, bhP)
     }
-    {
-        f32x4 Yo[4][4];
-        w43_epilogue_exchange(smem, acc, tid, pg, nh, Yo);
-        // The finish (BN, ReLU, pool, 4 - 16 stores per thread: 2 300 - 9 500 cycles) runs on registers only: once a barrier has seen
-        // every wave's last exchange read, the NEXT item's slabs 0 and 1 go out in front of it -- their latency (the ~3 000 - 4 000
-        // cycles every item used to start with) passes under the stores.  (VERDICT r5 next #2.)
-        prefetched = false;
-        int m_next, ct_next;
-        const int b_next = b + (int)gridDim.x;
-        if (S43_PREFETCH_NEXT && b_next < n_items && item_of(b_next, m_next, ct_next)) {
-            W43_BARRIER()
-            const char *vw_keep = vw, *uw_keep = uw;
-            vw = vsl + (int64_t)m_next * n_slabs * S43_VPART + w4 * 1024;
-            uw = usl + (int64_t)ct_next * n_slabs * S43_UPART + w4 * 1024;
-            if (set == 0) { S43_ISSUE(0, 0) } else { S43_ISSUE(1, 1) }
-            vw = vw_keep; uw = uw_keep;
-            prefetched = true;
-        }
-        w43_epilogue_store<TTW, POOL, true>(Yo, tid, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
-    }
-    }   // items
+    w43_epilogue<TTW, POOL, true>(smem, acc, tid, pg, nh, g, n0, vtr0, tc0, scale, shift, out, u_inv_p[0], amax);
     W43_CLK_END()
 }
 
@@ -1583,8 +1516,6 @@ static int w43_ttw(const ConvShape &c, bool pool) {
 
 template <int TTW>
 static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &lds, int64_t &blocks) {
-    g.n_items = 0;   // one item per workgroup unless a launcher sets up the persistent form
-
     constexpr int TTH = 32 / TTW;
     g = Wino43Geom{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
@@ -1698,14 +1629,6 @@ static int launch_w43(const float *in, const float *upk, const float *scale, con
                   "conv (winograd F(4x4,3x3)): %dx%d map, %d channels does not fit the kernel's staging", c.H, c.W, c.Cin);
     g.trace = trace;
     g.amax_out = amax_out;
-    if (trace == nullptr) {   // persistent form: one workgroup per CU walks the items (see the kernel); STITO_W43_PERSIST=0 = one workgroup per item
-        static const bool persist = [] { const char *e = getenv("STITO_W43_PERSIST"); return e ? atoi(e) != 0 : true; }();
-        DeviceInfo d;
-        if (persist && device_info(d) == STITO_OK && d.cus >= 8 && d.cus % 8 == 0 && d.cus % (c.Cout / 64) == 0 && blocks > d.cus && blocks < (1ll << 31)) {
-            g.n_items = (int)blocks;
-            blocks = d.cus;   // (a multiple of 8 and of the channel tiles: item b stays on XCD b % 8 and next to its patch's other tiles)
-        }
-    }
     W43_CLK_ARM(g)
     auto kern = trace ? k_conv_wino43<TTW, POOL, true> : k_conv_wino43<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1802,18 +1725,6 @@ int launch_wino43_pre(const float *in, const float *upk, const float *scale, con
     }
 }
 
-// Transform passes (MODE 3 / 4 / 5) in the persistent form: two workgroups per CU walk the (pixel block, chunk group) items.  OFF unless
-// STITO_W43T_PERSIST=1: measured neutral (tools/persist_ab.sh: eleven layers 41.08 -> 41.06 ms, bench step 45.93 -> 46.03) -- with two
-// workgroups resident per CU the other one covers a hand-over, and the passes run at the HBM roofline anyway.  -> the grid to launch
-static int64_t w43_transform_grid(Wino43Geom &gv, int64_t items) {
-    static const bool persist = [] { const char *e = getenv("STITO_W43T_PERSIST"); return e ? atoi(e) != 0 : false; }();
-    DeviceInfo d;
-    gv.n_items = 0;
-    if (!persist || device_info(d) != STITO_OK || items <= 2 * (int64_t)d.cus || items >= (1ll << 31)) return items;
-    gv.n_items = (int)items;
-    return 2 * (int64_t)d.cus;
-}
-
 // Split-precision variant of the hoisted path: stream maxima -> MODE 3 (V slabs as scaled f16 halves) -> k_conv_wino43s.
 // Workspace: the V slabs (the same bytes as MODE 2's) followed by one unsigned per stream.
 bool wino43_split_supported(const ConvShape &c, bool pool) {
@@ -1855,8 +1766,7 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
         auto kern = k_conv_wino43<TTW, POOL, false, 3>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-        const int64_t tgrid = w43_transform_grid(gv, m_blocks * ncg);   // (sets gv.n_items: before gv is copied into the launch)
-        hipLaunchKernelGGL(kern, dim3((unsigned)tgrid), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
@@ -1876,15 +1786,6 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     STITO_REQUIRE(blocks < (1ll << 31), STITO_E_UNSUPPORTED, "conv (split-precision winograd): grid");
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
-    {   // persistent form: one round of workgroups walks the items (see the kernel); STITO_W43S_PERSIST=0 = one workgroup per item
-        static const bool persist = [] { const char *e = getenv("STITO_W43S_PERSIST"); return e ? atoi(e) != 0 : true; }();
-        DeviceInfo d;
-        g.n_items = 0;
-        if (persist && device_info(d) == STITO_OK && d.cus >= 256 && blocks > 256) {
-            g.n_items = (int)blocks;
-            blocks = 256;   // 8 XCDs x 32: the round the workgroup order is built on
-        }
-    }
     W43_CLK_ARM(g)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
                        (const unsigned *)amax, u_inv);
@@ -1996,8 +1897,7 @@ static int launch_w43_split2(const float *in, const float *upk, const float *sca
         auto kern = k_conv_wino43<TTW, POOL, false, 4>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-        const int64_t tgrid = w43_transform_grid(gv, m_blocks2 * ncg);   // (sets gv.n_items: before gv is copied into the launch)
-        hipLaunchKernelGGL(kern, dim3((unsigned)tgrid), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks2 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }
@@ -2167,8 +2067,7 @@ static int launch_w43_split3(const float *in, const float *upk, const float *sca
         auto kern = k_conv_wino43<TTW, POOL, false, 5>;
         const size_t lds_t = ((size_t)2 * W43_V + 2 * W43Patch<TTW>::PFL) * sizeof(float);  // V buffers + patch buffers (no weights)
         STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-        const int64_t tgrid = w43_transform_grid(gv, m_blocks4 * ncg);   // (sets gv.n_items: before gv is copied into the launch)
-        hipLaunchKernelGGL(kern, dim3((unsigned)tgrid), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks4 * ncg)), dim3(W43_THREADS), lds_t, st, in, (const float *)nullptr,
                            (const float *)amax, (const float *)nullptr, (float *)ws, gv);
         STITO_LAUNCH_CHECK();
     }

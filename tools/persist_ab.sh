@@ -1,9 +1,12 @@
-# persistent workgroups (k_conv_wino43s, the f32 k_conv_wino43, the transform passes) against one workgroup per item: per-layer times
-# (conv_bench, production mix, random data) and the bench line
+# persistent k_conv_wino43s (item body as a non-inlined function) against the PRE-PERSISTENCE library (tools/build_rev_lib.sh 8fdea21 prepersist)
+# and against this library with one workgroup per item: per-layer times (conv_bench, production mix, random data) and the bench line, same box
 cd $GRAFT_REPO_ROOT
-for p in "0 0 0" "1 1 0" "1 1 1"; do
-  set -- $p
-  echo "== STITO_W43S_PERSIST=$1 STITO_W43_PERSIST=$2 STITO_W43T_PERSIST=$3"
-  STITO_W43S_PERSIST=$1 STITO_W43_PERSIST=$2 STITO_W43T_PERSIST=$3 python tools/conv_bench.py --streams 512 --modes 100 --reps 7 2>/dev/null | grep -vE "^layer|amdgpu"
-  STITO_W43S_PERSIST=$1 STITO_W43_PERSIST=$2 STITO_W43T_PERSIST=$3 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-pop512 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('bench', d['value'], d['ms_per_step'], d['last_fitness_sha16'])"
-done
+run() {
+  echo "== $1"
+  python tools/conv_bench.py --streams 512 --modes 100 --reps 7 2>/dev/null | grep -E "234x64 128|117x32|58x16 256|total" | tr '\n' ' '; echo
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-pop512 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('bench', d['value'], d['ms_per_step'], d['last_fitness_sha16'])"
+}
+STITO_LIB_PATH=st-ito_amd/st_ito/_lib/ab/libstito_hip_prepersist.so run "pre-persistence library (8fdea21)"
+STITO_W43S_PERSIST=0 STITO_W43_PERSIST=0 run "this library, one workgroup per item"
+run "this library, persistent (default)"
+STITO_LIB_PATH=st-ito_amd/st_ito/_lib/ab/libstito_hip_prepersist.so run "pre-persistence library (8fdea21), again"
