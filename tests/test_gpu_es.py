@@ -741,6 +741,22 @@ def test_bench_gpus2_self_launches_its_ranks(dev):
     assert st["evaluate_ms"]["max"] + st["gather_ms"]["min"] <= 1.05 * d["ms_per_step"] + 5.0 and "rccl_version" in st
 
 
+def test_bench_config_switch_runs_the_8gpu_configurations_at_one_gpu(dev):
+    """`bench.py --config 3 / 4` = BASELINE.json's two 8-GPU configurations as one command each (their per-GPU share
+    at any --gpus).  Here at N = 1 with the population and the length cut down so that the suite stays short: same JSON schema, the
+    workload string names the BASELINE entry, configs[4] really has the 96 000-tap convolution reverb in its chain (D = 66)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for cfg, D, word in ((3, 45, "pop=2048 sharded 256/GPU"), (4, 66, "convolution-reverb IR=2 s")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(cfg), "--steps", "1", "--warmup", "1", "--pop-per-gpu", "6",
+                              "--seconds", "4", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["baseline_config"] == cfg and word in d["config"]["workload"]
+        assert f"(D={D})" in d["config"]["workload"] and ("NoiseShapedReverb(96000 taps)" in d["config"]["chain"]) == (cfg == 4)
+        assert "north_star_pop512" not in d and d["vs_baseline"] is None
+
+
 def test_one_rank_rccl_group_runs_the_collective_branch(dev):
     """RCCL itself has to execute once before a first 8-GPU run.  bench.py with STITO_BENCH_FORCE_DIST=1 at
     N = 1 builds the one-rank `nccl` process group bound to cuda:0 (communicator creation, device binding) and sends every
