@@ -95,6 +95,7 @@ struct Wino43Geom {
     int n_cgroups;     // MODE 2 only: workgroups that share a pixel block's chunks between them (1 otherwise)
     int n_mblocks;     // pixel blocks (MODE 1: the grid is padded to whole XCD rounds)
     int ct_group;      // MODE 1: channel tiles that run side by side on one XCD (a power of two dividing Cout / 64, <= 32)
+    int b0;            // k_conv_wino43s: index of the launch's first workgroup item (a layer launched as two grids on two streams: 0 and the split point)
     int xcd_m;         // k_conv_wino43s3: the 8 XCDs as xcd_m pixel-block classes x 8 / xcd_m channel-tile ranges (8 = the other kernels' order)
     FDiv fH, fTR, fNCB, fNT;  // H, TR, n_col_blocks, Cout / 64 as launch-constant divisors (fdiv)
     long long *trace;  // TRACE instantiation only
@@ -326,8 +327,9 @@ __global__ __launch_bounds__(W43_THREADS, MODE >= 2 ? 4 : 2) void k_conv_wino43(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = VOUT ? g.n_cgroups : g.Cout / 64;
     int ct_;
-    int m_blk = VOUT ? (int)blockIdx.x / n_tiles : fdiv((int)blockIdx.x, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
-    if (VOUT) ct_ = (int)blockIdx.x % n_tiles;
+    const int bidx = (int)blockIdx.x + (MODE == 0 ? g.b0 : 0);   // (MODE 0 may be launched as several grids: w43_multi_queue_launch)
+    int m_blk = VOUT ? bidx / n_tiles : fdiv(bidx, g.fNT, ct_);  // channel tile fastest: the workgroups sharing a halo patch run side by side
+    if (VOUT) ct_ = bidx % n_tiles;
     int n0 = VOUT ? 0 : ct_ * 64;
     if constexpr (PREV) {
         // MODE 1 streams 18 KB of V and 36 KB of U per period through L2, and workgroup b runs on XCD b % 8 (own L2 each).
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(W43_THREADS) void k_conv_wino43s(const char *__rest
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup order: as MODE 1 (XCD b % 8 runs ct_group channel tiles x 32 / ct_group pixel blocks at a time)
     const int n_tiles = g.Cout / 64;
-    const int b = blockIdx.x, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
+    const int b = (int)blockIdx.x + g.b0, xcd = b & 7, jb = b >> 3, r = jb & 31, gi = jb >> 5;
     const int a = g.ct_group, n_ctg = n_tiles / a;
     const int ct = (gi % n_ctg) * a + (r % a);
     const int m_blk = ((gi / n_ctg) * (32 / a) + r / a) * 8 + xcd;
@@ -1516,6 +1518,8 @@ static int w43_ttw(const ConvShape &c, bool pool) {
 
 template <int TTW>
 static bool w43_geometry(const ConvShape &c, bool pool, Wino43Geom &g, size_t &lds, int64_t &blocks) {
+    g.b0 = 0;
+
     constexpr int TTH = 32 / TTW;
     g = Wino43Geom{};
     g.S = c.S; g.H = c.H; g.W = c.W; g.Cin = c.Cin; g.Cout = c.Cout;
@@ -1619,6 +1623,54 @@ static void w43_clk_report(const char *what, const ConvShape &c, hipStream_t) {
 #define W43_CLK_REPORT(WHAT, C, ST)
 #endif
 
+// One workgroup of k_conv_wino43s / the f32 k_conv_wino43 fills a CU (138 - 148 KB of LDS, 240 - 256 registers per lane), so between a
+// workgroup's last store and the next one's first copies the CU idles: W43_CLK stamps put 3 - 13 us of it between 40 - 50 us workgroups
+// (DESIGN 4.3).  Keeping the workgroup alive instead (a persistent item loop) was built three times in round 6 and lost every time to the
+// register allocation of the main loop.  What does NOT touch the kernel: launching the layer as N grids on N streams -- N hardware queues,
+// each with a dispatcher of its own, so that when a CU falls free one of them usually has a workgroup ready.  Grid q takes the items
+// [b0_q, b0_q + n_q) (whole XCD rounds of 256), the side streams fork from and join `st` by events (graph-capturable; the suite replays it),
+// results are bit for bit those of one grid (an item does not know which grid it rode in).  STITO_W43_QUEUES = N for k_conv_wino43s (default 2; 1 = one
+// grid), STITO_W43_QUEUES_F32 for the f32 kernel (default 1: measured neutral).
+template <class LAUNCH>
+static int w43_multi_queue_launch(int64_t blocks, hipStream_t st, LAUNCH &&launch, bool f32_kernel = false) {
+    constexpr int MAXQ = 4, MAXDEV = 64;
+    // (read per launch: the tests flip them)  Measured (tools/dual_grid_ab.sh, bench step, alternating runs on one box): k_conv_wino43s 1 -> 2 queues
+    // 43.36 / 42.80 / 43.25 -> 42.97 / 42.42 / 42.80 ms; 3 and 4 queues 42.98 / 43.05; the f32 kernel neutral (43.23 / 42.82 / 43.35 with two): one grid
+    const char *e_ = getenv(f32_kernel ? "STITO_W43_QUEUES_F32" : "STITO_W43_QUEUES");
+    int nq = e_ ? atoi(e_) : (f32_kernel ? 1 : 2);
+    nq = nq < 1 ? 1 : (nq > MAXQ ? MAXQ : nq);
+    while (nq > 1 && blocks / nq < 512) --nq;   // at least two XCD rounds per grid
+    if (nq <= 1) {
+        launch(blocks, 0, st);
+        return STITO_OK;
+    }
+    struct Side { hipStream_t q[MAXQ - 1]; hipEvent_t fork, join[MAXQ - 1]; bool ready; };
+    static Side sides[MAXDEV];
+    int dev = 0;
+    STITO_HIP_CHECK(hipGetDevice(&dev));
+    STITO_REQUIRE(dev >= 0 && dev < MAXDEV, STITO_E_UNSUPPORTED, "device index %d", dev);
+    Side &sd = sides[dev];
+    if (!sd.ready) {   // (one host thread drives a GPU: created on first use, kept for the life of the process)
+        STITO_HIP_CHECK(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+        for (int i = 0; i < MAXQ - 1; ++i) {
+            STITO_HIP_CHECK(hipStreamCreateWithFlags(&sd.q[i], hipStreamNonBlocking));
+            STITO_HIP_CHECK(hipEventCreateWithFlags(&sd.join[i], hipEventDisableTiming));
+        }
+        sd.ready = true;
+    }
+    const int64_t per = (blocks / nq) / 256 * 256;
+    STITO_HIP_CHECK(hipEventRecord(sd.fork, st));
+    for (int i = 1; i < nq; ++i) STITO_HIP_CHECK(hipStreamWaitEvent(sd.q[i - 1], sd.fork, 0));
+    launch(per, 0, st);
+    for (int i = 1; i < nq; ++i) {
+        const int64_t b0 = per * i, n = i == nq - 1 ? blocks - b0 : per;
+        launch(n, (int)b0, sd.q[i - 1]);
+        STITO_HIP_CHECK(hipEventRecord(sd.join[i - 1], sd.q[i - 1]));
+    }
+    for (int i = 1; i < nq; ++i) STITO_HIP_CHECK(hipStreamWaitEvent(st, sd.join[i - 1], 0));
+    return STITO_OK;
+}
+
 template <int TTW, bool POOL>
 static int launch_w43(const float *in, const float *upk, const float *scale, const float *shift, float *out, const ConvShape &c,
                       long long *trace, hipStream_t st, unsigned *amax_out) {
@@ -1632,7 +1684,15 @@ static int launch_w43(const float *in, const float *upk, const float *scale, con
     W43_CLK_ARM(g)
     auto kern = trace ? k_conv_wino43<TTW, POOL, true> : k_conv_wino43<TTW, POOL, false>;
     STITO_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g);
+    if (trace != nullptr || (256 % (c.Cout / 64)) != 0) {   // (the timeline build stamps by blockIdx; grids are cut at multiples of 256 items = whole pixel blocks)
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds, st, in, upk, scale, shift, out, g);
+    } else {
+        STITO_TRY(w43_multi_queue_launch(blocks, st, [&](int64_t n_blk, int b0, hipStream_t q) {
+            Wino43Geom gq = g;
+            gq.b0 = b0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_blk), dim3(W43_THREADS), lds, q, in, upk, scale, shift, out, gq);
+        }, true));
+    }
     STITO_LAUNCH_CHECK();
     W43_CLK_REPORT("k_conv_wino43 (f32 MFMA)", c, st)
     return STITO_OK;
@@ -1787,8 +1847,13 @@ static int launch_w43_split(const float *in, const float *upk, const float *scal
     g.amax_out = amax_out;
     const float *u_inv = upk + (size_t)36 * c.Cout * c.Cin + 1;
     W43_CLK_ARM(g)
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W43_THREADS), lds1, st, (const char *)ws, (const char *)upk, scale, shift, out, g,
-                       (const unsigned *)amax, u_inv);
+    // the layer as several grids on several hardware queues (w43_multi_queue_launch): the queues' dispatchers overlap the hand-over
+    STITO_TRY(w43_multi_queue_launch(blocks, st, [&](int64_t n_blk, int b0, hipStream_t q) {
+        Wino43Geom gq = g;
+        gq.b0 = b0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_blk), dim3(W43_THREADS), lds1, q, (const char *)ws, (const char *)upk, scale, shift, out, gq,
+                           (const unsigned *)amax, u_inv);
+    }));
     STITO_LAUNCH_CHECK();
     W43_CLK_REPORT("k_conv_wino43s (f16 MFMA)", c, st)
     return STITO_OK;

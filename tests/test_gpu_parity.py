@@ -808,6 +808,40 @@ def test_conv_sweep_split_and_xcd_order_are_bitwise_neutral(dev, n, H, W, cin, c
             assert torch.equal(out, ref), (m, env, rep)
 
 
+@pytest.mark.parametrize("algo,n,H,W,cin,cout,pool", [(4, 64, 117, 32, 128, 256, 0), (4, 40, 117, 32, 256, 256, 1), (2, 24, 234, 64, 128, 128, 1)])
+def test_conv_layer_as_several_grids_on_several_queues_is_bitwise_one_grid(dev, algo, n, H, W, cin, cout, pool, monkeypatch):
+    """Round 6: k_conv_wino43s launches a layer as TWO grids on two streams (two hardware queues overlap the hand-over between the
+    one-per-CU workgroups: bench step - 0.4 ms; the f32 kernel can do the same, STITO_W43_QUEUES_F32).  An item does not know which
+    grid it rode in: 1, 2, 3 and 4 queues must return the same bits, launch after launch (the side streams fork from and join the
+    caller's stream by events: a missing join would show as a stale or torn output)."""
+    from st_ito import _hip
+    L = _hip.lib()
+    st = _hip.stream_ptr()
+    g = torch.Generator().manual_seed(H + cin)
+    x = torch.relu(torch.randn((n, cin // 8, H, W, 8), generator=g)).to(dev)
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)).to(dev)
+    sc = (0.5 + torch.rand(cout, generator=g)).to(dev); sh = (0.1 * torch.randn(cout, generator=g)).to(dev)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    assert L.stito_conv3x3_supported(n, H, W, cin, cout, pool, algo)
+    packed = torch.empty(L.stito_cnn14_packed_conv_floats(cout, cin, algo), device=dev)
+    _hip.check(L.stito_cnn14_pack_conv(_hip.ptr(w), cout, cin, algo, _hip.ptr(packed), st))
+    wsb = L.stito_conv3x3_workspace_bytes(n, H, W, cin, cout, pool, algo)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    ref = None
+    for q in ("1", "2", "3", "4", "2"):
+        monkeypatch.setenv("STITO_W43_QUEUES", q)
+        monkeypatch.setenv("STITO_W43_QUEUES_F32", q)
+        for rep in range(5):
+            out = torch.full((n, cout // 8, Ho, Wo, 8), float("nan"), device=dev)
+            _hip.check(L.stito_conv3x3_bn_relu_ws(_hip.ptr(x), _hip.ptr(packed), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(out), n, H, W, cin, cout, pool, algo,
+                                                  _hip.ptr(ws), wsb, st))
+            x2 = out.clone()   # (a consumer on the caller's stream right behind the launch: it must see the joined result)
+            if ref is None:
+                ref = x2
+                assert not torch.isnan(ref).any()
+            assert torch.equal(x2, ref), (q, rep)
+
+
 def test_trunk_small_batches_take_the_two_sweep_packing(dev):
     """The six-sweep kernel's workgroups are four times the two-sweep kernel's: a batch that gives it fewer than 3 / 4 workgroup per
     CU (anything below ~380 streams for conv_block6) runs the two-sweep kernel from the alternative packing the model carries
