@@ -20,7 +20,10 @@
  *
  * Conventions: every pointer named *_dev is a device pointer owned by the caller (PyTorch in
  * the Python host); `stream` is a hipStream_t passed as void*; all work is enqueued on that
- * stream and nothing synchronises.  Functions return 0 on success and a negative STITO_E_*
+ * stream -- or, for the streaming convolutions of stito_cnn14_forward / stito_conv3x3_bn_relu_ws
+ * (ABI version 10), on library-owned side streams forked from and joined to it by events, so the
+ * caller sees one stream's ordering and a hipGraph capture of `stream` captures them too -- and
+ * nothing synchronises.  Functions return 0 on success and a negative STITO_E_*
  * code otherwise; stito_last_error() returns a thread-local message for the last failure.
  * No torch types appear here.  There is no CPU fallback: without a HIP device the calls fail.
  */
