@@ -86,6 +86,10 @@ for i, (name, _, _) in enumerate(f):
     if "k_w23_mel_params" in name:
         continue
     if mode_of(name) in (0, 1) or "k_conv_wino43s" in name or "wino43" not in name or "k_conv_wino23r" in name:
+        # (round 6: a k_conv_wino43s layer is launched as several grids on several queues -- consecutive dispatches of the SAME
+        # instantiation are one layer; two different layers never follow each other without a transform pass in between)
+        if i + 1 < len(f) and f[i + 1][0] == name and "k_conv_wino43" in name:
+            continue
         layers.append(cur)
         cur = []
 assert not cur and len(layers) == len(shapes), (len(layers), len(shapes), [x[0][:40] for x in f])
