@@ -20,7 +20,16 @@ for path in sys.argv[1:]:
     import re
     fam = {"f32": [0, 0.0], "f16-stream": [0, 0.0], "f16-reg": [0, 0.0]}   # bench.py's roofline families
     n_tr, t_tr = 0, 0.0
-    for name, dur in cur.execute("select name, end-start from kernels where name like '%k_conv_wino%' or name like '%k_conv3x3%'"):
+    # (round 6: a k_conv_wino43s layer runs as several grids on several queues -- dispatches of the same instantiation that OVERLAP in time
+    # are one layer, from the first one's start to the last one's end)
+    merged = []
+    for name, t0, t1 in cur.execute("select name, start, end from kernels where name like '%k_conv_wino%' or name like '%k_conv3x3%' order by start"):
+        if merged and merged[-1][0] == name and t0 < merged[-1][2] and "k_conv_wino43s<" in name:
+            merged[-1][2] = max(merged[-1][2], t1)
+        else:
+            merged.append([name, t0, t1])
+    for name, t0, t1 in merged:
+        dur = t1 - t0
         m = re.search(r"k_conv_wino43<([^>]*)>", name)
         mode = int(m.group(1).split(",")[-1]) if m and len(m.group(1).split(",")) >= 4 else 0
         if mode in (2, 3, 4, 5):
